@@ -1,0 +1,118 @@
+// ball_query.hip -- radius neighbour search for gfx950.
+//
+// Replaces ball_query_kernel_fast (reference ball_query_gpu.cu:9-66), which runs one thread
+// per centroid scanning all N points from global memory.  Here:
+//   * the cloud is staged ONCE per workgroup into LDS as SoA x[]/y[]/z[] tiles
+//     (conflict-free ds_read_b32 across lanes), coalesced from the AoS HBM layout;
+//   * one WAVE per centroid: the 64 lanes test 64 consecutive candidates, a ballot plus
+//     mbcnt prefix-popcount appends the hits in ascending index order (the reference's
+//     serial scan order), and the wave leaves the scan as soon as nsample hits are found;
+//   * every element of the output row is written (hits, then first-hit padding, or zeros),
+//     so the caller does not have to pre-zero idx (pointnet2_utils.py:262).
+#include "pn2_common.h"
+
+namespace pn2 {
+
+constexpr int kBqThreads = 256;
+constexpr int kBqWaves = kBqThreads / kWave;
+constexpr int kBqTile = 4096;  // points per LDS tile: 48 KiB -> 3 workgroups / CU
+
+template <int CPW>  // centroids per wave
+__global__ void __launch_bounds__(kBqThreads)
+ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz_all,
+                  const float *__restrict__ xyz_all, int *__restrict__ idx_all) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tile_cap = n < kBqTile ? n : kBqTile;
+    float *sx = smem, *sy = smem + tile_cap, *sz = smem + 2 * tile_cap;
+
+    const int b = blockIdx.y;
+    const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
+    const float *__restrict__ new_xyz = new_xyz_all + (size_t)b * m * 3;
+    int *__restrict__ idx = idx_all + (size_t)b * m * nsample;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int c_base = blockIdx.x * (kBqWaves * CPW);
+
+    float cx[CPW], cy[CPW], cz[CPW];
+    int cnt[CPW], first[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int s = c_base + c * kBqWaves + w;
+        const bool ok = s < m;
+        cx[c] = ok ? new_xyz[3 * s + 0] : 0.f;
+        cy[c] = ok ? new_xyz[3 * s + 1] : 0.f;
+        cz[c] = ok ? new_xyz[3 * s + 2] : 0.f;
+        cnt[c] = ok ? 0 : nsample;  // out-of-range centroids are "done"
+        first[c] = 0;
+    }
+
+    for (int t0 = 0; t0 < n; t0 += kBqTile) {
+        const int tn = (n - t0) < kBqTile ? (n - t0) : kBqTile;
+        if (t0 > 0) __syncthreads();
+        // AoS (12 B/pt) -> SoA; 3*tn consecutive floats read coalesced.
+        for (int i = tid; i < 3 * tn; i += kBqThreads) {
+            const float v = xyz[(size_t)3 * t0 + i];
+            const int p = i / 3, comp = i - 3 * p;
+            (comp == 0 ? sx : comp == 1 ? sy : sz)[p] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int s = c_base + c * kBqWaves + w;
+            int *__restrict__ row = idx + (size_t)s * nsample;
+            int mycnt = cnt[c];
+            if (mycnt >= nsample) continue;  // wave-uniform
+            for (int base = 0; base < tn; base += kWave) {
+                const int p = base + lane;
+                const bool in = p < tn;
+                const float x = in ? sx[p] : 0.f, y = in ? sy[p] : 0.f, z = in ? sz[p] : 0.f;
+                const float d2 = sqdist(cx[c], cy[c], cz[c], x, y, z);
+                const bool hit = in && (d2 < radius2);
+                const uint64_t mask = __ballot(hit);
+                if (mask) {
+                    if (mycnt == 0) first[c] = t0 + base + __builtin_ctzll(mask);
+                    const int pos = mycnt + prefix_popc(mask);
+                    if (hit && pos < nsample) row[pos] = t0 + p;
+                    mycnt += __builtin_popcountll(mask);
+                    if (mycnt >= nsample) break;
+                }
+            }
+            cnt[c] = mycnt;
+        }
+    }
+    // padding (ball_query_gpu.cu:35-39: slots beyond the hits repeat the first hit; no hit -> 0)
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int s = c_base + c * kBqWaves + w;
+        if (s >= m) continue;
+        int *__restrict__ row = idx + (size_t)s * nsample;
+        const int fill = cnt[c] > 0 ? first[c] : 0;
+        for (int p = cnt[c] + lane; p < nsample; p += kWave) row[p] = fill;
+    }
+}
+
+int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                        const float *xyz, int *idx, hipStream_t st) {
+    if (b == 0 || m == 0) return PN2_OK;
+    const float radius2 = radius * radius;  // fp32 product, ball_query_gpu.cu:23
+    const int tile_cap = n < kBqTile ? n : kBqTile;
+    const size_t lds = (size_t)3 * tile_cap * sizeof(float);
+    // pick centroids/wave so the grid still oversubscribes 256 CUs when it can
+    const long total = (long)b * m;
+    int cpw = 1;
+    if (total >= 4L * kBqWaves * 4096) cpw = 4;
+    else if (total >= 2L * kBqWaves * 2048) cpw = 2;
+    const int per_block = kBqWaves * cpw;
+    dim3 grid((m + per_block - 1) / per_block, b);
+    if (cpw == 4)
+        hipLaunchKernelGGL(ball_query_kernel<4>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx);
+    else if (cpw == 2)
+        hipLaunchKernelGGL(ball_query_kernel<2>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx);
+    else
+        hipLaunchKernelGGL(ball_query_kernel<1>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx);
+    return check_launch();
+}
+
+}  // namespace pn2

@@ -1,0 +1,143 @@
+// capi.hip -- extern "C" entry points of libpn2_hip.so (declared in include/pn2_hip.h).
+// Argument validation + dispatch only; kernels live in the sibling .hip files.
+#include <stdlib.h>
+
+#include "pn2_common.h"
+
+namespace pn2 {
+static thread_local int g_last_hip_error = 0;
+void set_last_hip_error(int e) { g_last_hip_error = e; }
+
+int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t st, int force_threads);
+int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                        int *idx, hipStream_t st);
+int three_nn_dispatch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                      hipStream_t st);
+int knn_dispatch(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2, int *idx,
+                 hipStream_t st);
+int group_fwd_dispatch(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,
+                       float *out, hipStream_t st);
+int group_bwd_dispatch(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                       float *grad_points, hipStream_t st);
+int interp_fwd_dispatch(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                        float *out, hipStream_t st);
+int interp_bwd_dispatch(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
+                        float *grad_points, hipStream_t st);
+}  // namespace pn2
+
+using namespace pn2;
+
+#define PN2_REQ(cond, code) \
+    do {                    \
+        if (!(cond)) return (code); \
+    } while (0)
+
+static inline bool fits_int(long v) { return v >= 0 && v <= 2147483647L; }
+
+extern "C" {
+
+int pn2_abi_version(void) { return 1; }
+
+int pn2_last_hip_error(void) { return g_last_hip_error; }
+
+const char *pn2_strerror(int code) {
+    switch (code) {
+        case PN2_OK: return "ok";
+        case PN2_EINVAL: return "invalid dimension or parameter";
+        case PN2_ENULL: return "required pointer is NULL";
+        case PN2_ERANGE: return "size outside the supported range";
+        case PN2_ESCRATCH: return "this size needs the scratch buffer (temp) to be provided";
+        case PN2_ELAUNCH: return "HIP kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+int pn2_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx, void *stream) {
+    PN2_REQ(b >= 0 && n >= 1 && m >= 0, PN2_EINVAL);
+    if (b == 0 || m == 0) return PN2_OK;
+    PN2_REQ(xyz && idx, PN2_ENULL);
+    PN2_REQ(b <= 65535 * 32768L, PN2_ERANGE);
+    PN2_REQ(fits_int((long)n * 3), PN2_ERANGE);
+    int force = 0;
+    if (const char *e = getenv("PN2_FPS_THREADS")) force = atoi(e);  // tuning/experiments only
+    return fps_dispatch(b, n, m, xyz, temp, idx, (hipStream_t)stream, force);
+}
+
+int pn2_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                   int *idx, void *stream) {
+    PN2_REQ(b >= 0 && n >= 1 && m >= 0 && nsample >= 1, PN2_EINVAL);
+    PN2_REQ(radius == radius, PN2_EINVAL);  // NaN radius
+    if (b == 0 || m == 0) return PN2_OK;
+    PN2_REQ(new_xyz && xyz && idx, PN2_ENULL);
+    PN2_REQ(b <= 65535, PN2_ERANGE);
+    PN2_REQ(fits_int((long)n * 3) && fits_int((long)m * nsample), PN2_ERANGE);
+    return ball_query_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
+}
+
+int pn2_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,
+                     float *out, void *stream) {
+    PN2_REQ(b >= 0 && c >= 0 && n >= 1 && npoints >= 0 && nsample >= 0, PN2_EINVAL);
+    if (b == 0 || c == 0 || npoints == 0 || nsample == 0) return PN2_OK;
+    PN2_REQ(points && idx && out, PN2_ENULL);
+    PN2_REQ(b <= 65535 && fits_int((long)npoints * nsample), PN2_ERANGE);
+    return group_fwd_dispatch(b, c, n, npoints, nsample, points, idx, out, (hipStream_t)stream);
+}
+
+int pn2_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                          float *grad_points, void *stream) {
+    PN2_REQ(b >= 0 && c >= 0 && n >= 1 && npoints >= 0 && nsample >= 0, PN2_EINVAL);
+    if (b == 0 || c == 0 || npoints == 0 || nsample == 0) return PN2_OK;
+    PN2_REQ(grad_out && idx && grad_points, PN2_ENULL);
+    PN2_REQ(b <= 65535 && c <= 65535 * 16 && fits_int((long)npoints * nsample), PN2_ERANGE);
+    return group_bwd_dispatch(b, c, n, npoints, nsample, grad_out, idx, grad_points, (hipStream_t)stream);
+}
+
+int pn2_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx, float *out,
+                      void *stream) {
+    return pn2_group_points(b, c, n, npoints, 1, points, idx, out, stream);
+}
+
+int pn2_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
+                           float *grad_points, void *stream) {
+    return pn2_group_points_grad(b, c, n, npoints, 1, grad_out, idx, grad_points, stream);
+}
+
+int pn2_knn(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2, int *idx,
+            void *stream) {
+    PN2_REQ(b >= 0 && n >= 0 && m >= 0, PN2_EINVAL);
+    PN2_REQ(k >= 1, PN2_EINVAL);
+    PN2_REQ(k <= PN2_KNN_MAX_K, PN2_ERANGE);
+    if (b == 0 || n == 0) return PN2_OK;
+    PN2_REQ(unknown && dist2 && idx && (known || m == 0), PN2_ENULL);
+    PN2_REQ(b <= 65535 && fits_int((long)n * k) && fits_int((long)m * 3), PN2_ERANGE);
+    return knn_dispatch(b, n, m, k, unknown, known, dist2, idx, (hipStream_t)stream);
+}
+
+int pn2_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                 void *stream) {
+    PN2_REQ(b >= 0 && n >= 0 && m >= 0, PN2_EINVAL);
+    if (b == 0 || n == 0) return PN2_OK;
+    PN2_REQ(unknown && dist2 && idx && (known || m == 0), PN2_ENULL);
+    PN2_REQ(b <= 65535 && fits_int((long)n * 3) && fits_int((long)m * 3), PN2_ERANGE);
+    return three_nn_dispatch(b, n, m, unknown, known, dist2, idx, (hipStream_t)stream);
+}
+
+int pn2_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                          float *out, void *stream) {
+    PN2_REQ(b >= 0 && c >= 0 && m >= 1 && n >= 0, PN2_EINVAL);
+    if (b == 0 || c == 0 || n == 0) return PN2_OK;
+    PN2_REQ(points && idx && weight && out, PN2_ENULL);
+    PN2_REQ(b <= 65535 && fits_int((long)n * 3), PN2_ERANGE);
+    return interp_fwd_dispatch(b, c, m, n, points, idx, weight, out, (hipStream_t)stream);
+}
+
+int pn2_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                               const float *weight, float *grad_points, void *stream) {
+    PN2_REQ(b >= 0 && c >= 0 && m >= 1 && n >= 0, PN2_EINVAL);
+    if (b == 0 || c == 0 || n == 0) return PN2_OK;
+    PN2_REQ(grad_out && idx && weight && grad_points, PN2_ENULL);
+    PN2_REQ(b <= 65535 && c <= 65535 * 16 && fits_int((long)n * 3), PN2_ERANGE);
+    return interp_bwd_dispatch(b, c, n, m, grad_out, idx, weight, grad_points, (hipStream_t)stream);
+}
+
+}  // extern "C"

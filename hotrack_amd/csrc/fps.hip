@@ -1,0 +1,240 @@
+// fps.hip -- furthest point sampling for gfx950 (MI355X).
+//
+// Replaces furthest_point_sampling_kernel / _launcher (reference sampling_gpu.cu:94-253).
+// Design (not a translation of the CUDA kernel):
+//   * one workgroup per cloud (the M-step dependency chain is inherent);
+//   * every point and its running min-distance live in VGPRs for the whole kernel --
+//     no `temp` traffic to HBM, xyz is read exactly once;
+//   * points are laid out over (thread, slot) in the ORDER OF THE REFERENCE'S TIE KEY
+//     (bitrev(k mod bs), k div bs), so "first maximum in my own order" is exactly the
+//     reference's shared-memory tree winner (sampling_gpu.cu:86-91,143-203) and the
+//     arg-max needs no index in the reduction: wave max via 6 DPP steps on the fp32 bit
+//     pattern, a ballot + s_ff1 picks the first lane holding the max;
+//   * the winning lane of each wave publishes (dist, k[, x, y, z]) to LDS; ONE barrier per
+//     iteration (double-buffered by iteration parity; the reference needs 11);
+//   * all waves redundantly combine the <=16 wave candidates with DPP inside one row and
+//     pull the winner's coordinates into SGPRs with v_readlane.
+#include "pn2_common.h"
+
+namespace pn2 {
+
+enum { kCentEntry = 0, kCentLds = 1, kCentGlobal = 2 };
+
+template <int T, int P, int CENT>
+__global__ void __launch_bounds__(T)
+fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_all, int *__restrict__ idx_all) {
+    constexpr int W = T / kWave;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // entries: [parity][field][wave]   field: 0 dist, 1 k, 2 x, 3 y, 4 z
+    float *ent = smem;
+    float *lxyz = smem + 2 * 5 * 16;
+
+    const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    int *__restrict__ idx = idx_all + (size_t)blockIdx.x * m;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+
+    float px[P], py[P], pz[P], pt[P];
+    int pk[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int s = tid * P + j;
+        const int bslot = s / Q;
+        const int q = s - bslot * Q;
+        const unsigned rev = lg ? (__builtin_bitreverse32((unsigned)bslot) >> (32 - lg)) : 0u;
+        const int k = (int)rev + q * bs;
+        const bool valid = (bslot < bs) && (k < n);
+        pk[j] = valid ? k : 0;
+        px[j] = valid ? xyz[3 * k + 0] : 0.f;
+        py[j] = valid ? xyz[3 * k + 1] : 0.f;
+        pz[j] = valid ? xyz[3 * k + 2] : 0.f;
+        pt[j] = valid ? 1e10f : -1.0f;  // padded slots can never win (all real dists >= 0)
+    }
+    if constexpr (CENT == kCentLds) {
+        for (int i = tid; i < 3 * n; i += T) lxyz[i] = xyz[i];
+    }
+    float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+    if (tid == 0) idx[0] = 0;
+    if constexpr (CENT == kCentLds) __syncthreads();
+
+    for (int it = 1; it < m; ++it) {
+        float best;
+        int bestk;
+        if constexpr (P == 1) {
+            const float d = sqdist(px[0], py[0], pz[0], cx, cy, cz);
+            pt[0] = fmin_raw(d, pt[0]);
+            best = pt[0];
+            bestk = pk[0];
+        } else {
+            best = -1.0f;
+            bestk = 0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const float d = sqdist(px[j], py[j], pz[j], cx, cy, cz);
+                const float tt = fmin_raw(d, pt[j]);
+                pt[j] = tt;
+                const bool gt = tt > best;  // strict: first (lowest tie-rank) maximum wins
+                bestk = gt ? pk[j] : bestk;
+                best = gt ? tt : best;
+            }
+        }
+        // fp32 >= 0 (or exactly -1.0f) orders like its bit pattern as a signed int.
+        const int bi = f2i(best);
+        const int wmax = wave_max_i32(bi);
+        const uint64_t tie = __ballot(bi == wmax);
+        const int wl = __builtin_ctzll(tie);  // first lane == lowest tie rank in this wave
+
+        int kstar;
+        if constexpr (W == 1) {
+            kstar = __builtin_amdgcn_readlane(bestk, wl);
+            if constexpr (CENT == kCentEntry) {
+                cx = i2f(__builtin_amdgcn_readlane(f2i(px[0]), wl));
+                cy = i2f(__builtin_amdgcn_readlane(f2i(py[0]), wl));
+                cz = i2f(__builtin_amdgcn_readlane(f2i(pz[0]), wl));
+            }
+        } else {
+            float *e = ent + (it & 1) * (5 * 16);
+            if (lane == wl) {
+                e[0 * 16 + w] = best;
+                e[1 * 16 + w] = i2f(bestk);
+                if constexpr (CENT == kCentEntry) {
+                    e[2 * 16 + w] = px[0];
+                    e[3 * 16 + w] = py[0];
+                    e[4 * 16 + w] = pz[0];
+                }
+            }
+            __syncthreads();
+            const int sl = lane & (W - 1);
+            const int ev = f2i(e[0 * 16 + sl]);
+            const int ek = f2i(e[1 * 16 + sl]);
+            int ex = 0, ey = 0, ez = 0;
+            if constexpr (CENT == kCentEntry) {
+                ex = f2i(e[2 * 16 + sl]);
+                ey = f2i(e[3 * 16 + sl]);
+                ez = f2i(e[4 * 16 + sl]);
+            }
+            const int gmax = __builtin_amdgcn_readfirstlane(row_group_max_i32<W>(ev));
+            const uint64_t tie2 = __ballot(ev == gmax);
+            const int wl2 = __builtin_ctzll(tie2);  // lanes 0..W-1 hold waves 0..W-1: lowest wave wins
+            kstar = __builtin_amdgcn_readlane(ek, wl2);
+            if constexpr (CENT == kCentEntry) {
+                cx = i2f(__builtin_amdgcn_readlane(ex, wl2));
+                cy = i2f(__builtin_amdgcn_readlane(ey, wl2));
+                cz = i2f(__builtin_amdgcn_readlane(ez, wl2));
+            }
+        }
+        if (tid == 0) idx[it] = kstar;
+        if constexpr (CENT == kCentLds) {
+            cx = lxyz[3 * kstar + 0];
+            cy = lxyz[3 * kstar + 1];
+            cz = lxyz[3 * kstar + 2];
+        } else if constexpr (CENT == kCentGlobal) {
+            cx = xyz[3 * kstar + 0];
+            cy = xyz[3 * kstar + 1];
+            cz = xyz[3 * kstar + 2];
+        }
+    }
+}
+
+// Large-cloud fallback (n > 16384): running distances in the caller's `temp` (HBM), the
+// reference's thread structure (bs = 1024 threads, strided ownership) with the tie key
+// carried explicitly through a 64-bit LDS tree.  Correct for any n; not tuned.
+__global__ void __launch_bounds__(1024)
+fps_large_kernel(int n, int m, const float *__restrict__ xyz_all, float *__restrict__ temp_all,
+                 int *__restrict__ idx_all) {
+    __shared__ unsigned long long keys[1024];
+    const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    float *__restrict__ temp = temp_all + (size_t)blockIdx.x * n;
+    int *__restrict__ idx = idx_all + (size_t)blockIdx.x * m;
+    const int tid = threadIdx.x;
+    // rank of this thread in the reference tree = bitrev10(tid); smaller wins ties.
+    const unsigned trank = __builtin_bitreverse32((unsigned)tid) >> 22;
+    int old = 0;
+    if (tid == 0) idx[0] = 0;
+    for (int it = 1; it < m; ++it) {
+        const float cx = xyz[3 * old], cy = xyz[3 * old + 1], cz = xyz[3 * old + 2];
+        float best = -1.f;
+        int besti = 0;
+        for (int k = tid; k < n; k += 1024) {
+            const float d = sqdist(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2], cx, cy, cz);
+            const float tt = fmin_raw(d, temp[k]);
+            temp[k] = tt;
+            besti = tt > best ? k : besti;
+            best = tt > best ? tt : best;
+        }
+        // key: dist bits (>=0) high; inverted (thread rank, k div 1024) low -> max = winner
+        const unsigned lo = ~((trank << 21) | (unsigned)(besti >> 10));
+        keys[tid] = ((unsigned long long)(unsigned)f2i(best) << 32) | lo;
+        __syncthreads();
+        for (int s = 512; s >= 1; s >>= 1) {
+            if (tid < s) {
+                const unsigned long long a = keys[tid], b2 = keys[tid + s];
+                keys[tid] = a > b2 ? a : b2;
+            }
+            __syncthreads();
+        }
+        const unsigned wlo = ~(unsigned)keys[0];
+        const unsigned wt = __builtin_bitreverse32((wlo >> 21) & 1023u) >> 22;
+        old = (int)(((wlo & 0x1FFFFFu) << 10) | wt);
+        if (tid == 0) idx[it] = old;
+        __syncthreads();
+    }
+}
+
+template <int T, int P>
+static int launch_fps(int b, int n, int m, int bs, int lg, int Q, const float *xyz, int *idx, hipStream_t st) {
+    const size_t ent_bytes = 2 * 5 * 16 * sizeof(float);
+    if constexpr (P == 1) {
+        hipLaunchKernelGGL((fps_kernel<T, 1, kCentEntry>), dim3(b), dim3(T), ent_bytes, st, n, m, bs, lg, Q, xyz, idx);
+    } else {
+        const size_t need = ent_bytes + (size_t)n * 3 * sizeof(float);
+        if (need <= 128 * 1024) {
+            auto kfn = fps_kernel<T, P, kCentLds>;
+            if (need > 64 * 1024)
+                (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            hipLaunchKernelGGL(kfn, dim3(b), dim3(T), need, st, n, m, bs, lg, Q, xyz, idx);
+        } else {
+            hipLaunchKernelGGL((fps_kernel<T, P, kCentGlobal>), dim3(b), dim3(T), ent_bytes, st, n, m, bs, lg, Q, xyz, idx);
+        }
+    }
+    return check_launch();
+}
+
+static int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t st, int force_threads) {
+    // reference block size: cuda_utils.h:10-14
+    int bs = 1;
+    while (bs * 2 <= n && bs * 2 <= 1024) bs *= 2;
+    int lg = 0;
+    while ((1 << lg) < bs) ++lg;
+    const int Q = (n + bs - 1) / bs;
+    const int slots = bs * Q;
+    if (slots > 1024 * 16) {
+        if (!temp) return PN2_ESCRATCH;
+        hipLaunchKernelGGL(fps_large_kernel, dim3(b), dim3(1024), 0, st, n, m, xyz, temp, idx);
+        return check_launch();
+    }
+    int T = next_pow2(slots);
+    if (T < 64) T = 64;
+    if (T > 1024) T = 1024;
+    if (force_threads == 64 || force_threads == 256 || force_threads == 1024) {
+        if (force_threads * 16 >= slots) T = force_threads;
+    }
+    const int P = next_pow2((slots + T - 1) / T);
+#define PN2_FPS_CASE(TT, PP) \
+    if (T == TT && P == PP) return launch_fps<TT, PP>(b, n, m, bs, lg, Q, xyz, idx, st);
+    PN2_FPS_CASE(64, 1) PN2_FPS_CASE(64, 2) PN2_FPS_CASE(64, 4) PN2_FPS_CASE(64, 8) PN2_FPS_CASE(64, 16)
+    PN2_FPS_CASE(128, 1) PN2_FPS_CASE(512, 1)
+    PN2_FPS_CASE(256, 1) PN2_FPS_CASE(256, 2) PN2_FPS_CASE(256, 4) PN2_FPS_CASE(256, 8) PN2_FPS_CASE(256, 16)
+    PN2_FPS_CASE(1024, 1) PN2_FPS_CASE(1024, 2) PN2_FPS_CASE(1024, 4) PN2_FPS_CASE(1024, 8) PN2_FPS_CASE(1024, 16)
+#undef PN2_FPS_CASE
+    return PN2_ERANGE;
+}
+
+}  // namespace pn2

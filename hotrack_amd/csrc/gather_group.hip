@@ -1,0 +1,130 @@
+// gather_group.hip -- gather_points / group_points forward and backward for gfx950.
+//
+// Replaces gather_points_kernel_fast / _grad_ (reference sampling_gpu.cu:8-83) and
+// group_points_kernel_fast / _grad_ (group_points_gpu.cu:8-86).  gather is group with
+// nsample = 1, so both share one pair of kernels.
+//
+// Forward is pure HBM streaming: the reference launches grid.y = C and re-reads the index
+// tile for every channel.  Here a thread owns VEC consecutive output positions, loads their
+// indices ONCE (one 16-byte load), then walks a channel range: VEC L2-resident gathers and
+// one 16-byte coalesced store per channel, several channels in flight.
+//
+// Backward: the reference issues one global fp32 atomicAdd per gradient element.  Here a
+// workgroup owns (cloud, CC channels), accumulates them in an LDS-private [CC][N] slab with
+// ds_add_f32 and adds the slab to grad_points once with coalesced read-modify-writes -- no
+// global atomics, no contention outside the CU.
+#include "pn2_common.h"
+
+namespace pn2 {
+
+constexpr int kGgThreads = 256;
+
+template <int VEC>
+__global__ void __launch_bounds__(kGgThreads)
+group_fwd_kernel(int c, int n, int ps, int c_per_block, const float *__restrict__ points_all,
+                 const int *__restrict__ idx_all, float *__restrict__ out_all) {
+    const int b = blockIdx.z;
+    const int e0 = (blockIdx.x * kGgThreads + threadIdx.x) * VEC;
+    if (e0 >= ps) return;
+    const int c0 = blockIdx.y * c_per_block;
+    const int c1 = (c0 + c_per_block) < c ? (c0 + c_per_block) : c;
+    const int *__restrict__ idx = idx_all + (size_t)b * ps + e0;
+    int id[VEC];
+    if constexpr (VEC == 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(idx);
+        id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w;
+    } else {
+        id[0] = idx[0];
+    }
+    const float *__restrict__ src = points_all + ((size_t)b * c + c0) * n;
+    float *__restrict__ dst = out_all + ((size_t)b * c + c0) * ps + e0;
+#pragma unroll 4
+    for (int ch = c0; ch < c1; ++ch) {
+        if constexpr (VEC == 4) {
+            float4 v;
+            v.x = src[id[0]]; v.y = src[id[1]]; v.z = src[id[2]]; v.w = src[id[3]];
+            *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+            dst[0] = src[id[0]];
+        }
+        src += n;
+        dst += ps;
+    }
+}
+
+int group_fwd_dispatch(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,
+                       float *out, hipStream_t st) {
+    const long ps_l = (long)npoints * nsample;
+    if (b == 0 || c == 0 || ps_l == 0) return PN2_OK;  // C == 0: HandTrackNet sa1 groups zero-channel features
+    const int ps = (int)ps_l;
+    const bool vec4 = (ps % 4 == 0) && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
+    const int per_block = kGgThreads * (vec4 ? 4 : 1);
+    const int xb = (ps + per_block - 1) / per_block;
+    // split channels so the launch reaches >= ~2048 workgroups when the problem allows it
+    int ysplit = (int)((2048 + (long)xb * b - 1) / ((long)xb * b));
+    if (ysplit < 1) ysplit = 1;
+    if (ysplit > c) ysplit = c;
+    const int c_per_block = (c + ysplit - 1) / ysplit;
+    ysplit = (c + c_per_block - 1) / c_per_block;
+    dim3 grid(xb, ysplit, b);
+    if (vec4)
+        hipLaunchKernelGGL(group_fwd_kernel<4>, grid, dim3(kGgThreads), 0, st, c, n, ps, c_per_block, points, idx, out);
+    else
+        hipLaunchKernelGGL(group_fwd_kernel<1>, grid, dim3(kGgThreads), 0, st, c, n, ps, c_per_block, points, idx, out);
+    return check_launch();
+}
+
+// ---- backward ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kGgThreads)
+group_bwd_lds_kernel(int c, int n, int ps, int cc, const float *__restrict__ grad_out_all,
+                     const int *__restrict__ idx_all, float *__restrict__ grad_points_all) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];  // [cc][n]
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * cc;
+    const int nc = (c - c0) < cc ? (c - c0) : cc;
+    for (int i = threadIdx.x; i < nc * n; i += kGgThreads) acc[i] = 0.f;
+    __syncthreads();
+    const int *__restrict__ idx = idx_all + (size_t)b * ps;
+    const float *__restrict__ g = grad_out_all + ((size_t)b * c + c0) * ps;
+    for (int e = threadIdx.x; e < ps; e += kGgThreads) {
+        const int id = idx[e];
+        for (int ch = 0; ch < nc; ++ch) atomicAdd(&acc[ch * n + id], g[(size_t)ch * ps + e]);
+    }
+    __syncthreads();
+    float *__restrict__ dst = grad_points_all + ((size_t)b * c + c0) * n;
+    for (int i = threadIdx.x; i < nc * n; i += kGgThreads) dst[i] += acc[i];
+}
+
+__global__ void __launch_bounds__(kGgThreads)
+group_bwd_atomic_kernel(int c, int n, int ps, const float *__restrict__ grad_out_all,
+                        const int *__restrict__ idx_all, float *__restrict__ grad_points_all) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int e = blockIdx.x * kGgThreads + threadIdx.x;
+    if (e >= ps) return;
+    const int id = idx_all[(size_t)b * ps + e];
+    unsafeAtomicAdd(grad_points_all + ((size_t)b * c + ch) * n + id, grad_out_all[((size_t)b * c + ch) * ps + e]);
+}
+
+int group_bwd_dispatch(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                       float *grad_points, hipStream_t st) {
+    const long ps_l = (long)npoints * nsample;
+    if (b == 0 || c == 0 || ps_l == 0) return PN2_OK;
+    const int ps = (int)ps_l;
+    const int lds_budget = 64 * 1024;
+    int cc = lds_budget / (int)(sizeof(float) * (size_t)n);
+    if (cc >= 1) {
+        if (cc > 16) cc = 16;
+        if (cc > c) cc = c;
+        // keep enough workgroups in flight: shrink the channel slab while the grid is small
+        while (cc > 1 && (long)b * ((c + cc - 1) / cc) < 1024) cc = (cc + 1) / 2;
+        dim3 grid((c + cc - 1) / cc, b);
+        hipLaunchKernelGGL(group_bwd_lds_kernel, grid, dim3(kGgThreads), (size_t)cc * n * sizeof(float), st, c, n, ps, cc,
+                           grad_out, idx, grad_points);
+    } else {
+        dim3 grid((ps + kGgThreads - 1) / kGgThreads, c, b);
+        hipLaunchKernelGGL(group_bwd_atomic_kernel, grid, dim3(kGgThreads), 0, st, c, n, ps, grad_out, idx, grad_points);
+    }
+    return check_launch();
+}
+
+}  // namespace pn2

@@ -1,0 +1,113 @@
+// interpolate.hip -- three_interpolate forward / backward for gfx950.
+//
+// Replaces three_interpolate_kernel_fast / _grad_ (reference interpolate_gpu.cu:149-233).
+// Same streaming structure as gather_group.hip: a thread owns one output point, loads its
+// three (index, weight) pairs once and walks a channel range with coalesced stores; the
+// backward accumulates into an LDS-private [CC][M] slab instead of 3 global atomics/element.
+#include "pn2_common.h"
+
+namespace pn2 {
+
+constexpr int kIpThreads = 256;
+
+__global__ void __launch_bounds__(kIpThreads)
+interp_fwd_kernel(int c, int m, int n, int c_per_block, const float *__restrict__ points_all,
+                  const int *__restrict__ idx_all, const float *__restrict__ weight_all,
+                  float *__restrict__ out_all) {
+    const int b = blockIdx.z;
+    const int j = blockIdx.x * kIpThreads + threadIdx.x;
+    if (j >= n) return;
+    const int c0 = blockIdx.y * c_per_block;
+    const int c1 = (c0 + c_per_block) < c ? (c0 + c_per_block) : c;
+    const int *__restrict__ id = idx_all + ((size_t)b * n + j) * 3;
+    const float *__restrict__ w = weight_all + ((size_t)b * n + j) * 3;
+    const int i0 = id[0], i1 = id[1], i2 = id[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    const float *__restrict__ src = points_all + ((size_t)b * c + c0) * m;
+    float *__restrict__ dst = out_all + ((size_t)b * c + c0) * n + j;
+#pragma unroll 4
+    for (int ch = c0; ch < c1; ++ch) {
+        // w0*p0 + w1*p1 + w2*p2 (interpolate_gpu.cu:168) in the oracle's contraction order
+        dst[0] = __builtin_fmaf(w2, src[i2], __builtin_fmaf(w0, src[i0], w1 * src[i1]));
+        src += m;
+        dst += n;
+    }
+}
+
+int interp_fwd_dispatch(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                        float *out, hipStream_t st) {
+    if (b == 0 || c == 0 || n == 0) return PN2_OK;
+    const int xb = (n + kIpThreads - 1) / kIpThreads;
+    int ysplit = (int)((2048 + (long)xb * b - 1) / ((long)xb * b));
+    if (ysplit < 1) ysplit = 1;
+    if (ysplit > c) ysplit = c;
+    const int c_per_block = (c + ysplit - 1) / ysplit;
+    ysplit = (c + c_per_block - 1) / c_per_block;
+    dim3 grid(xb, ysplit, b);
+    hipLaunchKernelGGL(interp_fwd_kernel, grid, dim3(kIpThreads), 0, st, c, m, n, c_per_block, points, idx, weight, out);
+    return check_launch();
+}
+
+__global__ void __launch_bounds__(kIpThreads)
+interp_bwd_lds_kernel(int c, int n, int m, int cc, const float *__restrict__ grad_out_all,
+                      const int *__restrict__ idx_all, const float *__restrict__ weight_all,
+                      float *__restrict__ grad_points_all) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];  // [cc][m]
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * cc;
+    const int nc = (c - c0) < cc ? (c - c0) : cc;
+    for (int i = threadIdx.x; i < nc * m; i += kIpThreads) acc[i] = 0.f;
+    __syncthreads();
+    const float *__restrict__ g = grad_out_all + ((size_t)b * c + c0) * n;
+    for (int j = threadIdx.x; j < n; j += kIpThreads) {
+        const int *__restrict__ id = idx_all + ((size_t)b * n + j) * 3;
+        const float *__restrict__ w = weight_all + ((size_t)b * n + j) * 3;
+        const int i0 = id[0], i1 = id[1], i2 = id[2];
+        const float w0 = w[0], w1 = w[1], w2 = w[2];
+        for (int ch = 0; ch < nc; ++ch) {
+            const float go = g[(size_t)ch * n + j];
+            atomicAdd(&acc[ch * m + i0], go * w0);
+            atomicAdd(&acc[ch * m + i1], go * w1);
+            atomicAdd(&acc[ch * m + i2], go * w2);
+        }
+    }
+    __syncthreads();
+    float *__restrict__ dst = grad_points_all + ((size_t)b * c + c0) * m;
+    for (int i = threadIdx.x; i < nc * m; i += kIpThreads) dst[i] += acc[i];
+}
+
+__global__ void __launch_bounds__(kIpThreads)
+interp_bwd_atomic_kernel(int c, int n, int m, const float *__restrict__ grad_out_all,
+                         const int *__restrict__ idx_all, const float *__restrict__ weight_all,
+                         float *__restrict__ grad_points_all) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int j = blockIdx.x * kIpThreads + threadIdx.x;
+    if (j >= n) return;
+    const int *__restrict__ id = idx_all + ((size_t)b * n + j) * 3;
+    const float *__restrict__ w = weight_all + ((size_t)b * n + j) * 3;
+    const float go = grad_out_all[((size_t)b * c + ch) * n + j];
+    float *__restrict__ dst = grad_points_all + ((size_t)b * c + ch) * m;
+    unsafeAtomicAdd(dst + id[0], go * w[0]);
+    unsafeAtomicAdd(dst + id[1], go * w[1]);
+    unsafeAtomicAdd(dst + id[2], go * w[2]);
+}
+
+int interp_bwd_dispatch(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
+                        float *grad_points, hipStream_t st) {
+    if (b == 0 || c == 0 || n == 0) return PN2_OK;
+    int cc = (64 * 1024) / (int)(sizeof(float) * (size_t)m);
+    if (cc >= 1) {
+        if (cc > 16) cc = 16;
+        if (cc > c) cc = c;
+        while (cc > 1 && (long)b * ((c + cc - 1) / cc) < 1024) cc = (cc + 1) / 2;
+        dim3 grid((c + cc - 1) / cc, b);
+        hipLaunchKernelGGL(interp_bwd_lds_kernel, grid, dim3(kIpThreads), (size_t)cc * m * sizeof(float), st, c, n, m, cc,
+                           grad_out, idx, weight, grad_points);
+    } else {
+        dim3 grid((n + kIpThreads - 1) / kIpThreads, c, b);
+        hipLaunchKernelGGL(interp_bwd_atomic_kernel, grid, dim3(kIpThreads), 0, st, c, n, m, grad_out, idx, weight, grad_points);
+    }
+    return check_launch();
+}
+
+}  // namespace pn2

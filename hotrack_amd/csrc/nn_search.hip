@@ -1,0 +1,199 @@
+// nn_search.hip -- three_nn and knn for gfx950.
+//
+// three_nn  replaces three_nn_kernel_fast (reference interpolate_gpu.cu:81-146):
+//   thread per query, but the known set is staged once per workgroup in LDS as 16-byte
+//   xyz_ records and read with wave-uniform (broadcast) ds_read_b128; the 3-entry cascade is
+//   branch-free (v_cmp + v_cndmask), so a wave never diverges.
+//
+// knn       replaces knn_kernel_fast (interpolate_gpu.cu:9-79), which keeps double[200]
+//   per thread in local memory and leaves HandTrackNet's 21 queries/cloud on 21 threads.
+//   Here one WAVE owns a query: each lane computes the distances of a contiguous chunk of
+//   P candidates into registers as 64-bit keys (dist_bits << 32 | index), sorts them with a
+//   compile-time odd-even merge network, and the k outputs are produced by k rounds of
+//   "wave-min over the lane heads (DPP) -> first lane holding it pops".  The 64-bit key order
+//   is exactly the reference's (distance ascending, index ascending) insertion order.
+#include "pn2_common.h"
+
+namespace pn2 {
+
+// ------------------------------------------------------------------------------------------
+// three_nn
+// ------------------------------------------------------------------------------------------
+constexpr int kNnTile = 2048;  // known points per LDS tile (32 KiB as float4)
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+three_nn_kernel(int n, int m, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
+                float *__restrict__ dist2_all, int *__restrict__ idx_all) {
+    extern __shared__ __attribute__((aligned(16))) float4 sk[];
+    const int b = blockIdx.y;
+    const float *__restrict__ known = known_all + (size_t)b * m * 3;
+    const int q = blockIdx.x * THREADS + threadIdx.x;
+    const bool active = q < n;
+    const float *__restrict__ u = unknown_all + ((size_t)b * n + (active ? q : 0)) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+
+    // double 1e40 sentinels of the reference (interpolate_gpu.cu:102) == +inf for fp32 compares
+    float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
+    int i1 = 0, i2 = 0, i3 = 0;
+
+    for (int t0 = 0; t0 < m; t0 += kNnTile) {
+        const int tn = (m - t0) < kNnTile ? (m - t0) : kNnTile;
+        if (t0 > 0) __syncthreads();
+        for (int p = threadIdx.x; p < tn; p += THREADS) {
+            const float *src = known + (size_t)3 * (t0 + p);
+            sk[p] = make_float4(src[0], src[1], src[2], 0.f);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < tn; ++p) {
+            const float4 kp = sk[p];  // wave-uniform address -> LDS broadcast
+            const float d = sqdist(ux, uy, uz, kp.x, kp.y, kp.z);
+            const int k = t0 + p;
+            const bool lt1 = d < b1, lt2 = d < b2, lt3 = d < b3;  // strict: ties keep the lower index
+            b3 = lt2 ? b2 : (lt3 ? d : b3);
+            i3 = lt2 ? i2 : (lt3 ? k : i3);
+            b2 = lt1 ? b1 : (lt2 ? d : b2);
+            i2 = lt1 ? i1 : (lt2 ? k : i2);
+            b1 = lt1 ? d : b1;
+            i1 = lt1 ? k : i1;
+        }
+    }
+    if (active) {
+        float *od = dist2_all + ((size_t)b * n + q) * 3;
+        int *oi = idx_all + ((size_t)b * n + q) * 3;
+        od[0] = b1; od[1] = b2; od[2] = b3;
+        oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    }
+}
+
+int three_nn_dispatch(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                      int *idx, hipStream_t st) {
+    if (b == 0 || n == 0) return PN2_OK;
+    const int tile_cap = m < kNnTile ? m : kNnTile;
+    const size_t lds = (size_t)(tile_cap > 0 ? tile_cap : 1) * sizeof(float4);
+    // few queries -> single-wave workgroups so the grid still spreads over the CUs
+    if ((long)b * n < 256L * 1024) {
+        dim3 grid((n + 63) / 64, b);
+        hipLaunchKernelGGL(three_nn_kernel<64>, grid, dim3(64), lds, st, n, m, unknown, known, dist2, idx);
+    } else {
+        dim3 grid((n + 255) / 256, b);
+        hipLaunchKernelGGL(three_nn_kernel<256>, grid, dim3(256), lds, st, n, m, unknown, known, dist2, idx);
+    }
+    return check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// knn
+// ------------------------------------------------------------------------------------------
+constexpr unsigned long long kInfKey = 0x7F80000000000000ull;  // (+inf, index 0)
+
+template <int P>
+__device__ __forceinline__ void sort_keys(unsigned long long (&key)[P]) {
+    // Batcher odd-even merge sort network, fully unrolled (all indices compile-time).
+#pragma unroll
+    for (int p = 1; p < P; p <<= 1) {
+#pragma unroll
+        for (int k = p; k >= 1; k >>= 1) {
+#pragma unroll
+            for (int j = k % p; j + k < P; j += 2 * k) {
+#pragma unroll
+                for (int i = 0; i < k; ++i) {
+                    if (i + j + k < P && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+                        const unsigned long long a = key[i + j], c = key[i + j + k];
+                        const bool sw = c < a;
+                        key[i + j] = sw ? c : a;
+                        key[i + j + k] = sw ? a : c;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+knn_wave_kernel(int n, int m, int k, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
+                float *__restrict__ dist2_all, int *__restrict__ idx_all) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= n) return;  // wave-uniform
+    const float *__restrict__ known = known_all + (size_t)b * m * 3;
+    const float *__restrict__ u = unknown_all + ((size_t)b * n + q) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+
+    unsigned long long key[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int c = lane * P + j;
+        const bool in = c < m;
+        const float *src = known + (size_t)3 * (in ? c : 0);
+        const float d = sqdist(ux, uy, uz, src[0], src[1], src[2]);
+        // `d < best[j]` against the 1e40 sentinel (interpolate_gpu.cu:33,41) never admits inf/NaN
+        const bool ok = in && (d < __builtin_inff());
+        key[j] = ok ? (((unsigned long long)(unsigned)f2i(d) << 32) | (unsigned)c) : kInfKey;
+    }
+    sort_keys<P>(key);
+
+    float *__restrict__ od = dist2_all + ((size_t)b * n + q) * k;
+    int *__restrict__ oi = idx_all + ((size_t)b * n + q) * k;
+    for (int r = 0; r < k; ++r) {
+        const unsigned hd = (unsigned)(key[0] >> 32);
+        const unsigned mn = wave_min_u32(hd);
+        const uint64_t tie = __ballot(hd == mn);
+        const int wl = __builtin_ctzll(tie);  // lanes own ascending index ranges: lowest lane = lowest index
+        if (lane == wl) {
+            od[r] = i2f((int)mn);
+            oi[r] = (int)(unsigned)key[0];
+#pragma unroll
+            for (int j = 0; j + 1 < P; ++j) key[j] = key[j + 1];
+            key[P - 1] = kInfKey;
+        }
+    }
+}
+
+// Fallback for m > 64*32 candidates: thread per query, reference-style insertion list in
+// private memory (k <= 200).  Correct for any m; not tuned.
+__global__ void __launch_bounds__(64)
+knn_thread_kernel(int n, int m, int k, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
+                  float *__restrict__ dist2_all, int *__restrict__ idx_all) {
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= n) return;
+    const float *__restrict__ known = known_all + (size_t)b * m * 3;
+    const float *__restrict__ u = unknown_all + ((size_t)b * n + q) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    float best[PN2_KNN_MAX_K];
+    int besti[PN2_KNN_MAX_K];
+    for (int i = 0; i < k; ++i) { best[i] = __builtin_inff(); besti[i] = 0; }
+    for (int i = 0; i < m; ++i) {
+        const float d = sqdist(ux, uy, uz, known[3 * i], known[3 * i + 1], known[3 * i + 2]);
+        if (!(d < best[k - 1])) continue;
+        int j = k - 1;
+        while (j > 0 && d < best[j - 1]) { best[j] = best[j - 1]; besti[j] = besti[j - 1]; --j; }
+        best[j] = d;
+        besti[j] = i;
+    }
+    float *od = dist2_all + ((size_t)b * n + q) * k;
+    int *oi = idx_all + ((size_t)b * n + q) * k;
+    for (int i = 0; i < k; ++i) { od[i] = best[i]; oi[i] = besti[i]; }
+}
+
+int knn_dispatch(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2,
+                 int *idx, hipStream_t st) {
+    if (b == 0 || n == 0) return PN2_OK;
+    dim3 grid((n + 3) / 4, b);
+#define PN2_KNN_CASE(PP)                                                                                    \
+    if (m <= 64 * PP) {                                                                                     \
+        hipLaunchKernelGGL(knn_wave_kernel<PP>, grid, dim3(256), 0, st, n, m, k, unknown, known, dist2, idx); \
+        return check_launch();                                                                              \
+    }
+    PN2_KNN_CASE(1) PN2_KNN_CASE(2) PN2_KNN_CASE(4) PN2_KNN_CASE(8) PN2_KNN_CASE(16) PN2_KNN_CASE(32)
+#undef PN2_KNN_CASE
+    dim3 grid2((n + 63) / 64, b);
+    hipLaunchKernelGGL(knn_thread_kernel, grid2, dim3(64), 0, st, n, m, k, unknown, known, dist2, idx);
+    return check_launch();
+}
+
+}  // namespace pn2

@@ -1,0 +1,92 @@
+// pn2_common.h -- shared device helpers for the gfx950 PointNet++ operator kernels.
+// wave64 only; DPP-based cross-lane reductions (no LDS round trips inside a wave).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pn2_hip.h"
+
+namespace pn2 {
+
+constexpr int kWave = 64;
+
+// Squared distance in the one fixed contraction order used by oracle and kernels alike:
+// fma(dz,dz, fma(dx,dx, dy*dy)).  (reference expression: sampling_gpu.cu:133,
+// ball_query_gpu.cu:33, interpolate_gpu.cu:40,108 compiled with nvcc --fmad=true.)
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+}
+
+// One fused DPP reduction step:  v = OP(v, lane_permute(v))  as a single VOP2-DPP instruction.
+// hipcc does not fold update_dpp+max into one instruction (it emits mov / s_nop / mov_dpp /
+// max), so the step is written in asm.  "s_nop 1" = the 2 wait states gfx9 requires between
+// a VALU write of a VGPR and a DPP read of it; lanes disabled by row_mask keep v (vdst==src).
+#define PN2_DPP_STEP(OPC, V, CTRL) \
+    asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 " CTRL : "+v"(V))
+
+// Max over aligned groups of NL lanes (NL in {1,2,4,8,16}) -- butterfly inside a row of 16:
+// afterwards every lane of the group holds the group's max.
+template <int NL>
+__device__ __forceinline__ int row_group_max_i32(int v) {
+    if constexpr (NL >= 2) PN2_DPP_STEP("v_max_i32_dpp", v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    if constexpr (NL >= 4) PN2_DPP_STEP("v_max_i32_dpp", v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    if constexpr (NL >= 8) PN2_DPP_STEP("v_max_i32_dpp", v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+    if constexpr (NL >= 16) PN2_DPP_STEP("v_max_i32_dpp", v, "row_mirror row_mask:0xf bank_mask:0xf");
+    return v;
+}
+template <int NL>
+__device__ __forceinline__ unsigned row_group_min_u32(unsigned v) {
+    if constexpr (NL >= 2) PN2_DPP_STEP("v_min_u32_dpp", v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    if constexpr (NL >= 4) PN2_DPP_STEP("v_min_u32_dpp", v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    if constexpr (NL >= 8) PN2_DPP_STEP("v_min_u32_dpp", v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+    if constexpr (NL >= 16) PN2_DPP_STEP("v_min_u32_dpp", v, "row_mirror row_mask:0xf bank_mask:0xf");
+    return v;
+}
+
+// Full wave64 signed-int max; result is wave-uniform (read from lane 63 into an SGPR).
+// row_bcast:15 feeds lane 15 of each row to the next row (rows 1,3 enabled), row_bcast:31
+// feeds lane 31 to rows 2,3: lane 63 ends up with the max of all four rows.
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = row_group_max_i32<16>(v);
+    PN2_DPP_STEP("v_max_i32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    PN2_DPP_STEP("v_max_i32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = row_group_min_u32<16>(v);
+    PN2_DPP_STEP("v_min_u32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    PN2_DPP_STEP("v_min_u32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// fminf without the v_max canonicalisation hipcc inserts in IEEE mode (operands are never sNaN here).
+__device__ __forceinline__ float fmin_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ int f2i(float f) { return __builtin_bit_cast(int, f); }
+__device__ __forceinline__ float i2f(int i) { return __builtin_bit_cast(float, i); }
+
+__device__ __forceinline__ int lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int prefix_popc(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// Host-side launch helpers ---------------------------------------------------------------
+void set_last_hip_error(int e);
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_hip_error((int)e);
+        return PN2_ELAUNCH;
+    }
+    return PN2_OK;
+}
+
+}  // namespace pn2

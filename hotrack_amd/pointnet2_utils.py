@@ -1,0 +1,271 @@
+"""pointnet2_utils -- the operator API HOTrack's network code imports, on MI355X.
+
+Drop-in for the reference's `network/models/pointnet_lib/pointnet2_utils.py`: same public
+names, argument order, dtypes, shapes and autograd behaviour
+(`furthest_point_sample`, `gather_operation`, `knn`, `three_nn`, `three_interpolate`,
+`grouping_operation`, `ball_query`, `QueryAndGroup`, `GroupAll`, `KNNAndGroup`;
+reference lines :38, :77, :109, :142, :193, :239, :272, :275, :311, :337).
+
+What is different underneath:
+  * the native module is `hotrack_amd.pointnet2_hip` (hand-written gfx950 kernels behind a
+    C ABI) instead of `pointnet2_cuda`;
+  * outputs are allocated with torch.empty on the input's device (the reference uses the
+    legacy torch.cuda.IntTensor/FloatTensor constructors, e.g. :27-28);
+  * FPS allocates no `temp` scratch (running distances live in registers; reference :28) and
+    ball_query does not pre-zero idx (every element is written by the kernel; reference :262);
+  * GPU tensors only -- a CPU tensor raises (no fallback path exists in this package).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import pointnet2_hip as pointnet2
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected a float32 tensor, got {t.dtype}")
+    return t.contiguous()
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        """xyz (B,N,3) f32 -> (B,npoint) int32 indices; first index is always 0 (reference :11-31)."""
+        xyz = _f32c(xyz)
+        if xyz.dim() != 3 or xyz.size(2) != 3:
+            raise ValueError(f"xyz must be (B, N, 3), got {tuple(xyz.shape)}")
+        B, N, _ = xyz.shape
+        npoint = int(npoint)
+        output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, None, output)
+        ctx.mark_non_differentiable(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """features (B,C,N), idx (B,npoint) int32 -> (B,C,npoint) (reference :43-65)."""
+        features = _f32c(features)
+        idx = idx.contiguous()
+        if idx.dtype != torch.int32:
+            raise TypeError(f"gather_operation: idx must be int32 (as in the reference), got {idx.dtype}")
+        B, npoint = idx.shape
+        _, C, N = features.shape
+        output = torch.empty((B, C, npoint), dtype=torch.float32, device=features.device)
+        pointnet2.gather_points_wrapper(B, C, N, npoint, features, idx, output)
+        ctx.for_backwards = (idx, C, N)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, C, N = ctx.for_backwards
+        B, npoint = idx.shape
+        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+        pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features)
+        return grad_features, None
+
+
+gather_operation = GatherOperation.apply
+
+
+class KNN(Function):
+    @staticmethod
+    def forward(ctx, k: int, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """unknown (B,N,3), known (B,M,3) -> (dist (B,N,k) Euclidean, idx (B,N,k) int32) (reference :81-103)."""
+        unknown = _f32c(unknown)
+        known = _f32c(known)
+        B, N, _ = unknown.shape
+        m = known.size(1)
+        k = int(k)
+        dist2 = torch.empty((B, N, k), dtype=torch.float32, device=unknown.device)
+        idx = torch.empty((B, N, k), dtype=torch.int32, device=unknown.device)
+        pointnet2.knn_wrapper(B, N, m, k, unknown, known, dist2, idx)
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(dist, idx)
+        return dist, idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None
+
+
+knn = KNN.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """unknown (B,N,3), known (B,M,3) -> (dist (B,N,3) Euclidean, idx (B,N,3) int32) (reference :113-135)."""
+        unknown = _f32c(unknown)
+        known = _f32c(known)
+        B, N, _ = unknown.shape
+        m = known.size(1)
+        dist2 = torch.empty((B, N, 3), dtype=torch.float32, device=unknown.device)
+        idx = torch.empty((B, N, 3), dtype=torch.int32, device=unknown.device)
+        pointnet2.three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(dist, idx)
+        return dist, idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """features (B,C,M), idx (B,n,3) int32, weight (B,n,3) -> (B,C,n) (reference :147-170)."""
+        features = _f32c(features)
+        idx = idx.contiguous()
+        weight = _f32c(weight)
+        if idx.dtype != torch.int32:
+            raise TypeError(f"three_interpolate: idx must be int32, got {idx.dtype}")
+        B, c, m = features.shape
+        n = idx.size(1)
+        ctx.three_interpolate_for_backward = (idx, weight, m)
+        output = torch.empty((B, c, n), dtype=torch.float32, device=features.device)
+        pointnet2.three_interpolate_wrapper(B, c, m, n, features, idx, weight, output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        """Gradient w.r.t. features only (the reference returns None for idx and weight, :190)."""
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.shape
+        grad_features = torch.zeros((B, c, m), dtype=torch.float32, device=grad_out.device)
+        pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """features (B,C,N), idx (B,npoint,nsample) any int dtype -> (B,C,npoint,nsample) (reference :198-219)."""
+        features = _f32c(features)
+        idx = idx.contiguous().int()  # the reference casts here too (:211)
+        B, nfeatures, nsample = idx.shape
+        _, C, N = features.shape
+        output = torch.empty((B, C, nfeatures, nsample), dtype=torch.float32, device=features.device)
+        pointnet2.group_points_wrapper(B, C, N, nfeatures, nsample, features, idx, output)
+        ctx.for_backwards = (idx, N)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, N = ctx.for_backwards
+        B, C, npoint, nsample = grad_out.shape
+        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+        pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features)
+        return grad_features, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+        """xyz (B,N,3), new_xyz (B,npoint,3) -> idx (B,npoint,nsample) int32 (reference :244-265)."""
+        new_xyz = _f32c(new_xyz)
+        xyz = _f32c(xyz)
+        B, N, _ = xyz.shape
+        npoint = new_xyz.size(1)
+        nsample = int(nsample)
+        idx = torch.empty((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
+        pointnet2.ball_query_wrapper(B, N, npoint, float(radius), nsample, new_xyz, xyz, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """Ball query + grouping; output channels [features, xyz - centre] (reference :275-308)."""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)  # (B,3,npoint,nsample)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return grouped_xyz
+        grouped_features = grouping_operation(features, idx)
+        if self.use_xyz:
+            return torch.cat([grouped_features, grouped_xyz], dim=1)  # (B, C+3, npoint, nsample)
+        return grouped_features
+
+
+class GroupAll(nn.Module):
+    """Single group holding every point; channels [xyz, features] (reference :311-334)."""
+
+    def __init__(self, use_xyz: bool = True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: Optional[torch.Tensor] = None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            return grouped_xyz
+        grouped_features = features.unsqueeze(2)
+        if self.use_xyz:
+            return torch.cat([grouped_xyz, grouped_features], dim=1)  # (B, 3+C, 1, N)
+        return grouped_features
+
+
+class KNNAndGroup(nn.Module):
+    """kNN + grouping; channels [xyz - centre, features] (reference :337-387).
+
+    The reference's forward calls `knn(xyz, new_xyz, self.radius, self.nsample)` (:362), which
+    does not match the KNN signature and is never executed by the network; here the module
+    works: idx = knn(nsample, new_xyz, xyz).
+    """
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: Optional[torch.Tensor] = None,
+                idx: Optional[torch.Tensor] = None, features: Optional[torch.Tensor] = None):
+        if new_xyz is None:
+            new_xyz = xyz
+        if idx is None:
+            _, idx = knn(self.nsample, new_xyz, xyz)  # (B, M, K)
+        idx = idx.detach()
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)  # (B,3,M,K)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return grouped_xyz
+        grouped_features = grouping_operation(features, idx)
+        if self.use_xyz:
+            return torch.cat([grouped_xyz, grouped_features], dim=1)  # (B, 3+C, M, K)
+        return grouped_features

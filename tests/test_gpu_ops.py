@@ -1,0 +1,217 @@
+"""GPU parity: hotrack_amd HIP operators (through the C-ABI) vs the CPU oracle.
+
+Index outputs must be bit-exact; float outputs within 1e-5 (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _cases import cloud, take_points
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from hotrack_amd import pointnet2_utils
+    return pointnet2_utils
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+FPS_CASES = [
+    # (B, N, M, kind)
+    (2, 1, 1, "uniform"), (2, 3, 3, "uniform"), (3, 21, 8, "uniform"), (2, 64, 64, "uniform"),
+    (2, 100, 40, "uniform"), (4, 256, 128, "uniform"), (4, 1000, 256, "uniform"), (8, 1024, 256, "uniform"),
+    (4, 1024, 256, "hand"), (2, 2560, 512, "uniform"), (2, 5120, 1024, "uniform"), (1, 8192, 2048, "uniform"),
+    (3, 1024, 300, "lattice"), (3, 1000, 300, "lattice"), (2, 343, 343, "lattice"), (2, 2560, 200, "lattice"),
+    (2, 8192, 300, "lattice"), (2, 512, 64, "dup"), (2, 1024, 64, "dup"), (2, 33, 33, "lattice"),
+    (1, 12000, 64, "uniform"), (1, 16384, 40, "lattice"), (2, 4096, 512, "uniform"), (2, 2048, 700, "lattice"),
+]
+
+
+@pytest.mark.parametrize("B,N,M,kind", FPS_CASES)
+def test_fps_index_exact(ops, oracle, B, N, M, kind):
+    xyz = cloud(B * 1000 + N, B, N, kind)
+    ref = oracle.furthest_point_sample(xyz, M)
+    got = ops.furthest_point_sample(dev(xyz), M)
+    assert got.dtype == torch.int32 and tuple(got.shape) == (B, M)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("threads", ["64", "256", "1024"])
+def test_fps_thread_configs_agree(ops, oracle, threads, monkeypatch):
+    """Every (threads, points-per-lane) layout must give the reference's tie order."""
+    monkeypatch.setenv("PN2_FPS_THREADS", threads)
+    for N, M, kind in [(1024, 256, "uniform"), (1024, 300, "lattice"), (1000, 128, "lattice"), (700, 128, "uniform")]:
+        xyz = cloud(7 + N, 3, N, kind)
+        ref = oracle.furthest_point_sample(xyz, M)
+        got = ops.furthest_point_sample(dev(xyz), M)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_fps_large_needs_temp(oracle):
+    from hotrack_amd import pointnet2_hip as native
+    B, N, M = 1, 20000, 32
+    xyz = cloud(5, B, N, "uniform")
+    out = torch.empty((B, M), dtype=torch.int32, device="cuda")
+    with pytest.raises(native.Pn2Error):
+        native.furthest_point_sampling_wrapper(B, N, M, dev(xyz), None, out)
+    temp = torch.full((B, N), 1e10, dtype=torch.float32, device="cuda")
+    native.furthest_point_sampling_wrapper(B, N, M, dev(xyz), temp, out)
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.furthest_point_sample(xyz, M))
+
+
+BALL_CASES = [
+    # (B, N, S, radius, nsample, kind)
+    (4, 1024, 256, 0.1, 32, "hand"), (4, 256, 128, 0.2, 32, "hand"), (2, 1024, 256, 0.1, 32, "uniform"),
+    (2, 1024, 256, 0.5, 32, "uniform"), (2, 1000, 100, 0.3, 1, "uniform"), (2, 777, 50, 0.25, 64, "lattice"),
+    (1, 8192, 2048, 0.2, 64, "uniform"), (1, 8192, 512, 0.1, 64, "uniform"), (2, 5000, 300, 0.05, 100, "uniform"),
+    (2, 64, 64, 0.01, 16, "uniform"), (2, 3, 2, 10.0, 8, "uniform"), (3, 1024, 21, 0.2, 130, "uniform"),
+]
+
+
+@pytest.mark.parametrize("B,N,S,radius,nsample,kind", BALL_CASES)
+def test_ball_query_index_exact(ops, oracle, B, N, S, radius, nsample, kind):
+    xyz = cloud(11 * N + S, B, N, kind)
+    fps = oracle.furthest_point_sample(xyz, S)
+    new_xyz = take_points(xyz, fps)
+    if kind == "lattice":  # put centroids off-lattice too, some exactly on the sphere
+        new_xyz = new_xyz + np.float32(0.25)
+    ref = oracle.ball_query(radius, nsample, xyz, new_xyz)
+    got = ops.ball_query(radius, nsample, dev(xyz), dev(new_xyz))
+    assert got.dtype == torch.int32
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_ball_query_no_hits_rows_are_zero(ops, oracle):
+    xyz = cloud(3, 2, 500, "uniform")
+    new_xyz = xyz[:, :40] + np.float32(100.0)
+    got = ops.ball_query(0.1, 16, dev(xyz), dev(new_xyz)).cpu().numpy()
+    assert (got == 0).all()
+    np.testing.assert_array_equal(got, oracle.ball_query(0.1, 16, xyz, new_xyz))
+
+
+NN_CASES = [(4, 256, 128), (4, 1024, 256), (2, 1000, 333), (2, 50, 2), (2, 10, 1), (2, 5000, 3000), (3, 64, 64)]
+
+
+@pytest.mark.parametrize("B,n,m", NN_CASES)
+@pytest.mark.parametrize("kind", ["uniform", "lattice"])
+def test_three_nn(ops, oracle, B, n, m, kind):
+    unknown = cloud(n, B, n, kind)
+    known = cloud(m + 1, B, m, kind)
+    d2, idx = oracle.three_nn(unknown, known)
+    gd, gi = ops.three_nn(dev(unknown), dev(known))
+    np.testing.assert_array_equal(gi.cpu().numpy(), idx)
+    np.testing.assert_allclose(gd.cpu().numpy(), np.sqrt(d2), rtol=0, atol=ATOL)
+
+
+KNN_CASES = [(4, 21, 1024, 16), (4, 21, 1024, 64), (2, 21, 1024, 4), (2, 21, 1024, 200), (2, 30, 1000, 50),
+             (2, 17, 100, 7), (2, 5, 64, 64), (2, 9, 2048, 33), (1, 40, 3000, 20), (2, 8, 10, 16), (2, 4, 1, 1),
+             (2, 128, 512, 32)]
+
+
+@pytest.mark.parametrize("B,n,m,k", KNN_CASES)
+@pytest.mark.parametrize("kind", ["uniform", "lattice"])
+def test_knn(ops, oracle, B, n, m, k, kind):
+    unknown = cloud(n + k, B, n, kind)
+    known = cloud(m, B, m, kind)
+    d2, idx = oracle.knn(k, unknown, known)
+    gd, gi = ops.knn(k, dev(unknown), dev(known))
+    np.testing.assert_array_equal(gi.cpu().numpy(), idx)
+    ref = np.sqrt(d2)
+    g = gd.cpu().numpy()
+    assert np.array_equal(np.isinf(g), np.isinf(ref))
+    np.testing.assert_allclose(np.where(np.isinf(g), 0, g), np.where(np.isinf(ref), 0, ref), rtol=0, atol=ATOL)
+
+
+GROUP_CASES = [(4, 3, 1024, 256, 32), (4, 0, 1024, 256, 32), (4, 64, 256, 128, 32), (2, 384, 1024, 21, 16),
+               (2, 384, 1024, 21, 64), (2, 5, 100, 7, 3), (1, 67, 8192, 2048, 64), (2, 1, 1, 1, 1), (2, 130, 333, 10, 5)]
+
+
+@pytest.mark.parametrize("B,C,N,P,S", GROUP_CASES)
+def test_group_points_forward_backward(ops, oracle, B, C, N, P, S):
+    rng = np.random.default_rng(C * 31 + N)
+    feat = rng.normal(size=(B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, (B, P, S)).astype(np.int32)
+    f = dev(feat).requires_grad_(True)
+    out = ops.grouping_operation(f, dev(idx))
+    assert tuple(out.shape) == (B, C, P, S)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), oracle.group_points(feat, idx))  # pure copy: bit exact
+    if C == 0:
+        return
+    go = rng.normal(size=(B, C, P, S)).astype(np.float32)
+    out.backward(dev(go))
+    ref = oracle.group_points_grad(go, idx, N)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,N,M", [(4, 3, 1024, 256), (4, 3, 256, 128), (2, 64, 500, 77), (2, 7, 9, 20)])
+def test_gather_forward_backward(ops, oracle, B, C, N, M):
+    rng = np.random.default_rng(N + M)
+    feat = rng.normal(size=(B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, (B, M)).astype(np.int32)
+    f = dev(feat).requires_grad_(True)
+    out = ops.gather_operation(f, dev(idx))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), oracle.gather_points(feat, idx))
+    go = rng.normal(size=(B, C, M)).astype(np.float32)
+    out.backward(dev(go))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.gather_points_grad(go, idx, N), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,M,n", [(4, 256, 128, 256), (4, 128, 256, 1024), (2, 5, 3, 10), (2, 33, 700, 999),
+                                     (1, 16, 20000, 300)])
+def test_three_interpolate_forward_backward(ops, oracle, B, C, M, n):
+    rng = np.random.default_rng(M + n)
+    feat = rng.normal(size=(B, C, M)).astype(np.float32)
+    idx = rng.integers(0, M, (B, n, 3)).astype(np.int32)
+    w = rng.random((B, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    f = dev(feat).requires_grad_(True)
+    out = ops.three_interpolate(f, dev(idx), dev(w))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), oracle.three_interpolate(feat, idx, w), rtol=0, atol=ATOL)
+    go = rng.normal(size=(B, C, n)).astype(np.float32)
+    out.backward(dev(go))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.three_interpolate_grad(go, idx, w, M), rtol=1e-5, atol=1e-5)
+
+
+def test_grad_accumulates_into_existing_buffer(oracle):
+    """The reference kernels atomicAdd into the caller's buffer; so do ours (+= semantics)."""
+    from hotrack_amd import pointnet2_hip as native
+    rng = np.random.default_rng(0)
+    B, C, N, P, S = 2, 6, 50, 9, 4
+    go = rng.normal(size=(B, C, P, S)).astype(np.float32)
+    idx = rng.integers(0, N, (B, P, S)).astype(np.int32)
+    init = rng.normal(size=(B, C, N)).astype(np.float32)
+    buf = dev(init.copy())
+    native.group_points_grad_wrapper(B, C, N, P, S, dev(go), dev(idx), buf)
+    np.testing.assert_allclose(buf.cpu().numpy(), init + oracle.group_points_grad(go, idx, N), rtol=1e-5, atol=1e-5)
+
+
+def test_cpu_tensor_raises(ops):
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.furthest_point_sample(torch.rand(1, 16, 3), 4)
+
+
+def test_forward_ops_deterministic(ops):
+    xyz = dev(cloud(1, 8, 1024, "hand"))
+    a = ops.furthest_point_sample(xyz, 256)
+    b = ops.furthest_point_sample(xyz, 256)
+    assert torch.equal(a, b)
+    new = torch.gather(xyz, 1, a.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    i1 = ops.ball_query(0.1, 32, xyz, new)
+    i2 = ops.ball_query(0.1, 32, xyz, new)
+    assert torch.equal(i1, i2)
+
+
+def test_non_default_stream(ops, oracle):
+    xyz = cloud(9, 4, 1024, "uniform")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        got = ops.furthest_point_sample(dev(xyz), 128)
+    s.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), oracle.furthest_point_sample(xyz, 128))
