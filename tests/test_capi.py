@@ -1,0 +1,86 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol the headers declare
+(no compute calls -- there is no GPU here), and the Python boundary validates its arguments."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pn2x?_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_headers_declare_the_reference_surface():
+    names = _declared("pn2_hip.h")
+    for n in ("pn2_ball_query", "pn2_group_points", "pn2_group_points_grad", "pn2_gather_points", "pn2_gather_points_grad",
+              "pn2_furthest_point_sampling", "pn2_knn", "pn2_three_nn", "pn2_three_interpolate", "pn2_three_interpolate_grad"):
+        assert n in names  # one per m.def of pointnet2_api.cpp:11-24
+
+
+def test_library_exports_every_declared_symbol(hip_lib_path):
+    lib = ctypes.CDLL(hip_lib_path)
+    for header in ("pn2_hip.h", "pn2_ext.h"):
+        for name in _declared(header):
+            assert hasattr(lib, name), f"{name} declared in {header} but not exported"
+    lib.pn2_abi_version.restype = ctypes.c_int
+    assert lib.pn2_abi_version() >= 1
+    lib.pn2_strerror.restype = ctypes.c_char_p
+    assert b"NULL" in lib.pn2_strerror(-2)
+
+
+def test_argument_validation_without_gpu(hip_lib_path):
+    """Invalid arguments are rejected before anything touches the device."""
+    lib = ctypes.CDLL(hip_lib_path)
+    vp = ctypes.c_void_p
+    lib.pn2_knn.argtypes = [ctypes.c_int] * 4 + [vp] * 5
+    assert lib.pn2_knn(1, 4, 16, 0, None, None, None, None, None) == -1      # k < 1
+    assert lib.pn2_knn(1, 4, 16, 201, None, None, None, None, None) == -3    # k > 200 (reference array bound)
+    assert lib.pn2_knn(1, 4, 16, 8, None, None, None, None, None) == -2      # NULL pointers
+    lib.pn2_furthest_point_sampling.argtypes = [ctypes.c_int] * 3 + [vp] * 4
+    assert lib.pn2_furthest_point_sampling(1, 0, 4, None, None, None, None) == -1   # n < 1
+    assert lib.pn2_furthest_point_sampling(0, 16, 4, None, None, None, None) == 0   # empty batch is a no-op
+    lib.pn2_ball_query.argtypes = [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] + [vp] * 4
+    assert lib.pn2_ball_query(1, 16, 4, 0.1, 0, None, None, None, None) == -1       # nsample < 1
+    lib.pn2_group_points.argtypes = [ctypes.c_int] * 5 + [vp] * 4
+    assert lib.pn2_group_points(2, 0, 16, 4, 4, None, None, None, None) == 0        # C == 0 is legal (sa1)
+
+
+def test_python_boundary_exports_reference_names():
+    from hotrack_amd import pointnet2_hip, pointnet2_utils
+    for n in pointnet2_hip.EXPORTED:
+        assert callable(getattr(pointnet2_hip, n))
+    for n in ("furthest_point_sample", "gather_operation", "knn", "three_nn", "three_interpolate", "grouping_operation",
+              "ball_query", "QueryAndGroup", "GroupAll", "KNNAndGroup", "FurthestPointSampling", "GatherOperation", "KNN",
+              "ThreeNN", "ThreeInterpolate", "GroupingOperation", "BallQuery"):
+        assert hasattr(pointnet2_utils, n)
+
+
+def test_cpu_tensors_fail_loudly():
+    from hotrack_amd import pointnet2_utils as ops
+    xyz = torch.rand(1, 32, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.furthest_point_sample(xyz, 8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.ball_query(0.1, 4, xyz, xyz[:, :4].contiguous())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.three_nn(xyz, xyz)
+    with pytest.raises(TypeError):
+        ops.furthest_point_sample(xyz.double(), 8)
+
+
+def test_product_code_never_imports_the_oracle():
+    bad = []
+    for base in ("hotrack_amd", "network", "configs", "datasets"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "pn2_oracle" in txt:
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
