@@ -110,11 +110,15 @@ def _check_train(dev, elide, rtol):
     np.testing.assert_allclose(ret["pred_kp"].detach().cpu().numpy(), GOLD["train_pred_kp"], atol=5e-4)
     none_mask = np.array([p.grad is None for _, p in model.named_parameters()])
     np.testing.assert_array_equal(none_mask, GOLD["param_grad_is_none"])
+    names = [n for n, _ in model.named_parameters()]
     gn = np.array([0.0 if p.grad is None else float(p.grad.norm()) for _, p in model.named_parameters()])
     ref = GOLD["param_grad_norm"]
-    # conv biases that feed a train-mode BatchNorm have an analytically ZERO gradient: what is
-    # left there is accumulation-order noise (~1e-3 of the weight gradients), hence the atol
-    np.testing.assert_allclose(gn, ref, rtol=5e-3, atol=5e-3)
+    # A conv bias that feeds a train-mode BatchNorm has an analytically ZERO gradient; what both
+    # implementations report there is accumulation-order noise, so it is only bounded, not matched.
+    pre_bn_bias = np.array([n.endswith(".bias") and ("conv_blocks" in n or "mlp_convs" in n or n == "bhand.conv1.bias")
+                            for n in names])
+    np.testing.assert_allclose(gn[~pre_bn_bias], ref[~pre_bn_bias], rtol=5e-3, atol=1e-5)
+    assert (gn[pre_bn_bias] < 2e-2 * ref.max()).all()
 
 
 @pytest.mark.parametrize("elide", [True, False])
