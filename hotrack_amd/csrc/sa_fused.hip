@@ -1,0 +1,242 @@
+// sa_fused.hip -- fused grouped-MLP + max of one PointNet++ set-abstraction scale (eval mode).
+//
+// The reference materialises the grouped tensor (B, Cin, S, K) with advanced indexing and then
+// runs [Conv2d 1x1 + BatchNorm2d + ReLU] x3 and a max over K as ~12 separate kernels
+// (pointnet_utils.py:389-403, :566-581).  On MI355X that is pure HBM traffic over tensors that
+// exist only to be reduced.  Here one kernel consumes the neighbour indices directly:
+//
+//   layer 1 is linear in [feat_j | xyz_j - c_s | centre_feat_s], so it splits into a per-POINT
+//   term A1[b,j,:] and a per-CENTROID term c1[b,s,:] (two small dense GEMMs done by the caller);
+//   in the kernel layer 1 is   h1 = relu(A1[idx] + c1)   -- a coalesced row gather into LDS;
+//   layers 2 and 3 run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, 157 TF
+//   peak) with the BN-folded weights held in REGISTERS as the B operand for the whole kernel
+//   (the workgroup is persistent over position tiles), activations staged through LDS as the
+//   A operand; bias is the accumulator's initial value, ReLU is applied on the way to LDS;
+//   the max over the K neighbours is taken on the accumulator registers (rows of the MFMA
+//   D tile are positions) + two cross-lane steps, so (B, C, S, K) never exists.
+//
+// Tile geometry: 4 waves = WC channel groups x WP position groups (WC*WP = 4); a position
+// group owns 64 consecutive (s,k) positions = 64/K centroids (K in {16,32,64}).
+#include "pn2_common.h"
+#include "../../include/pn2_ext.h"
+
+namespace pn2 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int C1, int C2, int C3, int WC>
+__global__ void __launch_bounds__(256)
+sa_mlp_max_kernel(int N, int S, int K, int lgK, const float *__restrict__ A1, const float *__restrict__ c1v,
+                  const int *__restrict__ idx, const float *__restrict__ W2, const float *__restrict__ b2,
+                  const float *__restrict__ W3, const float *__restrict__ b3, float *__restrict__ out,
+                  int num_tiles, int tiles_per_cloud) {
+    constexpr int WP = 4 / WC;
+    constexpr int TM = WP * 64;
+    constexpr int LD1 = C1 + 4, LD2 = C2 + 4;
+    constexpr int NT2 = C2 / (16 * WC), NT3 = C3 / (16 * WC);
+    static_assert(C2 % (16 * WC) == 0 && C3 % (16 * WC) == 0 && C1 % 16 == 0, "tile geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *H1 = smem;
+    float *H2 = smem + TM * LD1;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int wc = w % WC, wp = w / WC;
+    const int li = lane & 15, g = lane >> 4;
+
+    // ---- weights -> registers (B operand: lane holds W[out = tile*16 + li][in = 16*tq + 4*g + j]) -------
+    float w2r[NT2][C1 / 4], w3r[NT3][C2 / 4];
+    float bias2[NT2], bias3[NT3];
+#pragma unroll
+    for (int ct = 0; ct < NT2; ++ct) {
+        const int oc = (wc * NT2 + ct) * 16 + li;
+        bias2[ct] = b2[oc];
+#pragma unroll
+        for (int tq = 0; tq < C1 / 16; ++tq) {
+            const float4 v = *reinterpret_cast<const float4 *>(W2 + (size_t)oc * C1 + 16 * tq + 4 * g);
+            w2r[ct][4 * tq + 0] = v.x; w2r[ct][4 * tq + 1] = v.y; w2r[ct][4 * tq + 2] = v.z; w2r[ct][4 * tq + 3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NT3; ++ct) {
+        const int oc = (wc * NT3 + ct) * 16 + li;
+        bias3[ct] = b3[oc];
+#pragma unroll
+        for (int tq = 0; tq < C2 / 16; ++tq) {
+            const float4 v = *reinterpret_cast<const float4 *>(W3 + (size_t)oc * C2 + 16 * tq + 4 * g);
+            w3r[ct][4 * tq + 0] = v.x; w3r[ct][4 * tq + 1] = v.y; w3r[ct][4 * tq + 2] = v.z; w3r[ct][4 * tq + 3] = v.w;
+        }
+    }
+
+    const int SK = S * K;
+    for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_cloud;
+        const int pos0 = (tile - b * tiles_per_cloud) * TM;
+        const float *__restrict__ A1b = A1 + (size_t)b * N * C1;
+        const float *__restrict__ c1b = c1v + (size_t)b * S * C1;
+        const int *__restrict__ idxb = idx + (size_t)b * SK;
+
+        // ---- phase 1: h1 = relu(A1[idx] + c1) -> LDS (row = position, C1 contiguous) -------------------
+        constexpr int Q1 = C1 / 4;
+#pragma unroll 4
+        for (int e = tid; e < TM * Q1; e += 256) {
+            const int row = e / Q1, c4 = e - row * Q1;
+            const int p = pos0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < SK) {
+                const int j = idxb[p];
+                const int s = p >> lgK;
+                const float4 a = *reinterpret_cast<const float4 *>(A1b + (size_t)j * C1 + 4 * c4);
+                const float4 c = *reinterpret_cast<const float4 *>(c1b + (size_t)s * C1 + 4 * c4);
+                v.x = fmaxf(a.x + c.x, 0.f); v.y = fmaxf(a.y + c.y, 0.f);
+                v.z = fmaxf(a.z + c.z, 0.f); v.w = fmaxf(a.w + c.w, 0.f);
+            }
+            *reinterpret_cast<float4 *>(H1 + row * LD1 + 4 * c4) = v;
+        }
+        __syncthreads();
+
+        // ---- phase 2: layer 2 on the matrix cores ----------------------------------------------------
+        {
+            f32x4 acc[4][NT2];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < NT2; ++ct) acc[rt][ct] = (f32x4){bias2[ct], bias2[ct], bias2[ct], bias2[ct]};
+            const float *arow = H1 + (wp * 64 + li) * LD1 + 4 * g;
+#pragma unroll
+            for (int tq = 0; tq < C1 / 16; ++tq) {
+                float4 a[4];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1 + 16 * tq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
+#pragma unroll
+                        for (int ct = 0; ct < NT2; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
+                    }
+            }
+            // relu -> H2 (D tile: row = g*4 + r, col = li)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < NT2; ++ct) {
+                    float *dst = H2 + (wp * 64 + rt * 16 + g * 4) * LD2 + (wc * NT2 + ct) * 16 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[r * LD2] = fmaxf(acc[rt][ct][r], 0.f);
+                }
+        }
+        __syncthreads();
+
+        // ---- phase 3: layer 3 + max over the K neighbours ---------------------------------------------
+        {
+            f32x4 acc[4][NT3];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < NT3; ++ct) acc[rt][ct] = (f32x4){bias3[ct], bias3[ct], bias3[ct], bias3[ct]};
+            const float *arow = H2 + (wp * 64 + li) * LD2 + 4 * g;
+#pragma unroll
+            for (int tq = 0; tq < C2 / 16; ++tq) {
+                float4 a[4];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD2 + 16 * tq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
+#pragma unroll
+                        for (int ct = 0; ct < NT3; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w3r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
+                    }
+            }
+            // per row-tile max over its 16 positions: 4 registers in-lane, then the 4 lane groups
+            float m[4][NT3];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < NT3; ++ct)
+                    m[rt][ct] = fmaxf(fmaxf(acc[rt][ct][0], acc[rt][ct][1]), fmaxf(acc[rt][ct][2], acc[rt][ct][3]));
+            // combine row tiles that belong to the same centroid (K = 16 -> 1, 32 -> 2, 64 -> 4 tiles)
+            if (K >= 32) {
+#pragma unroll
+                for (int ct = 0; ct < NT3; ++ct) {
+                    m[0][ct] = fmaxf(m[0][ct], m[1][ct]);
+                    m[2][ct] = fmaxf(m[2][ct], m[3][ct]);
+                }
+            }
+            if (K >= 64) {
+#pragma unroll
+                for (int ct = 0; ct < NT3; ++ct) m[0][ct] = fmaxf(m[0][ct], m[2][ct]);
+            }
+            const int rstep = K >> 4;  // row tiles per centroid
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                if (rt % rstep != 0) continue;  // wave-uniform
+                const int s = ((pos0 + wp * 64) >> lgK) + rt / rstep;
+#pragma unroll
+                for (int ct = 0; ct < NT3; ++ct) {
+                    float v = m[rt][ct];
+                    v = fmaxf(v, __shfl_xor(v, 16));
+                    v = fmaxf(v, __shfl_xor(v, 32));
+                    if (g == 0 && s < S) {
+                        const int oc = (wc * NT3 + ct) * 16 + li;
+                        out[((size_t)b * C3 + oc) * S + s] = fmaxf(v, 0.f);  // relu commutes with max
+                    }
+                }
+            }
+        }
+        // no third barrier: H1 is next written after this tile's 2nd barrier, H2 after the next tile's 1st
+    }
+}
+
+template <int C1, int C2, int C3, int WC>
+static int launch_sa(int b, int n, int s, int k, const float *a1, const float *c1, const int *idx, const float *w2,
+                     const float *b2, const float *w3, const float *b3, float *out, hipStream_t st) {
+    constexpr int WP = 4 / WC, TM = WP * 64;
+    const int sk = s * k;
+    const int tiles_per_cloud = (sk + TM - 1) / TM;
+    const long num_tiles_l = (long)b * tiles_per_cloud;
+    if (num_tiles_l > 2147483647L) return PN2_ERANGE;
+    const int num_tiles = (int)num_tiles_l;
+    int lgk = 0;
+    while ((1 << lgk) < k) ++lgk;
+    const size_t lds = (size_t)TM * (C1 + 4 + C2 + 4) * sizeof(float);
+    auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // persistent workgroups: weights are loaded into registers once per workgroup
+    const int max_wg = 256 * (lds > 80 * 1024 ? 1 : 2);
+    const int grid = num_tiles < max_wg ? num_tiles : max_wg;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, n, s, k, lgk, a1, c1, idx, w2, b2, w3, b3, out, num_tiles,
+                       tiles_per_cloud);
+    return check_launch();
+}
+
+}  // namespace pn2
+
+extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c3, const float *a1, const float *c1v,
+                               const int *idx, const float *w2, const float *b2, const float *w3, const float *b3,
+                               float *out, void *stream) {
+    using namespace pn2;
+    if (b < 0 || n < 1 || s < 0 || k < 1) return PN2_EINVAL;
+    if (b == 0 || s == 0) return PN2_OK;
+    if (!a1 || !c1v || !idx || !w2 || !b2 || !w3 || !b3 || !out) return PN2_ENULL;
+    if (!(k == 16 || k == 32 || k == 64)) return PN2_ERANGE;
+    if (((uintptr_t)a1 | (uintptr_t)c1v | (uintptr_t)w2 | (uintptr_t)w3) % 16 != 0) return PN2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2>(b, n, s, k, a1, c1v, idx, w2, b2, w3, b3, out, st);
+    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4>(b, n, s, k, a1, c1v, idx, w2, b2, w3, b3, out, st);
+    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4>(b, n, s, k, a1, c1v, idx, w2, b2, w3, b3, out, st);
+    return PN2_ERANGE;
+}
+
+extern "C" int pn2x_sa_mlp_max_supported(int k, int c1, int c2, int c3) {
+    const bool kk = (k == 16 || k == 32 || k == 64);
+    const bool cc = (c1 == 32 && c2 == 32 && c3 == 64) || (c1 == 64 && c2 == 64 && c3 == 128) ||
+                    (c1 == 128 && c2 == 128 && c3 == 192);
+    return (kk && cc) ? 1 : 0;
+}

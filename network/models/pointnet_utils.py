@@ -166,7 +166,10 @@ class _MultiScaleGroupedMLP(nn.Module):
         """
         fused = _FUSED
         if fused is not None and not self.training and not torch.is_grad_enabled() and xyz.is_cuda:
-            return fused.sa_scale(self.conv_blocks[i], self.bn_blocks[i], xyz, points, new_xyz, group_idx, center_feat)
+            pts = points if points is not None and points.shape[1] > 0 else None
+            out = fused.sa_scale(self.conv_blocks[i], self.bn_blocks[i], xyz, pts, new_xyz, group_idx, center_feat)
+            if out is not None:
+                return out  # None: shape not covered by the fused kernel -> unfused operator path below
         ops = _ops()
         grouped_xyz = ops.grouping_operation(xyz, group_idx)
         grouped_xyz = grouped_xyz - new_xyz.unsqueeze(-1)

@@ -196,6 +196,53 @@ def gen_network(ref_pu, ref_hn):
     out["param_grad_norm"] = np.array([0.0 if p.grad is None else float(p.grad.norm()) for _, p in model.named_parameters()])
     out["param_shapes"] = np.array([str(tuple(p.shape)) for _, p in model.named_parameters()])
     out["state_dict_keys"] = np.array(list(model.state_dict().keys()))
+    # fp64 re-run of the same train step = ground truth for the gradient norms (the fp32 step above
+    # carries ~1e-3 relative accumulation noise through the train-mode BatchNorm backward).  Index
+    # operators still see fp32 coordinates; gather / group / interpolate run as the reference's own
+    # dtype-agnostic torch indexing.
+    class _F64Ops:
+        furthest_point_sample = staticmethod(lambda xyz, n: torch_ops.furthest_point_sample(xyz.float(), n))
+        ball_query = staticmethod(lambda r, k, xyz, new: torch_ops.ball_query(r, k, xyz.float(), new.float()))
+        knn = staticmethod(lambda k, u, kn: tuple(t if i else t.double() for i, t in enumerate(torch_ops.knn(k, u.float(), kn.float()))))
+
+        @staticmethod
+        def three_nn(u, kn):
+            _, idx = torch_ops.three_nn(u.float(), kn.float())
+            d = (u.unsqueeze(2) - torch.gather(kn.unsqueeze(1).expand(-1, u.shape[1], -1, -1), 2,
+                                               idx.long().unsqueeze(-1).expand(-1, -1, -1, 3))).norm(dim=-1)
+            return d, idx
+
+        @staticmethod
+        def three_interpolate(points, idx, weight):
+            B, N = idx.shape[:2]
+            g = ref_pu.index_points(points.permute(0, 2, 1), idx.long())
+            return (g * weight.view(B, N, 3, 1)).sum(dim=2).permute(0, 2, 1)
+
+    ref_pu.futils = _F64Ops
+    model64 = ref_hn.HandTrackNet(cfg)
+    deterministic_init(model64)
+    model64 = model64.double().train()
+    for m in model64.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    to64 = lambda d: {k: (v.double() if torch.is_tensor(v) else to64(v)) for k, v in d.items()}
+    data64 = to64(data)
+    _float = torch.Tensor.float
+    torch.Tensor.float = lambda self: self  # hand_network.py casts its inputs with .float(); keep fp64 for this run
+    torch.set_default_dtype(torch.float64)  # torch.eye / torch.ones inside the reference
+    try:
+        ret64 = model64(data64, dict(flags, test_flag=False))
+        loss64, ret64 = model64.compute_loss(data64, ret64, dict(flags, test_flag=False))
+    finally:
+        torch.Tensor.float = _float
+        torch.set_default_dtype(torch.float32)
+    total64 = 10 * loss64["hand_pred_kp_loss"] + loss64["hand_pred_r_loss"] + loss64["hand_pred_t_loss"]
+    total64.backward()
+    out["train_total_loss_f64"] = np.array(float(total64))
+    out["param_grad_norm_f64"] = np.array([0.0 if p.grad is None else float(p.grad.norm()) for _, p in model64.named_parameters()])
+    ref_pu.futils = torch_ops
     np.savez_compressed(os.path.join(HERE, "handtracknet_reference.npz"), **out)
     n_none = int(out["param_grad_is_none"].sum())
     numel_none = sum(p.numel() for _, p in model.named_parameters() if p.grad is None)

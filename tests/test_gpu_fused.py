@@ -1,0 +1,124 @@
+"""GPU: the MI355X-side extensions (include/pn2_ext.h) against plain torch fp32 references."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _netinit import deterministic_init, make_cfg, synthetic_frames
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "network"))
+pytestmark = pytest.mark.gpu
+
+
+def _kabsch_ref(x, y):
+    x, y = x.double(), y.double()
+    cx, cy = x.mean(1, keepdim=True), y.mean(1, keepdim=True)
+    w = (x - cx).transpose(1, 2) @ (y - cy)
+    u, _, vh = torch.linalg.svd(w)
+    v = vh.transpose(1, 2)
+    d = torch.det(v @ u.transpose(1, 2))
+    fix = torch.eye(3, dtype=torch.float64).repeat(x.shape[0], 1, 1)
+    fix[:, 2, 2] = d
+    R = v @ fix @ u.transpose(1, 2)
+    t = cy - cx @ R.transpose(1, 2)
+    return R.float(), t.transpose(1, 2).float()
+
+
+@pytest.mark.parametrize("B,num,shared", [(64, 6, False), (5, 6, True), (1, 14, False), (300, 4, False)])
+def test_kabsch_matches_svd(B, num, shared):
+    from hotrack_amd import ext
+    g = torch.Generator().manual_seed(B + num)
+    x = torch.randn(1 if shared else B, num, 3, generator=g) * 0.05
+    q = torch.randn(B, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    w_, a, b_, c = q.unbind(1)
+    Rgt = torch.stack([1 - 2 * (b_ * b_ + c * c), 2 * (a * b_ - c * w_), 2 * (a * c + b_ * w_),
+                       2 * (a * b_ + c * w_), 1 - 2 * (a * a + c * c), 2 * (b_ * c - a * w_),
+                       2 * (a * c - b_ * w_), 2 * (b_ * c + a * w_), 1 - 2 * (a * a + b_ * b_)], 1).view(B, 3, 3)
+    y = x.expand(B, -1, -1) @ Rgt.transpose(1, 2) + torch.randn(B, 1, 3, generator=g) + 0.002 * torch.randn(B, num, 3, generator=g)
+    R, t = ext.kabsch(x.cuda(), y.cuda())
+    Rr, tr = _kabsch_ref(x.expand(B, -1, -1), y)
+    assert torch.allclose(R.cpu(), Rr, atol=2e-6) and torch.allclose(t.cpu(), tr, atol=2e-6)
+    assert torch.allclose(torch.det(R.cpu()), torch.ones(B), atol=1e-5)
+
+
+def _mk_sa(in_ch, widths, seed):
+    from models.pointnet_utils import PointNetSetAbstractionMsg_GivenCenterPoints
+    m = PointNetSetAbstractionMsg_GivenCenterPoints([0.2], [16], [widths], in_channel=in_ch, knn=True)
+    deterministic_init(m)
+    g = torch.Generator().manual_seed(seed)
+    for p in m.parameters():
+        p.data.add_(0.01 * torch.randn(p.shape, generator=g))
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("D,D2,widths,N,S,K", [
+    (0, 0, [32, 32, 64], 1024, 256, 32), (64, 0, [64, 64, 128], 256, 128, 32), (384, 0, [128, 128, 192], 1024, 21, 16),
+    (384, 0, [128, 128, 192], 1024, 21, 64), (384, 384, [128, 128, 192], 1024, 21, 16), (384, 384, [128, 128, 192], 1024, 21, 64),
+    (64, 0, [64, 64, 128], 300, 37, 16), (0, 0, [32, 32, 64], 100, 5, 64)])
+def test_fused_sa_scale_matches_unfused(D, D2, widths, N, S, K):
+    from hotrack_amd import fused, pointnet2_utils
+    from models import pointnet_utils
+    pointnet_utils.set_operator_backend(pointnet2_utils)
+    B = 3
+    g = torch.Generator().manual_seed(D + N + K)
+    m = _mk_sa(D + 3 + D2, widths, seed=K)
+    xyz = torch.rand(B, 3, N, generator=g).cuda()
+    pts = torch.randn(B, D, N, generator=g).cuda() if D else None
+    new_xyz = torch.rand(B, 3, S, generator=g).cuda()
+    cf = torch.randn(B, D2, S, generator=g).cuda() if D2 else None
+    idx = torch.randint(0, N, (B, S, K), generator=g, dtype=torch.int32).cuda()
+    with torch.no_grad():
+        pointnet_utils.set_fused_backend(None)
+        ref = m._scale(0, xyz, pts, new_xyz, idx, cf)
+        pointnet_utils.set_fused_backend(fused)
+        assert fused.supported(m.conv_blocks[0], K)
+        got = m._scale(0, xyz, pts, new_xyz, idx, cf)
+        pointnet_utils.set_fused_backend(None)
+    assert got.shape == ref.shape
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1.0) + 1e-5, (float((got - ref).abs().max()), scale)
+
+
+def test_fused_unsupported_shape_falls_back_to_operator_path():
+    from hotrack_amd import fused, pointnet2_utils
+    from models import pointnet_utils
+    pointnet_utils.set_operator_backend(pointnet2_utils)
+    m = _mk_sa(3, [16, 16, 24], seed=1)
+    assert not fused.supported(m.conv_blocks[0], 16)
+    xyz = torch.rand(2, 3, 50).cuda()
+    idx = torch.randint(0, 50, (2, 4, 16), dtype=torch.int32).cuda()
+    new_xyz = torch.rand(2, 3, 4).cuda()
+    with torch.no_grad():
+        pointnet_utils.set_fused_backend(fused)
+        a = m._scale(0, xyz, None, new_xyz, idx)
+        pointnet_utils.set_fused_backend(None)
+        b = m._scale(0, xyz, None, new_xyz, idx)
+    assert torch.equal(a, b)
+
+
+def test_network_with_fused_backend_matches_reference_golden():
+    from hotrack_amd import fused, pointnet2_utils
+    from models import pointnet_utils
+    from models.hand_network import HandTrackNet
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "handtracknet_reference.npz"))
+    pointnet_utils.set_operator_backend(pointnet2_utils)
+    torch.manual_seed(0)
+    model = HandTrackNet(make_cfg("cuda"))
+    deterministic_init(model)
+    model = model.cuda().eval()
+    data = {"hand_points": torch.from_numpy(gold["in_hand_points"]).cuda(),
+            "jittered_hand_kp": torch.from_numpy(gold["in_jittered_hand_kp"]).cuda(),
+            "gt_hand_pose": {"palm_template": torch.from_numpy(gold["in_palm_template"]).cuda()}}
+    flags = {"track_flag": False, "test_flag": True, "save_flag": False, "IKNet_flag": False}
+    try:
+        pointnet_utils.set_fused_backend(fused)
+        with torch.no_grad():
+            ret = model(data, dict(flags))
+    finally:
+        pointnet_utils.set_fused_backend(None)
+    np.testing.assert_allclose(ret["pred_kp"].cpu().numpy(), gold["eval_pred_kp"], atol=2e-4)
+    np.testing.assert_allclose(ret["pred_kp_handframe"].cpu().numpy(), gold["eval_pred_kp_handframe"], atol=2e-4)

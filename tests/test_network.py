@@ -110,15 +110,17 @@ def _check_train(dev, elide, rtol):
     np.testing.assert_allclose(ret["pred_kp"].detach().cpu().numpy(), GOLD["train_pred_kp"], atol=5e-4)
     none_mask = np.array([p.grad is None for _, p in model.named_parameters()])
     np.testing.assert_array_equal(none_mask, GOLD["param_grad_is_none"])
-    names = [n for n, _ in model.named_parameters()]
     gn = np.array([0.0 if p.grad is None else float(p.grad.norm()) for _, p in model.named_parameters()])
-    ref = GOLD["param_grad_norm"]
-    # A conv bias that feeds a train-mode BatchNorm has an analytically ZERO gradient; what both
-    # implementations report there is accumulation-order noise, so it is only bounded, not matched.
-    pre_bn_bias = np.array([n.endswith(".bias") and ("conv_blocks" in n or "mlp_convs" in n or n == "bhand.conv1.bias")
-                            for n in names])
-    np.testing.assert_allclose(gn[~pre_bn_bias], ref[~pre_bn_bias], rtol=5e-3, atol=1e-5)
-    assert (gn[pre_bn_bias] < 2e-2 * ref.max()).all()
+    # Ground truth = the reference's train step re-run in fp64 (make_golden.py).  The reference's own
+    # fp32 CPU step deviates from it by up to 4e-3 on live gradients (train-mode BatchNorm backward
+    # cancels large sums), so that is the noise floor any fp32 implementation is compared at.
+    truth = GOLD["param_grad_norm_f64"]
+    live = truth > 1e-6 * truth.max()
+    np.testing.assert_allclose(gn[live], truth[live], rtol=1e-2, atol=5e-4)
+    # analytically-zero gradients (conv biases feeding a train-mode BatchNorm, ...): only bounded
+    assert (gn[~live] < 2e-3 * truth.max()).all()
+    ref32 = GOLD["param_grad_norm"]
+    assert (np.abs(ref32[live] - truth[live]) <= 1e-2 * truth[live] + 5e-4).all()  # the reference itself meets the same bar
 
 
 @pytest.mark.parametrize("elide", [True, False])
