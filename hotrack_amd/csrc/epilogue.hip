@@ -1,0 +1,52 @@
+// epilogue.hip -- y[b,c,n] = act(y[b,c,n] + bias[c]) in place: the bias/ReLU half of an
+// eval-mode (BatchNorm-folded) 1x1 convolution whose GEMM half is a plain library GEMM.
+// Pure HBM streaming: 16-byte loads/stores, one pass.
+#include "pn2_common.h"
+#include "../../include/pn2_ext.h"
+
+namespace pn2 {
+
+template <bool RELU, bool VEC>
+__global__ void __launch_bounds__(256)
+bias_act_kernel(float *__restrict__ y, const float *__restrict__ bias, int C, long n, long total_rows) {
+    // rows = b*C + c, each of n contiguous floats
+    const long per_row = VEC ? (n >> 2) : n;
+    const long total = total_rows * per_row;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / per_row;
+        const float bv = bias[row % C];
+        if constexpr (VEC) {
+            float4 *p = reinterpret_cast<float4 *>(y) + e;
+            float4 v = *p;
+            v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *p = v;
+        } else {
+            float v = y[e] + bv;
+            y[e] = RELU ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+}  // namespace pn2
+
+extern "C" int pn2x_bias_act(int b, int c, int n, float *y, const float *bias, int relu, void *stream) {
+    using namespace pn2;
+    if (b < 0 || c < 0 || n < 0) return PN2_EINVAL;
+    if (b == 0 || c == 0 || n == 0) return PN2_OK;
+    if (!y || !bias) return PN2_ENULL;
+    const bool vec = (n % 4 == 0) && ((uintptr_t)y % 16 == 0);
+    const long rows = (long)b * c;
+    const long work = rows * (vec ? n / 4 : n);
+    long blocks = (work + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) {
+        if (relu) hipLaunchKernelGGL((bias_act_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, y, bias, c, (long)n, rows);
+        else hipLaunchKernelGGL((bias_act_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, y, bias, c, (long)n, rows);
+    } else {
+        if (relu) hipLaunchKernelGGL((bias_act_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, y, bias, c, (long)n, rows);
+        else hipLaunchKernelGGL((bias_act_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, y, bias, c, (long)n, rows);
+    }
+    return check_launch();
+}

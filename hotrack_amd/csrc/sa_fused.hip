@@ -207,7 +207,11 @@ static int launch_sa(int b, int n, int s, int k, const float *a1, const float *c
     while ((1 << lgk) < k) ++lgk;
     const size_t lds = (size_t)TM * (C1 + 4 + C2 + 4) * sizeof(float);
     auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_set = false;  // once per instantiation; never during a later stream capture
+    if (lds > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     // persistent workgroups: weights are loaded into registers once per workgroup
     const int max_wg = 256 * (lds > 80 * 1024 ? 1 : 2);
     const int grid = num_tiles < max_wg ? num_tiles : max_wg;

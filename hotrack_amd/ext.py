@@ -61,3 +61,17 @@ def sa_mlp_max(a1: torch.Tensor, c1v: torch.Tensor, idx: torch.Tensor, w2, b2, w
         _native._check(_lib.pn2x_sa_mlp_max(B, N, S, K, C1, C2, C3, pa, pc, pi, pw2, pb2, pw3, pb3, out.data_ptr(),
                                             _native._stream(a1)), "sa_mlp_max")
     return out
+
+
+_lib.pn2x_bias_act.argtypes = [_ci, _ci, _ci, _vp, _vp, _ci, _vp]
+_lib.pn2x_bias_act.restype = _ci
+
+
+def bias_act_(y: torch.Tensor, bias: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """In place y[b,c,n] = act(y + bias[c]); y (B,C,N) contiguous fp32."""
+    B, C, N = y.shape
+    py = _native._ptr(y, "y", torch.float32, B * C * N)
+    pb = _native._ptr(bias, "bias", torch.float32, C)
+    with torch.cuda.device(y.device):
+        _native._check(_lib.pn2x_bias_act(B, C, N, py, pb, 1 if relu else 0, _native._stream(y)), "bias_act")
+    return y

@@ -71,3 +71,26 @@ def sa_scale(convs, bns, xyz: torch.Tensor, points: Optional[torch.Tensor], new_
         Wc = W1[:, D + 3:]
         c1 = torch.baddbmm(c1, center_feat.transpose(1, 2), Wc.t().unsqueeze(0).expand(center_feat.shape[0], -1, -1))
     return ext.sa_mlp_max(a1.contiguous(), c1.contiguous(), group_idx.contiguous(), W2, b2, W3, b3)
+
+
+def mlp_stack(x: torch.Tensor, convs, bns) -> torch.Tensor:
+    """Eval-mode [Conv 1x1 + BN + ReLU]* on (B,C,N) (or (B,C,N,1)) activations: BatchNorm folded into
+    the weights, GEMM by the BLAS library, bias + ReLU in one in-place streaming kernel.
+    (reference: the Conv1d/Conv2d + BatchNorm + ReLU stacks of pointnet_utils.py:460-462, :504-506)."""
+    squeeze = x.dim() == 4
+    if squeeze:
+        x = x.squeeze(-1)
+    for W, b in _folded(convs, bns):
+        x = ext.bias_act_(torch.matmul(W, x), b, relu=True)
+    return x.unsqueeze(-1) if squeeze else x
+
+
+def conv_bn_relu(x: torch.Tensor, conv, bn) -> torch.Tensor:
+    """Single eval-mode Conv1d 1x1 + BatchNorm1d + ReLU (backbones.py:131 conv1/bn1)."""
+    key = _versions([conv], [bn])
+    cache = getattr(conv, "_pn2_folded", None)
+    if cache is None or cache[0] != key:
+        cache = (key, fold_conv_bn(conv, bn))
+        conv._pn2_folded = cache
+    W, b = cache[1]
+    return ext.bias_act_(torch.matmul(W, x), b, relu=True)

