@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--no-elide", action="store_true", help="also compute the attention the reference discards")
     ap.add_argument("--no-fused", action="store_true", help="disable the fused SA kernels (unfused torch MLPs)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--chunks", type=int, default=1, help="split the per-GPU batch into this many sub-batches that run "
+                    "concurrently on separate HIP streams inside the captured graph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,9 +175,33 @@ def main():
             torch.cuda.synchronize()
 
     use_graph = not args.no_graph
+    nchunk = max(1, args.chunks) if use_graph else 1
+    assert args.batch % nchunk == 0
+
+    def chunk_of(d, i):
+        n = args.batch // nchunk
+        return {k: (v[i * n:(i + 1) * n].contiguous() if torch.is_tensor(v) else chunk_of(v, i)) for k, v in d.items()}
+
+    chunks = [data] if nchunk == 1 else [chunk_of(data, i) for i in range(nchunk)]
+    streams = [torch.cuda.Stream() for _ in range(nchunk)] if nchunk > 1 else []
+    outs = [None] * nchunk
+
+    def forward_all():
+        """One step = the whole per-GPU batch; sub-batches are independent clouds, so they may overlap."""
+        if nchunk == 1:
+            outs[0] = model(chunks[0], dict(FLAGS))
+            return
+        cur = torch.cuda.current_stream()
+        for i, st in enumerate(streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs[i] = model(chunks[i], dict(FLAGS))
+        for st in streams:
+            cur.wait_stream(st)
+
     with torch.no_grad():
         for _ in range(max(args.warmup, 3) if use_graph else args.warmup):
-            out = model(data, dict(FLAGS))
+            forward_all()
         eager_ms = None
         if use_graph:
             # one forward = ~150 short kernels: capture it once, replay it per step (HIP graph, no host launch cost).
@@ -183,19 +209,17 @@ def main():
             sync_all()
             t0 = time.perf_counter()
             for _ in range(5):
-                model(data, dict(FLAGS))
+                forward_all()
             torch.cuda.synchronize()
             eager_ms = (time.perf_counter() - t0) / 5 * 1e3
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = model(data, dict(FLAGS))
+                forward_all()
             step = graph.replay
             for _ in range(args.warmup):
                 step()
         else:
-            def step():
-                nonlocal out
-                out = model(data, dict(FLAGS))
+            step = forward_all
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -209,7 +233,7 @@ def main():
         torch.cuda.synchronize()
         timer.enabled = False
     timer.remove()
-    assert torch.isfinite(out["pred_kp"]).all()
+    assert all(torch.isfinite(o["pred_kp"]).all() for o in outs)
 
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -242,7 +266,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "npoints": args.npoints,
                        "parallelism": "dp%d (independent batches, no collective)" % world,
                        "dead_attention_elided": not args.no_elide, "fused_sa_kernels": fused_on,
-                       "launch": "hipGraph replay" if use_graph else "eager", "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),
+                       "launch": "hipGraph replay" if use_graph else "eager", "concurrent_sub_batches": nchunk, "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),
                        "weights": "deterministic random init (no checkpoint available offline)"},
             "frame_alg_bytes": alg_bytes,
             "frame_hbm_frac": None if alg_bytes is None else round(alg_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 6),

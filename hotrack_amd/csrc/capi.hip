@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "pn2_common.h"
+#include "../../include/pn2_ext.h"
 
 namespace pn2 {
 static thread_local int g_last_hip_error = 0;
@@ -12,7 +13,9 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
 int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                         int *idx, hipStream_t st);
 int three_nn_dispatch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
-                      hipStream_t st);
+                      hipStream_t st, bool weights);
+int interp_pm_dispatch(int b, int c, int m, int n, const float *points, int ldp, const int *idx, const float *weight,
+                       float *out, int ldo, hipStream_t st);
 int knn_dispatch(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2, int *idx,
                  hipStream_t st);
 int group_fwd_dispatch(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,
@@ -119,7 +122,7 @@ int pn2_three_nn(int b, int n, int m, const float *unknown, const float *known, 
     if (b == 0 || n == 0) return PN2_OK;
     PN2_REQ(unknown && dist2 && idx && (known || m == 0), PN2_ENULL);
     PN2_REQ(b <= 65535 && fits_int((long)n * 3) && fits_int((long)m * 3), PN2_ERANGE);
-    return three_nn_dispatch(b, n, m, unknown, known, dist2, idx, (hipStream_t)stream);
+    return three_nn_dispatch(b, n, m, unknown, known, dist2, idx, (hipStream_t)stream, false);
 }
 
 int pn2_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
@@ -138,6 +141,25 @@ int pn2_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out
     PN2_REQ(grad_out && idx && weight && grad_points, PN2_ENULL);
     PN2_REQ(b <= 65535 && c <= 65535 * 16 && fits_int((long)n * 3), PN2_ERANGE);
     return interp_bwd_dispatch(b, c, n, m, grad_out, idx, weight, grad_points, (hipStream_t)stream);
+}
+
+/* ---- MI355X-side extensions (include/pn2_ext.h) that reuse the operator kernels ---------------------- */
+int pn2x_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *weight, int *idx,
+                          void *stream) {
+    PN2_REQ(b >= 0 && n >= 0 && m >= 3, PN2_EINVAL);  // fewer than 3 known points give inf distances -> NaN weights
+    if (b == 0 || n == 0) return PN2_OK;
+    PN2_REQ(unknown && known && weight && idx, PN2_ENULL);
+    PN2_REQ(b <= 65535 && fits_int((long)n * 3) && fits_int((long)m * 3), PN2_ERANGE);
+    return three_nn_dispatch(b, n, m, unknown, known, weight, idx, (hipStream_t)stream, true);
+}
+
+int pn2x_three_interpolate_pm(int b, int c, int m, int n, const float *points, int ldp, const int *idx,
+                              const float *weight, float *out, int ldo, void *stream) {
+    PN2_REQ(b >= 0 && c >= 0 && m >= 1 && n >= 0 && ldp >= c && ldo >= c, PN2_EINVAL);
+    if (b == 0 || c == 0 || n == 0) return PN2_OK;
+    PN2_REQ(points && idx && weight && out, PN2_ENULL);
+    PN2_REQ(fits_int((long)n * 3), PN2_ERANGE);
+    return interp_pm_dispatch(b, c, m, n, points, ldp, idx, weight, out, ldo, (hipStream_t)stream);
 }
 
 }  // extern "C"

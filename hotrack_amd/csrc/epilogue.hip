@@ -50,3 +50,49 @@ extern "C" int pn2x_bias_act(int b, int c, int n, float *y, const float *bias, i
     }
     return check_launch();
 }
+
+namespace pn2 {
+__global__ void __launch_bounds__(256)
+bias_act_pm_kernel(float *__restrict__ y, int ldy, const float *__restrict__ bias, int c, long rows, long rows_per_bias, int relu) {
+    const long total = rows * c;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / c;
+        const int ch = (int)(e - r * c);
+        float v = y[r * ldy + ch] + bias[(r / rows_per_bias) * c + ch];
+        y[r * ldy + ch] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(int n, int m, int c, const float *__restrict__ src, const int *__restrict__ idx, float *__restrict__ out, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / c;  // b*m + j
+        const int ch = (int)(e - row * c);
+        const long b = row / m;
+        out[e] = src[((size_t)b * n + idx[row]) * c + ch];
+    }
+}
+}  // namespace pn2
+
+extern "C" int pn2x_bias_act_pm(long rows, int c, float *y, int ldy, const float *bias, long rows_per_bias, int relu, void *stream) {
+    using namespace pn2;
+    if (rows < 0 || c < 0 || ldy < c || rows_per_bias < 1) return PN2_EINVAL;
+    if (rows == 0 || c == 0) return PN2_OK;
+    if (!y || !bias) return PN2_ENULL;
+    long blocks = (rows * c + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bias_act_pm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, bias, c, rows, rows_per_bias, relu);
+    return check_launch();
+}
+
+extern "C" int pn2x_gather_rows(int b, int n, int m, int c, const float *src, const int *idx, float *out, void *stream) {
+    using namespace pn2;
+    if (b < 0 || n < 1 || m < 0 || c < 0) return PN2_EINVAL;
+    if (b == 0 || m == 0 || c == 0) return PN2_OK;
+    if (!src || !idx || !out) return PN2_ENULL;
+    const long total = (long)b * m * c;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, m, c, src, idx, out, total);
+    return check_launch();
+}

@@ -110,4 +110,50 @@ int interp_bwd_dispatch(int b, int c, int n, int m, const float *grad_out, const
     return check_launch();
 }
 
+// ---- point-major variant (pn2x_three_interpolate_pm) --------------------------------------------------
+// points (b, m, ldp) and out (b, n, ldo) hold one point per ROW: the three source rows are read and the
+// destination row written as contiguous 16-byte segments (better coalescing than the channel-major
+// reference layout), and `out` may be a column block of a wider buffer (the reference's torch.cat of
+// [skip features | interpolated] then costs nothing).
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+interp_pm_kernel(int c, int m, int n, const float *__restrict__ points_all, int ldp, const int *__restrict__ idx_all,
+                 const float *__restrict__ weight_all, float *__restrict__ out_all, int ldo, long total) {
+    const int per_row = VEC ? (c >> 2) : c;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / per_row;  // = b*n + j
+        const int col = (int)(e - row * per_row);
+        const long b = row / n;
+        const int *__restrict__ id = idx_all + row * 3;
+        const float *__restrict__ w = weight_all + row * 3;
+        const float *__restrict__ src = points_all + (size_t)b * m * ldp;
+        const float w0 = w[0], w1 = w[1], w2 = w[2];
+        if constexpr (VEC) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(src + (size_t)id[0] * ldp + 4 * col);
+            const float4 p1 = *reinterpret_cast<const float4 *>(src + (size_t)id[1] * ldp + 4 * col);
+            const float4 p2 = *reinterpret_cast<const float4 *>(src + (size_t)id[2] * ldp + 4 * col);
+            float4 o;
+            o.x = __builtin_fmaf(w2, p2.x, __builtin_fmaf(w0, p0.x, w1 * p1.x));
+            o.y = __builtin_fmaf(w2, p2.y, __builtin_fmaf(w0, p0.y, w1 * p1.y));
+            o.z = __builtin_fmaf(w2, p2.z, __builtin_fmaf(w0, p0.z, w1 * p1.z));
+            o.w = __builtin_fmaf(w2, p2.w, __builtin_fmaf(w0, p0.w, w1 * p1.w));
+            *reinterpret_cast<float4 *>(out_all + (size_t)row * ldo + 4 * col) = o;
+        } else {
+            const float p0 = src[(size_t)id[0] * ldp + col], p1 = src[(size_t)id[1] * ldp + col], p2 = src[(size_t)id[2] * ldp + col];
+            out_all[(size_t)row * ldo + col] = __builtin_fmaf(w2, p2, __builtin_fmaf(w0, p0, w1 * p1));
+        }
+    }
+}
+
+int interp_pm_dispatch(int b, int c, int m, int n, const float *points, int ldp, const int *idx, const float *weight,
+                       float *out, int ldo, hipStream_t st) {
+    const bool vec = (c % 4 == 0) && (ldp % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)points | (uintptr_t)out) % 16 == 0);
+    const long total = (long)b * n * (vec ? c / 4 : c);
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (vec) hipLaunchKernelGGL(interp_pm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, c, m, n, points, ldp, idx, weight, out, ldo, total);
+    else hipLaunchKernelGGL(interp_pm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, c, m, n, points, ldp, idx, weight, out, ldo, total);
+    return check_launch();
+}
+
 }  // namespace pn2

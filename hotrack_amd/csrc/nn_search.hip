@@ -21,7 +21,11 @@ namespace pn2 {
 // ------------------------------------------------------------------------------------------
 constexpr int kNnTile = 2048;  // known points per LDS tile (32 KiB as float4)
 
-template <int THREADS>
+// WEIGHTS == false: the reference operator (squared distances + indices).
+// WEIGHTS == true : pn2x_three_nn_weights -- the same search, but the second output is the normalised
+//   inverse-distance interpolation weight the caller of the reference computes in four torch kernels
+//   (pointnet_utils.py:446-449: d = sqrt(d2); r = 1/(d + 1e-8); w = r / sum r).
+template <int THREADS, bool WEIGHTS>
 __global__ void __launch_bounds__(THREADS)
 three_nn_kernel(int n, int m, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
                 float *__restrict__ dist2_all, int *__restrict__ idx_all) {
@@ -62,23 +66,32 @@ three_nn_kernel(int n, int m, const float *__restrict__ unknown_all, const float
     if (active) {
         float *od = dist2_all + ((size_t)b * n + q) * 3;
         int *oi = idx_all + ((size_t)b * n + q) * 3;
-        od[0] = b1; od[1] = b2; od[2] = b3;
+        if constexpr (WEIGHTS) {
+            const float r1 = 1.0f / (__builtin_sqrtf(b1) + 1e-8f), r2 = 1.0f / (__builtin_sqrtf(b2) + 1e-8f),
+                        r3 = 1.0f / (__builtin_sqrtf(b3) + 1e-8f);
+            const float norm = (r1 + r2) + r3;  // torch.sum over 3 elements adds left to right
+            od[0] = r1 / norm; od[1] = r2 / norm; od[2] = r3 / norm;
+        } else {
+            od[0] = b1; od[1] = b2; od[2] = b3;
+        }
         oi[0] = i1; oi[1] = i2; oi[2] = i3;
     }
 }
 
 int three_nn_dispatch(int b, int n, int m, const float *unknown, const float *known, float *dist2,
-                      int *idx, hipStream_t st) {
+                      int *idx, hipStream_t st, bool weights) {
     if (b == 0 || n == 0) return PN2_OK;
     const int tile_cap = m < kNnTile ? m : kNnTile;
     const size_t lds = (size_t)(tile_cap > 0 ? tile_cap : 1) * sizeof(float4);
     // few queries -> single-wave workgroups so the grid still spreads over the CUs
     if ((long)b * n < 256L * 1024) {
         dim3 grid((n + 63) / 64, b);
-        hipLaunchKernelGGL(three_nn_kernel<64>, grid, dim3(64), lds, st, n, m, unknown, known, dist2, idx);
+        if (weights) hipLaunchKernelGGL((three_nn_kernel<64, true>), grid, dim3(64), lds, st, n, m, unknown, known, dist2, idx);
+        else hipLaunchKernelGGL((three_nn_kernel<64, false>), grid, dim3(64), lds, st, n, m, unknown, known, dist2, idx);
     } else {
         dim3 grid((n + 255) / 256, b);
-        hipLaunchKernelGGL(three_nn_kernel<256>, grid, dim3(256), lds, st, n, m, unknown, known, dist2, idx);
+        if (weights) hipLaunchKernelGGL((three_nn_kernel<256, true>), grid, dim3(256), lds, st, n, m, unknown, known, dist2, idx);
+        else hipLaunchKernelGGL((three_nn_kernel<256, false>), grid, dim3(256), lds, st, n, m, unknown, known, dist2, idx);
     }
     return check_launch();
 }

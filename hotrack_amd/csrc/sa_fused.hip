@@ -24,12 +24,30 @@ namespace pn2 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+struct SaArgs {
+    int N, S, K, lgK;
+    const float *a1f;   // (B,N,a1f_ld>=C1) point-major per-point feature term of layer 1, or nullptr
+    const float *xyz;   // (B,N,3) point coordinates, or nullptr (no relative-coordinate term)
+    const float *cxyz;  // (B,S,3) centroid coordinates (with xyz)
+    const float *wx;    // (C1,3) layer-1 weights of the [xyz_j - c_s] channels (with xyz)
+    const float *b1;    // (C1) layer-1 bias, or nullptr
+    const float *cadd;  // (B,S,cadd_ld>=C1) per-centroid additive term (centre features), or nullptr
+    int a1f_ld, cadd_ld;
+    const int *idx;     // (B,S,K)
+    const float *w2, *b2, *w3, *b3;
+    float *out;         // out[b*out_b + s*out_s + c*out_c]
+    long out_b;
+    int out_s, out_c;
+    int num_tiles, tiles_per_cloud;
+};
+
 template <int C1, int C2, int C3, int WC>
 __global__ void __launch_bounds__(256)
-sa_mlp_max_kernel(int N, int S, int K, int lgK, const float *__restrict__ A1, const float *__restrict__ c1v,
-                  const int *__restrict__ idx, const float *__restrict__ W2, const float *__restrict__ b2,
-                  const float *__restrict__ W3, const float *__restrict__ b3, float *__restrict__ out,
-                  int num_tiles, int tiles_per_cloud) {
+sa_mlp_max_kernel(const SaArgs A) {
+    const int N = A.N, S = A.S, K = A.K, lgK = A.lgK;
+    const float *__restrict__ W2 = A.w2, *__restrict__ b2 = A.b2, *__restrict__ W3 = A.w3, *__restrict__ b3 = A.b3;
+    float *__restrict__ out = A.out;
+    const int num_tiles = A.num_tiles, tiles_per_cloud = A.tiles_per_cloud;
     constexpr int WP = 4 / WC;
     constexpr int TM = WP * 64;
     constexpr int LD1 = C1 + 4, LD2 = C2 + 4;
@@ -69,28 +87,53 @@ sa_mlp_max_kernel(int N, int S, int K, int lgK, const float *__restrict__ A1, co
         }
     }
 
+    // phase-1 role of this thread: 4 consecutive layer-1 channels (fixed), rows tid/Q1 + i*(256/Q1)
+    constexpr int Q1 = C1 / 4;
+    static_assert(256 % Q1 == 0, "a thread keeps its channel quad across phase-1 iterations");
+    const int c4 = tid % Q1;
+    float wxr[4][3] = {{0.f}};
+    float4 b1r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (A.xyz) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) wxr[i][d] = A.wx[(4 * c4 + i) * 3 + d];
+    }
+    if (A.b1) b1r = *reinterpret_cast<const float4 *>(A.b1 + 4 * c4);
+
     const int SK = S * K;
     for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_cloud;
         const int pos0 = (tile - b * tiles_per_cloud) * TM;
-        const float *__restrict__ A1b = A1 + (size_t)b * N * C1;
-        const float *__restrict__ c1b = c1v + (size_t)b * S * C1;
-        const int *__restrict__ idxb = idx + (size_t)b * SK;
+        const int *__restrict__ idxb = A.idx + (size_t)b * SK;
 
-        // ---- phase 1: h1 = relu(A1[idx] + c1) -> LDS (row = position, C1 contiguous) -------------------
-        constexpr int Q1 = C1 / 4;
+        // ---- phase 1: h1 = relu(a1f[idx] + Wx (p_idx - c_s) + b1 + cadd_s) -> LDS (row = position) ---------
 #pragma unroll 4
-        for (int e = tid; e < TM * Q1; e += 256) {
-            const int row = e / Q1, c4 = e - row * Q1;
+        for (int row = tid / Q1; row < TM; row += 256 / Q1) {
             const int p = pos0 + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < SK) {
                 const int j = idxb[p];
                 const int s = p >> lgK;
-                const float4 a = *reinterpret_cast<const float4 *>(A1b + (size_t)j * C1 + 4 * c4);
-                const float4 c = *reinterpret_cast<const float4 *>(c1b + (size_t)s * C1 + 4 * c4);
-                v.x = fmaxf(a.x + c.x, 0.f); v.y = fmaxf(a.y + c.y, 0.f);
-                v.z = fmaxf(a.z + c.z, 0.f); v.w = fmaxf(a.w + c.w, 0.f);
+                v = b1r;
+                if (A.a1f) {
+                    const float4 a = *reinterpret_cast<const float4 *>(A.a1f + ((size_t)b * N + j) * A.a1f_ld + 4 * c4);
+                    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                }
+                if (A.xyz) {
+                    const float *pj = A.xyz + ((size_t)b * N + j) * 3;
+                    const float *cs = A.cxyz + ((size_t)b * S + s) * 3;
+                    const float dx = pj[0] - cs[0], dy = pj[1] - cs[1], dz = pj[2] - cs[2];
+                    v.x += wxr[0][0] * dx + wxr[0][1] * dy + wxr[0][2] * dz;
+                    v.y += wxr[1][0] * dx + wxr[1][1] * dy + wxr[1][2] * dz;
+                    v.z += wxr[2][0] * dx + wxr[2][1] * dy + wxr[2][2] * dz;
+                    v.w += wxr[3][0] * dx + wxr[3][1] * dy + wxr[3][2] * dz;
+                }
+                if (A.cadd) {
+                    const float4 c = *reinterpret_cast<const float4 *>(A.cadd + ((size_t)b * S + s) * A.cadd_ld + 4 * c4);
+                    v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+                }
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
             *reinterpret_cast<float4 *>(H1 + row * LD1 + 4 * c4) = v;
         }
@@ -185,7 +228,7 @@ sa_mlp_max_kernel(int N, int S, int K, int lgK, const float *__restrict__ A1, co
                     v = fmaxf(v, __shfl_xor(v, 32));
                     if (g == 0 && s < S) {
                         const int oc = (wc * NT3 + ct) * 16 + li;
-                        out[((size_t)b * C3 + oc) * S + s] = fmaxf(v, 0.f);  // relu commutes with max
+                        out[(size_t)b * A.out_b + (size_t)s * A.out_s + (size_t)oc * A.out_c] = fmaxf(v, 0.f);  // relu commutes with max
                     }
                 }
             }
@@ -195,16 +238,15 @@ sa_mlp_max_kernel(int N, int S, int K, int lgK, const float *__restrict__ A1, co
 }
 
 template <int C1, int C2, int C3, int WC>
-static int launch_sa(int b, int n, int s, int k, const float *a1, const float *c1, const int *idx, const float *w2,
-                     const float *b2, const float *w3, const float *b3, float *out, hipStream_t st) {
+static int launch_sa(int b, SaArgs a, hipStream_t st) {
     constexpr int WP = 4 / WC, TM = WP * 64;
-    const int sk = s * k;
-    const int tiles_per_cloud = (sk + TM - 1) / TM;
-    const long num_tiles_l = (long)b * tiles_per_cloud;
+    const int sk = a.S * a.K;
+    a.tiles_per_cloud = (sk + TM - 1) / TM;
+    const long num_tiles_l = (long)b * a.tiles_per_cloud;
     if (num_tiles_l > 2147483647L) return PN2_ERANGE;
-    const int num_tiles = (int)num_tiles_l;
-    int lgk = 0;
-    while ((1 << lgk) < k) ++lgk;
+    a.num_tiles = (int)num_tiles_l;
+    a.lgK = 0;
+    while ((1 << a.lgK) < a.K) ++a.lgK;
     const size_t lds = (size_t)TM * (C1 + 4 + C2 + 4) * sizeof(float);
     auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC>;
     static bool attr_set = false;  // once per instantiation; never during a later stream capture
@@ -214,27 +256,36 @@ static int launch_sa(int b, int n, int s, int k, const float *a1, const float *c
     }
     // persistent workgroups: weights are loaded into registers once per workgroup
     const int max_wg = 256 * (lds > 80 * 1024 ? 1 : 2);
-    const int grid = num_tiles < max_wg ? num_tiles : max_wg;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, n, s, k, lgk, a1, c1, idx, w2, b2, w3, b3, out, num_tiles,
-                       tiles_per_cloud);
+    const int grid = a.num_tiles < max_wg ? a.num_tiles : max_wg;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
     return check_launch();
 }
 
 }  // namespace pn2
 
-extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c3, const float *a1, const float *c1v,
-                               const int *idx, const float *w2, const float *b2, const float *w3, const float *b3,
-                               float *out, void *stream) {
+extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c3, const float *a1f, int a1f_ld,
+                               const float *xyz, const float *cxyz, const float *wx, const float *b1, const float *cadd,
+                               int cadd_ld, const int *idx,
+                               const float *w2, const float *b2, const float *w3, const float *b3, float *out,
+                               long out_b, int out_s, int out_c, void *stream) {
     using namespace pn2;
     if (b < 0 || n < 1 || s < 0 || k < 1) return PN2_EINVAL;
     if (b == 0 || s == 0) return PN2_OK;
-    if (!a1 || !c1v || !idx || !w2 || !b2 || !w3 || !b3 || !out) return PN2_ENULL;
+    if (!idx || !w2 || !b2 || !w3 || !b3 || !out) return PN2_ENULL;
+    if (!a1f && !xyz) return PN2_ENULL;          // layer 1 needs at least one per-point term
+    if (xyz && (!cxyz || !wx)) return PN2_ENULL;
+    if ((a1f && (a1f_ld < c1 || a1f_ld % 4)) || (cadd && (cadd_ld < c1 || cadd_ld % 4))) return PN2_EINVAL;
     if (!(k == 16 || k == 32 || k == 64)) return PN2_ERANGE;
-    if (((uintptr_t)a1 | (uintptr_t)c1v | (uintptr_t)w2 | (uintptr_t)w3) % 16 != 0) return PN2_EINVAL;
+    if (((uintptr_t)a1f | (uintptr_t)cadd | (uintptr_t)b1 | (uintptr_t)w2 | (uintptr_t)w3) % 16 != 0) return PN2_EINVAL;
+    SaArgs a;
+    a.N = n; a.S = s; a.K = k; a.lgK = 0;
+    a.a1f = a1f; a.a1f_ld = a1f_ld; a.cadd_ld = cadd_ld; a.xyz = xyz; a.cxyz = cxyz; a.wx = wx; a.b1 = b1; a.cadd = cadd; a.idx = idx;
+    a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out; a.out_b = out_b; a.out_s = out_s; a.out_c = out_c;
+    a.num_tiles = 0; a.tiles_per_cloud = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2>(b, n, s, k, a1, c1v, idx, w2, b2, w3, b3, out, st);
-    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4>(b, n, s, k, a1, c1v, idx, w2, b2, w3, b3, out, st);
-    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4>(b, n, s, k, a1, c1v, idx, w2, b2, w3, b3, out, st);
+    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2>(b, a, st);
+    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4>(b, a, st);
+    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4>(b, a, st);
     return PN2_ERANGE;
 }
 

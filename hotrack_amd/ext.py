@@ -32,35 +32,114 @@ def kabsch(x: torch.Tensor, y: torch.Tensor):
     return R, t
 
 
-_lib.pn2x_sa_mlp_max.argtypes = [_ci] * 7 + [_vp] * 8 + [_vp]
+_cl = ctypes.c_long
+_lib.pn2x_sa_mlp_max.argtypes = [_ci] * 7 + [_vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cl, _ci, _ci, _vp]
 _lib.pn2x_sa_mlp_max.restype = _ci
 _lib.pn2x_sa_mlp_max_supported.argtypes = [_ci] * 4
 _lib.pn2x_sa_mlp_max_supported.restype = _ci
+_lib.pn2x_three_nn_weights.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_three_nn_weights.restype = _ci
+_lib.pn2x_three_interpolate_pm.argtypes = [_ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp]
+_lib.pn2x_three_interpolate_pm.restype = _ci
+_lib.pn2x_gather_rows.argtypes = [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]
+_lib.pn2x_gather_rows.restype = _ci
+_lib.pn2x_bias_act_pm.argtypes = [_cl, _ci, _vp, _ci, _vp, _cl, _ci, _vp]
+_lib.pn2x_bias_act_pm.restype = _ci
 
 
 def sa_mlp_max_supported(k: int, c1: int, c2: int, c3: int) -> bool:
     return bool(_lib.pn2x_sa_mlp_max_supported(k, c1, c2, c3))
 
 
-def sa_mlp_max(a1: torch.Tensor, c1v: torch.Tensor, idx: torch.Tensor, w2, b2, w3, b3) -> torch.Tensor:
-    """a1 (B,N,C1) per-point layer-1 term, c1v (B,S,C1) per-centroid term, idx (B,S,K) int32,
-    w2 (C2,C1), w3 (C3,C2) BN-folded -> (B,C3,S) = relu(max_k W3 relu(W2 relu(a1[idx]+c1v)+b2)+b3)."""
-    B, N, C1 = a1.shape
-    _, S, K = idx.shape
-    C2, C3 = w2.shape[0], w3.shape[0]
-    f32, i32 = torch.float32, torch.int32
-    pa = _native._ptr(a1, "a1", f32, B * N * C1)
-    pc = _native._ptr(c1v, "c1v", f32, B * S * C1)
-    pi = _native._ptr(idx, "idx", i32, B * S * K)
-    pw2 = _native._ptr(w2, "w2", f32, C2 * C1)
-    pb2 = _native._ptr(b2, "b2", f32, C2)
-    pw3 = _native._ptr(w3, "w3", f32, C3 * C2)
-    pb3 = _native._ptr(b3, "b3", f32, C3)
-    out = torch.empty((B, C3, S), dtype=f32, device=a1.device)
-    with torch.cuda.device(a1.device):
-        _native._check(_lib.pn2x_sa_mlp_max(B, N, S, K, C1, C2, C3, pa, pc, pi, pw2, pb2, pw3, pb3, out.data_ptr(),
-                                            _native._stream(a1)), "sa_mlp_max")
+def _rows(t: torch.Tensor, name: str, cols: int):
+    """Validate a point-major (B, R, >=cols) fp32 tensor whose rows may be a column block of a wider
+    buffer (last dim contiguous, uniform row stride).  Returns (data_ptr, row_stride)."""
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3:
+        raise TypeError(f"{name}: expected a 3-D float32 GPU tensor")
+    B, R, C = t.shape
+    if C < cols or t.stride(2) != 1 or (R > 1 and B > 1 and t.stride(0) != R * t.stride(1)):
+        raise ValueError(f"{name}: unsupported layout shape={tuple(t.shape)} strides={t.stride()}")
+    return t.data_ptr(), t.stride(1)
+
+
+def sa_mlp_max(idx: torch.Tensor, w2, b2, w3, b3, *, a1f=None, xyz=None, cxyz=None, wx=None, b1=None, cadd=None,
+               out=None, point_major=False) -> torch.Tensor:
+    """Fused SA scale (include/pn2_ext.h: pn2x_sa_mlp_max).
+    idx (B,S,K) int32; a1f (B,N,>=C1) rows; xyz (B,N,3); cxyz (B,S,3); wx (C1,3); b1 (C1); cadd (B,S,>=C1).
+    Returns (B,C3,S), or (B,S,C3) if point_major; `out` may be a (B,S,C3) column block of a wider buffer."""
+    B, S, K = idx.shape
+    C1, C2, C3 = w2.shape[1], w2.shape[0], w3.shape[0]
+    f32 = torch.float32
+    N = a1f.shape[1] if a1f is not None else xyz.shape[1]
+    pa, lda = (None, 0) if a1f is None else _rows(a1f, "a1f", C1)
+    pc, ldc = (None, 0) if cadd is None else _rows(cadd, "cadd", C1)
+    px = None if xyz is None else _native._ptr(xyz, "xyz", f32, B * N * 3)
+    pcx = None if cxyz is None else _native._ptr(cxyz, "cxyz", f32, B * S * 3)
+    pwx = None if wx is None else _native._ptr(wx, "wx", f32, C1 * 3)
+    pb1 = None if b1 is None else _native._ptr(b1, "b1", f32, C1)
+    pi = _native._ptr(idx, "idx", torch.int32, B * S * K)
+    pw2, pb2 = _native._ptr(w2, "w2", f32, C2 * C1), _native._ptr(b2, "b2", f32, C2)
+    pw3, pb3 = _native._ptr(w3, "w3", f32, C3 * C2), _native._ptr(b3, "b3", f32, C3)
+    if out is None:
+        out = torch.empty((B, S, C3) if point_major else (B, C3, S), dtype=f32, device=idx.device)
+        ob, os_, oc = (S * C3, C3, 1) if point_major else (C3 * S, 1, S)
+        po = out.data_ptr()
+    else:
+        po, ld = _rows(out, "out", C3)
+        ob, os_, oc = out.stride(0), ld, 1
+    with torch.cuda.device(idx.device):
+        _native._check(_lib.pn2x_sa_mlp_max(B, N, S, K, C1, C2, C3, pa, lda, px, pcx, pwx, pb1, pc, ldc, pi, pw2, pb2, pw3,
+                                            pb3, po, ob, os_, oc, _native._stream(idx)), "sa_mlp_max")
     return out
+
+
+def three_nn_weights(unknown: torch.Tensor, known: torch.Tensor):
+    """unknown (B,n,3), known (B,m>=3,3) -> (weight (B,n,3) normalised inverse distances, idx (B,n,3) int32)."""
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    f32 = torch.float32
+    w = torch.empty((B, n, 3), dtype=f32, device=unknown.device)
+    idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
+    with torch.cuda.device(unknown.device):
+        _native._check(_lib.pn2x_three_nn_weights(B, n, m, _native._ptr(unknown, "unknown", f32, B * n * 3),
+                                                  _native._ptr(known, "known", f32, B * m * 3), w.data_ptr(), idx.data_ptr(),
+                                                  _native._stream(unknown)), "three_nn_weights")
+    return w, idx
+
+
+def three_interpolate_pm(points: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """points (B,M,C) rows, idx/weight (B,n,3) -> out (B,n,C) rows (may be a column block of a wider buffer)."""
+    B, M, C = points.shape
+    n = idx.shape[1]
+    pp, ldp = _rows(points, "points", C)
+    po, ldo = _rows(out, "out", C)
+    with torch.cuda.device(points.device):
+        _native._check(_lib.pn2x_three_interpolate_pm(B, C, M, n, pp, ldp, _native._ptr(idx, "idx", torch.int32, B * n * 3),
+                                                      _native._ptr(weight, "weight", torch.float32, B * n * 3), po, ldo,
+                                                      _native._stream(points)), "three_interpolate_pm")
+    return out
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """src (B,N,C) contiguous, idx (B,M) int32 -> (B,M,C)."""
+    B, N, C = src.shape
+    M = idx.shape[1]
+    out = torch.empty((B, M, C), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _native._check(_lib.pn2x_gather_rows(B, N, M, C, _native._ptr(src, "src", torch.float32, B * N * C),
+                                             _native._ptr(idx, "idx", torch.int32, B * M), out.data_ptr(),
+                                             _native._stream(src)), "gather_rows")
+    return out
+
+
+def bias_act_pm_(y: torch.Tensor, bias: torch.Tensor, rows_per_bias: int, relu: bool = True) -> torch.Tensor:
+    """In place on point-major y (B,R,C): y[b,r,:] = act(y[b,r,:] + bias[(b*R+r)//rows_per_bias, :])."""
+    B, R, C = y.shape
+    py, ldy = _rows(y, "y", C)
+    with torch.cuda.device(y.device):
+        _native._check(_lib.pn2x_bias_act_pm(B * R, C, py, ldy, _native._ptr(bias.contiguous(), "bias", torch.float32, bias.numel()),
+                                             rows_per_bias, 1 if relu else 0, _native._stream(y)), "bias_act_pm")
+    return y
 
 
 _lib.pn2x_bias_act.argtypes = [_ci, _ci, _ci, _vp, _vp, _ci, _vp]

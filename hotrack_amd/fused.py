@@ -60,29 +60,30 @@ def sa_scale(convs, bns, xyz: torch.Tensor, points: Optional[torch.Tensor], new_
         return None
     (W1, b1), (W2, b2), (W3, b3) = _folded(convs, bns)
     D = 0 if points is None else points.shape[1]
-    Wx = W1[:, D:D + 3]
-    # per-point half of layer 1:  (B,N,C1) = [points ; xyz]^T W1[:, :D+3]^T
-    a1 = torch.matmul(xyz.transpose(1, 2), Wx.t())
-    if D:
-        a1 = torch.baddbmm(a1, points.transpose(1, 2), W1[:, :D].t().unsqueeze(0).expand(points.shape[0], -1, -1))
-    # per-centroid half:  bias - Wx c_s (+ Wc centre_feat_s)
-    c1 = b1 - torch.matmul(new_xyz.transpose(1, 2), Wx.t())
-    if center_feat is not None:
-        Wc = W1[:, D + 3:]
-        c1 = torch.baddbmm(c1, center_feat.transpose(1, 2), Wc.t().unsqueeze(0).expand(center_feat.shape[0], -1, -1))
-    return ext.sa_mlp_max(a1.contiguous(), c1.contiguous(), group_idx.contiguous(), W2, b2, W3, b3)
+    B = xyz.shape[0]
+    parts = getattr(convs, "_pn2_w1_parts", None)
+    if parts is None or parts[0] is not W1:
+        parts = (W1, W1[:, :D].t().contiguous(), W1[:, D:D + 3].contiguous(), W1[:, D + 3:].t().contiguous())
+        convs._pn2_w1_parts = parts
+    _, W1f_t, Wx, Wc_t = parts
+    # per-point feature half of layer 1 as ONE dense GEMM over the N points: (B,N,C1) = points^T W1[:, :D]^T
+    a1f = torch.matmul(points.transpose(1, 2), W1f_t) if D else None
+    # per-centroid half W1[:, centre] . centre_feat_s; the [xyz_j - c_s] term and the bias are added in-kernel
+    cadd = torch.matmul(center_feat.transpose(1, 2), Wc_t) if center_feat is not None else None
+    return ext.sa_mlp_max(group_idx.contiguous(), W2, b2, W3, b3, a1f=a1f, xyz=xyz.transpose(1, 2).contiguous(),
+                          cxyz=new_xyz.transpose(1, 2).contiguous(), wx=Wx, b1=b1, cadd=cadd)
 
 
 def mlp_stack(x: torch.Tensor, convs, bns) -> torch.Tensor:
     """Eval-mode [Conv 1x1 + BN + ReLU]* on (B,C,N) (or (B,C,N,1)) activations: BatchNorm folded into
     the weights, GEMM by the BLAS library, bias + ReLU in one in-place streaming kernel.
     (reference: the Conv1d/Conv2d + BatchNorm + ReLU stacks of pointnet_utils.py:460-462, :504-506)."""
-    squeeze = x.dim() == 4
-    if squeeze:
-        x = x.squeeze(-1)
+    shape4 = x.shape if x.dim() == 4 else None
+    if shape4 is not None:
+        x = x.reshape(shape4[0], shape4[1], shape4[2] * shape4[3])
     for W, b in _folded(convs, bns):
         x = ext.bias_act_(torch.matmul(W, x), b, relu=True)
-    return x.unsqueeze(-1) if squeeze else x
+    return x.view(shape4[0], -1, shape4[2], shape4[3]) if shape4 is not None else x
 
 
 def conv_bn_relu(x: torch.Tensor, conv, bn) -> torch.Tensor:

@@ -32,19 +32,28 @@ int pn2x_kabsch(int b, int xb, int num, const float *x, const float *y, float *R
  * (pointnet_utils.py:389-403 for SA-MSG, :566-581 for GivenCenterPoints) without ever
  * materialising the (B, C, S, K) grouped tensors.
  *
- * Layer 1 is linear in its input [feat_j | xyz_j - c_s | centre_feat_s], so the caller splits it:
- *   a1  (b, n, c1)  per-point term     W1[:, feat|xyz] . [feat_j ; xyz_j]            (point-major)
- *   c1v (b, s, c1)  per-centroid term  bias1 - W1[:, xyz] . c_s + W1[:, centre] . centre_feat_s
- * and the kernel computes, for every centroid s and neighbour idx[b,s,k] (idx: (b, s, k) int32),
- *   h1 = relu(a1[idx] + c1v);  h2 = relu(w2 h1 + b2);  h3 = w3 h2 + b3;  out = relu(max_k h3)
- * w2 (c2, c1), w3 (c3, c2) row-major; out (b, c3, s).  fp32 throughout (matrix cores:
+ * Layer 1 is linear in its input [feat_j | xyz_j - c_s | centre_feat_s], so it is split:
+ *   a1f  (b, n, a1f_ld) or NULL  per-point feature term  W1[:, feat] . feat_j  (point-major rows of
+ *                            a1f_ld >= c1 floats; a GEMM over the n points instead of the s*k positions)
+ *   xyz  (b, n, 3)  or NULL  point coordinates; with cxyz (b, s, 3) centroids and wx (c1, 3) =
+ *                            W1[:, xyz] the kernel adds  wx . (xyz_j - c_s)  itself
+ *   b1   (c1)       or NULL  layer-1 bias
+ *   cadd (b, s, cadd_ld) or NULL  per-centroid term  W1[:, centre] . centre_feat_s
+ * and for every centroid s and neighbour j = idx[b,s,k] (idx: (b, s, k) int32) computes
+ *   h1 = relu(a1f[j] + wx.(xyz_j - c_s) + b1 + cadd_s);  h2 = relu(w2 h1 + b2);  h3 = w3 h2 + b3;
+ *   out[b*out_b + s*out_s + c*out_c] = relu(max_k h3[c])
+ * (out strides in floats: channel-major (b,c3,s) = {c3*s, 1, s}; point-major rows of a wider
+ * (b, s, ld) buffer = {s*ld, ld, 1}, which lets the caller skip the reference's torch.cat).
+ * w2 (c2, c1), w3 (c3, c2) row-major, BN folded.  fp32 throughout (matrix cores:
  * v_mfma_f32_16x16x4_f32, exact fp32).  Supported: k in {16,32,64} and (c1,c2,c3) in
  * {(32,32,64), (64,64,128), (128,128,192)} -- PN2_ERANGE otherwise (query with
  * pn2x_sa_mlp_max_supported; callers keep the unfused operator path for other shapes).
  */
-int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c3, const float *a1, const float *c1v,
-                    const int *idx, const float *w2, const float *b2, const float *w3, const float *b3,
-                    float *out, void *stream);
+int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c3, const float *a1f, int a1f_ld,
+                    const float *xyz, const float *cxyz, const float *wx, const float *b1, const float *cadd,
+                    int cadd_ld, const int *idx,
+                    const float *w2, const float *b2, const float *w3, const float *b3, float *out,
+                    long out_b, int out_s, int out_c, void *stream);
 int pn2x_sa_mlp_max_supported(int k, int c1, int c2, int c3);
 
 /*
@@ -53,6 +62,36 @@ int pn2x_sa_mlp_max_supported(int k, int c1, int c2, int c3);
  * stacks, pointnet_utils.py:460-462) whose GEMM half is a library GEMM on the (b, c, n) tensor.
  */
 int pn2x_bias_act(int b, int c, int n, float *y, const float *bias, int relu, void *stream);
+
+/*
+ * three_nn that returns interpolation WEIGHTS: idx (b,n,3) as pn2_three_nn, and
+ *   weight[t] = (1/(sqrt(d2_t)+1e-8)) / sum_t (1/(sqrt(d2_t)+1e-8))
+ * i.e. the sqrt of pointnet2_utils.py:135 plus the three torch kernels of the reference's caller
+ * (pointnet_utils.py:447-449) folded into the search kernel's epilogue.  Needs m >= 3.
+ */
+int pn2x_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *weight, int *idx,
+                          void *stream);
+
+/*
+ * three_interpolate on POINT-MAJOR features: points (b, m, ldp), out (b, n, ldo), c <= ldp, ldo channels
+ * per row; out[b,j,ch] = sum_t weight[b,j,t] * points[b, idx[b,j,t], ch]  (same arithmetic as
+ * pn2_three_interpolate).  `out` may point at a column block of a wider row (ldo > c).
+ */
+int pn2x_three_interpolate_pm(int b, int c, int m, int n, const float *points, int ldp, const int *idx,
+                              const float *weight, float *out, int ldo, void *stream);
+
+/*
+ * Row gather on point-major data: out[b, j, :] = src[b, idx[b,j], :]  (src (b,n,c), idx (b,m), out (b,m,c)).
+ * The point-major twin of pn2_gather_points (used for the FPS-selected centroid coordinates).
+ */
+int pn2x_gather_rows(int b, int n, int m, int c, const float *src, const int *idx, float *out, void *stream);
+
+/*
+ * In-place point-major epilogue: y[r, ch] = act(y[r, ch] + bias[r / rows_per_bias, ch]) for y (rows, c) with row
+ * stride ldy.  rows_per_bias = rows gives an ordinary per-channel bias; rows_per_bias = points-per-cloud adds a
+ * per-cloud vector (the broadcast global feature of the reference's fp3 layer, pointnet_utils.py:443-444).
+ */
+int pn2x_bias_act_pm(long rows, int c, float *y, int ldy, const float *bias, long rows_per_bias, int relu, void *stream);
 
 #ifdef __cplusplus
 }

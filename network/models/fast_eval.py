@@ -1,0 +1,230 @@
+"""Point-major eval forward of HandTrackNet for MI355X (inference fast path).
+
+Same network, same parameters, same arithmetic up to fp32 re-association as
+`HandTrackNet.forward` (reference hand_network.py:78-157) -- but laid out for the GPU:
+
+  * activations are POINT-MAJOR (B, N, C): every 1x1 convolution becomes ONE 2-D GEMM over all
+    B*N points with bias+ReLU in the GEMM epilogue (BatchNorm folded), instead of B small
+    batched GEMMs + separate bias / BN / ReLU passes on channel-major tensors;
+  * each set-abstraction scale is one fused kernel (pn2x_sa_mlp_max): the per-point half of
+    its first layer is a dense GEMM over the N points (for q1/q2 all four scale GEMMs are ONE
+    (B*N x 384) x (384 x 512) GEMM), the gather / relative-xyz / centre terms, layers 2-3 (fp32
+    MFMA) and the max over K happen in-kernel and write straight into the consumer's input
+    buffer (no torch.cat);
+  * feature propagation = three_nn with the interpolation weights computed in its epilogue +
+    a point-major interpolate that also writes into the consumer's buffer;
+  * the discarded attention of the "TransT" blocks is not computed (see transformer.py).
+
+It is selected by HandTrackNet.forward when the fused backend is enabled, the module is in
+eval mode, grad is disabled and the input is on the GPU.  Parity: tests/test_gpu_fused.py
+(vs the unfused operator path and vs the golden vectors captured from the imported reference).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .hand_utils import handkp2palmkp, ransac_rt
+
+
+def _lin_relu(x2d: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """relu(x W^T + b) as one GEMM with a bias+ReLU epilogue (hipBLASLt)."""
+    return torch._addmm_activation(b, x2d, W.t())
+
+
+class FastEval:
+    def __init__(self, net):
+        self.net = net
+        self._key = None
+        self.P = None
+
+    # ------------------------------------------------------------------------------------
+    def _versions(self):
+        return tuple(p._version for p in self.net.parameters()) + tuple(b._version for b in self.net.buffers())
+
+    def prepare(self, force: bool = False):
+        """Fold BatchNorm into the convolutions and pre-arrange the weights (cached; refreshed when any
+        parameter / buffer changed in place)."""
+        key = self._versions()
+        if not force and self._key == key:
+            return self.P
+        from hotrack_amd.fused import fold_conv_bn as fold
+        net, bh = self.net, self.net.bhand
+        P = {}
+
+        def msg(mod, i):
+            return [fold(c, n) for c, n in zip(mod.conv_blocks[i], mod.bn_blocks[i])]
+
+        (W1, b1), l2, l3 = msg(bh.sa1, 0)
+        P["sa1"] = dict(wx=W1.contiguous(), b1=b1, l2=l2, l3=l3)
+        (W1, b1), l2, l3 = msg(bh.sa2, 0)
+        D = W1.shape[1] - 3
+        P["sa2"] = dict(w1f=W1[:, :D].contiguous(), wx=W1[:, D:].contiguous(), b1=b1, l2=l2, l3=l3)
+        P["sa3"] = [fold(c, n) for c, n in zip(bh.sa3.mlp_convs, bh.sa3.mlp_bns)]  # in = [xyz | feat]
+        fp3 = [fold(c, n) for c, n in zip(bh.fp3.mlp_convs, bh.fp3.mlp_bns)]
+        c_l2 = bh.sa2.out_channel
+        P["fp3"] = dict(wa=fp3[0][0][:, :c_l2].contiguous(), wb=fp3[0][0][:, c_l2:].contiguous(), b=fp3[0][1], rest=fp3[1:])
+        P["fp2"] = [fold(c, n) for c, n in zip(bh.fp2.mlp_convs, bh.fp2.mlp_bns)]  # in = [l1_feat | interp]
+        fp1 = [fold(c, n) for c, n in zip(bh.fp1.mlp_convs, bh.fp1.mlp_bns)]  # in = [xyz | interp]
+        W = fp1[0][0]
+        fp1[0] = (torch.cat([W[:, 3:], W[:, :3]], dim=1).contiguous(), fp1[0][1])  # -> [interp | xyz] (aligned block first)
+        P["fp1"] = fp1
+        P["conv1"] = fold(bh.conv1, bh.bn1)
+        C = bh.out_dim
+        wq, q = [], {}
+        for name, mod in (("q1", net.q1), ("q2", net.q2)):
+            for i in range(2):
+                (W1, b1), l2, l3 = msg(mod, i)
+                wq.append(W1[:, :C])
+                q[(name, i)] = dict(wx=W1[:, C:C + 3].contiguous(), b1=b1, l2=l2, l3=l3, K=mod.nsample_list[i],
+                                    wc=W1[:, C + 3:] if W1.shape[1] > C + 3 else None)
+        P["q"] = q
+        P["wq"] = torch.cat(wq, dim=0).contiguous()  # (4*128, C): all four per-point layer-1 GEMMs at once
+        P["wc2"] = torch.cat([q[("q2", 0)]["wc"], q[("q2", 1)]["wc"]], dim=0).contiguous()  # (2*128, C)
+        P["r1"] = (net.r1.linear.weight.detach().squeeze(-1), net.r1.linear.bias.detach(), net.r1._perm.t().contiguous())
+        P["r2"] = (net.r2.linear.weight.detach().squeeze(-1), net.r2.linear.bias.detach(), net.r2._perm.t().contiguous())
+        self.P, self._key = P, key
+        return P
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def _ffn_block(m, x):
+        """attn_module with the attention elided: norm1 [-> FFN -> norm2] on token-major x (T, C)."""
+        x = F.layer_norm(x, m.norm1.normalized_shape, m.norm1.weight, m.norm1.bias, m.norm1.eps)
+        if not m.no_linear:
+            h = _lin_relu(x, m.linear1.weight, m.linear1.bias)
+            x = x + F.linear(h, m.linear2.weight, m.linear2.bias)
+            x = F.layer_norm(x, m.norm2.normalized_shape, m.norm2.weight, m.norm2.bias, m.norm2.eps)
+        return x
+
+    @torch.no_grad()
+    def forward(self, input, flag_dict):
+        from hotrack_amd import ext
+        from hotrack_amd import pointnet2_utils as ops
+        net = self.net
+        P = self.prepare()
+        dev = net.device
+        if flag_dict["track_flag"]:
+            palm = input["pred_palm_template"]
+        else:
+            palm = input["gt_hand_pose"]["palm_template"]
+        palm = palm.to(dev).float()
+        kp = input["jittered_hand_kp"].to(dev).float()  # (B,21,3)
+        pts = input["hand_points"].to(dev).float()  # (B,N,3)
+        B, N, _ = pts.shape
+        J = kp.shape[1]
+        f32 = dict(dtype=torch.float32, device=pts.device)
+
+        # ---- hand frame: R^T (x - t) / s, written for row vectors ------------------------------
+        if net.handframe != "kp":
+            raise NotImplementedError("fast path covers handframe='kp' (HandTrackNet's configuration)")
+        R, t, _, _, _ = ransac_rt(palm, handkp2palmkp(kp))
+        scale = 0.2 * torch.ones(1, **f32)
+        canon = {"scale": scale, "rotation": R, "translation": t}
+        tt = t.transpose(1, 2)
+        xyz2 = torch.matmul(pts - tt, R).div_(0.2)  # (B,N,3) hand points, hand frame
+        xyz1 = torch.matmul(kp - tt, R).div_(0.2)  # (B,J,3) keypoints, hand frame
+
+        bh = net.bhand
+        # ---- sa1: 1024 -> 256 centroids, r = 0.1, K = 32, MLP [3 -> 32 -> 32 -> 64] ------------------
+        p = P["sa1"]
+        S1, K1 = bh.sa1.npoint, bh.sa1.nsample_list[0]
+        l1_xyz = ext.gather_rows(xyz2, ops.furthest_point_sample(xyz2, S1))
+        idx1 = ops.ball_query(bh.sa1.radius_list[0], K1, xyz2, l1_xyz)
+        c_l1 = p["l3"][0].shape[0]
+        fp2_w = P["fp2"][0][0].shape[1]
+        fp2_in = torch.empty((B, S1, fp2_w), **f32)  # [l1_feat | interp(l2 -> l1)]
+        l1_feat = fp2_in[:, :, :c_l1]
+        ext.sa_mlp_max(idx1, *p["l2"], *p["l3"], xyz=xyz2, cxyz=l1_xyz, wx=p["wx"], b1=p["b1"], out=l1_feat)
+
+        # ---- sa2: 256 -> 128, r = 0.2, K = 32, MLP [64+3 -> 64 -> 64 -> 128] ---------------------------
+        p = P["sa2"]
+        S2, K2 = bh.sa2.npoint, bh.sa2.nsample_list[0]
+        l2_xyz = ext.gather_rows(l1_xyz, ops.furthest_point_sample(l1_xyz, S2))
+        idx2 = ops.ball_query(bh.sa2.radius_list[0], K2, l1_xyz, l2_xyz)
+        a1f = F.linear(l1_feat.reshape(B * S1, c_l1), p["w1f"]).view(B, S1, -1)
+        c_l2 = p["l3"][0].shape[0]
+        l2_feat = torch.empty((B, S2, c_l2), **f32)
+        ext.sa_mlp_max(idx2, *p["l2"], *p["l3"], a1f=a1f, xyz=l1_xyz, cxyz=l2_xyz, wx=p["wx"], b1=p["b1"], out=l2_feat)
+
+        # ---- sa3: group-all [xyz | feat] -> MLP -> max over the 128 points ------------------------------
+        x = torch.cat([l2_xyz, l2_feat], dim=2).view(B * S2, -1)
+        for W, b in P["sa3"]:
+            x = _lin_relu(x, W, b)
+        l3 = x.view(B, S2, -1).max(dim=1)[0]  # (B,512)
+
+        # ---- fp3: S == 1 -> the global feature is broadcast; first layer split so it is applied once per cloud
+        p = P["fp3"]
+        g = F.linear(l3, p["wb"], p["b"])  # (B,256) per-cloud half, bias included
+        h = F.linear(l2_feat.view(B * S2, c_l2), p["wa"]).view(B, S2, -1)
+        ext.bias_act_pm_(h, g, rows_per_bias=S2, relu=True)
+        x = h.view(B * S2, -1)
+        for W, b in p["rest"]:
+            x = _lin_relu(x, W, b)
+        l2_out = x.view(B, S2, -1)
+
+        # ---- fp2: interpolate l2 -> l1, [l1_feat | interp] -> MLP ---------------------------------------
+        w, i3 = ext.three_nn_weights(l1_xyz, l2_xyz)
+        ext.three_interpolate_pm(l2_out, i3, w, fp2_in[:, :, c_l1:])
+        x = fp2_in.view(B * S1, fp2_w)
+        for W, b in P["fp2"]:
+            x = _lin_relu(x, W, b)
+        l1_out = x.view(B, S1, -1)
+
+        # ---- fp1: interpolate l1 -> l0, [interp | xyz] (weights permuted to match) -> MLP; conv1 ----------
+        c_i = l1_out.shape[2]
+        fp1_in = torch.empty((B, N, c_i + 4), **f32)
+        w, i3 = ext.three_nn_weights(xyz2, l1_xyz)
+        ext.three_interpolate_pm(l1_out, i3, w, fp1_in[:, :, :c_i])
+        fp1_in[:, :, c_i:c_i + 3] = xyz2
+        x = fp1_in.view(B * N, c_i + 4)[:, :c_i + 3]
+        for W, b in P["fp1"]:
+            x = _lin_relu(x, W, b)
+        src2 = _lin_relu(x, *P["conv1"])  # (B*N, C) per-point backbone features
+        C = src2.shape[1]
+
+        # ---- q1 / q2: kNN (16 / 64) neighbourhoods of the 21 keypoints ------------------------------------
+        aq = F.linear(src2, P["wq"]).view(B, N, -1)  # (B,N,4*128): per-point layer-1 halves of q1s0,q1s1,q2s0,q2s1
+        q = P["q"]
+        idxs = []
+        for i in range(2):
+            _, gi = ops.knn(q[("q1", i)]["K"], xyz1, xyz2)
+            idxs.append(gi)
+        c_q = q[("q1", 0)]["l3"][0].shape[0]
+        c1q = q[("q1", 0)]["l2"][0].shape[1]
+        f11 = torch.empty((B, J, 2 * c_q), **f32)
+        for i in range(2):
+            p = q[("q1", i)]
+            ext.sa_mlp_max(idxs[i], *p["l2"], *p["l3"], a1f=aq[:, :, i * c1q:(i + 1) * c1q], xyz=xyz2, cxyz=xyz1,
+                           wx=p["wx"], b1=p["b1"], out=f11[:, :, i * c_q:(i + 1) * c_q])
+        Wr, br, perm = P["r1"]
+        f12 = F.linear(f11[:, perm].reshape(B * J, -1), Wr, br)  # (B*J, C)
+        cadd = F.linear(f12, P["wc2"]).view(B, J, -1)
+        f13 = torch.empty((B, J, 2 * c_q), **f32)
+        for i in range(2):
+            p = q[("q2", i)]
+            ext.sa_mlp_max(idxs[i], *p["l2"], *p["l3"], a1f=aq[:, :, (2 + i) * c1q:(3 + i) * c1q], xyz=xyz2, cxyz=xyz1,
+                           wx=p["wx"], b1=p["b1"], cadd=cadd[:, :, i * c1q:(i + 1) * c1q], out=f13[:, :, i * c_q:(i + 1) * c_q])
+        Wr, br, perm = P["r2"]
+        f14 = F.linear(f13[:, perm].reshape(B * J, -1), Wr, br)
+
+        # ---- "TransT" with attn=False: only LayerNorms and FFNs are live -----------------------------------
+        x = self._ffn_block(net.transt.s11, f14)
+        x = self._ffn_block(net.transt.c11, x)
+        x = self._ffn_block(net.c3, x)
+        h = _lin_relu(x, net.final_mlp[0].weight.squeeze(-1), net.final_mlp[0].bias)
+        delta = F.linear(h, net.final_mlp[2].weight.squeeze(-1), net.final_mlp[2].bias).view(B, J, 3)
+        pred_hf = delta + xyz1  # (B,J,3) hand frame
+
+        ret = {"canon_pose": canon}
+        ret["pred_kp_handframe"] = pred_hf.transpose(1, 2)
+        ret["init_kp_handframe"] = xyz1.transpose(1, 2)
+        ret["points_handframe"] = xyz2.transpose(1, 2)
+        ret["pred_kp"] = torch.matmul(pred_hf, R.transpose(1, 2)).mul_(0.2).add_(tt)
+        if flag_dict.get("IKNet_flag", False):
+            d4, _ = ops.knn(4, ret["pred_kp"].contiguous(), pts.contiguous())
+            d4 = d4.mean(dim=-1)
+            d4[:, 0] -= 0.01
+            d4[:, 1] -= 0.01
+            ret["pred_kp_vis_mask"] = (d4 < 0.02).bool()
+        return ret

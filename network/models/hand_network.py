@@ -66,6 +66,8 @@ class HandTrackNet(nn.Module):
         C = cfg["network"]["backbone_out_dim"]
         assert C % 6 == 0
         self.elide_dead_attention = elide_dead_attention
+        self.use_fast_eval = True  # eval + fused backend + GPU -> models/fast_eval.py (set False to force this file's path)
+        self._fast = None
         self.bhand = PointNet2Msg_fast(cfg, C)
         self.r1 = rearrange_module(channel=C)
         self.r2 = rearrange_module(channel=C)
@@ -95,6 +97,13 @@ class HandTrackNet(nn.Module):
     def forward(self, input, flag_dict):
         """input: hand_points (B,N,3), jittered_hand_kp (B,21,3), palm template (gt_hand_pose.palm_template
         or pred_palm_template when tracking).  Returns the reference's ret_dict (pred_kp (B,21,3), ...)."""
+        if (self.use_fast_eval and pointnet_utils.fused_backend() is not None and not self.training
+                and not torch.is_grad_enabled() and self.elide_dead_attention and self.handframe == "kp"
+                and torch.device(self.device).type == "cuda"):
+            if self._fast is None:
+                from .fast_eval import FastEval
+                self._fast = FastEval(self)
+            return self._fast.forward(input, flag_dict)  # point-major inference path, same results
         dev = self.device
         if flag_dict["track_flag"]:
             palm_template = input["pred_palm_template"]

@@ -100,6 +100,66 @@ def test_fused_unsupported_shape_falls_back_to_operator_path():
     assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)  # same operator path; only the BN folding differs
 
 
+def test_new_extension_kernels_match_torch():
+    from hotrack_amd import ext
+    g = torch.Generator().manual_seed(3)
+    B, n, m, C = 3, 300, 77, 40
+    u, k = torch.rand(B, n, 3, generator=g).cuda(), torch.rand(B, m, 3, generator=g).cuda()
+    w, idx = ext.three_nn_weights(u, k)
+    from hotrack_amd import pointnet2_utils as ops
+    d, i2 = ops.three_nn(u, k)
+    assert torch.equal(idx, i2)
+    r = 1.0 / (d + 1e-8)
+    assert torch.allclose(w, r / r.sum(2, keepdim=True), atol=1e-6)
+    feats = torch.randn(B, m, C, generator=g).cuda()
+    wide = torch.zeros(B, n, C + 8).cuda()
+    ext.three_interpolate_pm(feats, idx, w, wide[:, :, 4:4 + C])
+    ref = ops.three_interpolate(feats.transpose(1, 2).contiguous(), idx, w).transpose(1, 2)
+    assert torch.allclose(wide[:, :, 4:4 + C], ref, atol=1e-6) and float(wide[:, :, :4].abs().max()) == 0.0
+    sel = torch.randint(0, m, (B, 19), generator=g, dtype=torch.int32).cuda()
+    assert torch.equal(ext.gather_rows(feats, sel), torch.gather(feats, 1, sel.long().unsqueeze(-1).expand(-1, -1, C)))
+    y = torch.randn(B, n, C, generator=g).cuda()
+    bias = torch.randn(B, C, generator=g).cuda()
+    exp = torch.relu(y + bias[:, None, :])
+    assert torch.allclose(ext.bias_act_pm_(y.clone(), bias, rows_per_bias=n), exp, atol=1e-6)
+
+
+@pytest.mark.parametrize("B", [1, 2, 5])
+def test_fast_point_major_forward_matches_module_path(B):
+    """models/fast_eval.py (point-major inference path) == HandTrackNet.forward's channel-major path."""
+    from hotrack_amd import fused, pointnet2_utils
+    from models import pointnet_utils
+    from models.hand_network import HandTrackNet
+    pointnet_utils.set_operator_backend(pointnet2_utils)
+    torch.manual_seed(0)
+    model = HandTrackNet(make_cfg("cuda"))
+    deterministic_init(model)
+    model = model.cuda().eval()
+    d = synthetic_frames(11 + B, B, 1024)
+    d = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in d.items()}
+    flags = {"track_flag": False, "test_flag": True, "save_flag": False, "IKNet_flag": True}
+    with torch.no_grad():
+        pointnet_utils.set_fused_backend(None)
+        ref = model(d, dict(flags))
+        try:
+            pointnet_utils.set_fused_backend(fused)
+            fast = model(d, dict(flags))
+            assert model._fast is not None
+            model.use_fast_eval = False
+            mid = model(d, dict(flags))  # fused kernels, channel-major module path
+        finally:
+            pointnet_utils.set_fused_backend(None)
+    for other in (fast, mid):
+        for k in ("pred_kp", "pred_kp_handframe", "init_kp_handframe", "points_handframe"):
+            assert other[k].shape == ref[k].shape
+            assert torch.allclose(other[k], ref[k], atol=2e-4), (k, float((other[k] - ref[k]).abs().max()))
+        assert torch.equal(other["pred_kp_vis_mask"], ref["pred_kp_vis_mask"])
+    loss_a, _ = model.compute_loss(dict(d, gt_hand_kp=d["gt_hand_kp"]), fast, dict(flags))
+    loss_b, _ = model.compute_loss(dict(d, gt_hand_kp=d["gt_hand_kp"]), ref, dict(flags))
+    for k in loss_b:
+        assert abs(float(loss_a[k]) - float(loss_b[k])) < 1e-3 * max(1.0, abs(float(loss_b[k]))), k
+
+
 def test_network_with_fused_backend_matches_reference_golden():
     from hotrack_amd import fused, pointnet2_utils
     from models import pointnet_utils

@@ -141,13 +141,25 @@ def test_train_step_matches_reference_gpu():
 
 @pytest.mark.gpu
 def test_gpu_forward_is_deterministic_and_batch_independent():
+    from hotrack_amd import fused
+    from models import pointnet_utils
     model = _build("cuda").eval()
     d = synthetic_frames(77, 8, 1024)
     d = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in d.items()}
-    with torch.no_grad():
-        a = model(d, dict(FLAGS))["pred_kp"]
-        b = model(d, dict(FLAGS))["pred_kp"]
-        one = {k: (v[:1] if torch.is_tensor(v) else {kk: vv[:1] for kk, vv in v.items()}) for k, v in d.items()}
-        c = model(one, dict(FLAGS))["pred_kp"]
-    assert torch.equal(a, b)
-    assert torch.allclose(a[:1], c, atol=2e-4), float((a[:1] - c).abs().max())  # library GEMMs pick batch-dependent kernels
+    one = {k: (v[:1] if torch.is_tensor(v) else {kk: vv[:1] for kk, vv in v.items()}) for k, v in d.items()}
+    try:
+        for backend, exact in ((fused, True), (None, False)):
+            pointnet_utils.set_fused_backend(backend)
+            with torch.no_grad():
+                model(d, dict(FLAGS))  # library warm-up (GEMM / conv solution selection happens on first use)
+                a = model(d, dict(FLAGS))["pred_kp"]
+                b = model(d, dict(FLAGS))["pred_kp"]
+                c = model(one, dict(FLAGS))["pred_kp"]
+            if exact:  # our kernels + library GEMMs: bit-reproducible run to run
+                assert torch.equal(a, b)
+            else:      # the unfused path goes through the convolution library, whose algorithm choice may vary
+                assert torch.allclose(a, b, atol=1e-5)
+            # per-cloud independence (library GEMMs pick batch-size dependent kernels -> rounding-level differences)
+            assert torch.allclose(a[:1], c, atol=2e-4), float((a[:1] - c).abs().max())
+    finally:
+        pointnet_utils.set_fused_backend(None)
