@@ -32,6 +32,7 @@ import torch.distributed as dist  # noqa: E402
 
 ALG_BYTES_PER_FRAME_1024 = 12_046_456  # SURVEY.md 8(d) / BASELINE.md: operator-API compulsory bytes per frame
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) peak
 FLAGS = {"track_flag": False, "test_flag": True, "save_flag": False, "IKNet_flag": False}
 
 
@@ -49,34 +50,48 @@ def build_model(dev, elide=True):
 
 
 class KernelTimer:
-    """HIP-event timing of one operator's launches on the stream they are enqueued on."""
+    """HIP-event timing of the hand-written kernels: hotrack_amd.pointnet2_hip.PROFILE makes the bindings
+    record two events immediately around each C-ABI enqueue, on the stream the kernel is launched on."""
 
-    def __init__(self, module, name):
-        self.module, self.name, self.orig = module, name, getattr(module, name)
-        self.events, self.meta, self.enabled = [], [], False
+    def __init__(self):
+        from hotrack_amd import pointnet2_hip
+        self.native = pointnet2_hip
+        self.records = []
 
-    def install(self):
-        def wrapped(*a, **k):
-            if not self.enabled:
-                return self.orig(*a, **k)
-            s = torch.cuda.Event(enable_timing=True)
-            e = torch.cuda.Event(enable_timing=True)
-            s.record()  # current stream == the stream pointnet2_hip passes to the C-ABI
-            out = self.orig(*a, **k)
-            e.record()
-            self.events.append((s, e))
-            self.meta.append(tuple(a[0].shape) + (int(a[1]),))
-            return out
-        setattr(self.module, self.name, wrapped)
+    def start(self):
+        self.native.PROFILE = self.records
 
-    def remove(self):
-        setattr(self.module, self.name, self.orig)
+    def stop(self):
+        self.native.PROFILE = None
 
-    def summary(self):
+    def summary(self, passes):
         by = {}
-        for (s, e), m in zip(self.events, self.meta):
-            by.setdefault(m, []).append(s.elapsed_time(e) * 1e-3)
-        return {m: (sum(v) / len(v), len(v)) for m, v in by.items()}
+        for name, a, s, e in self.records:
+            if name == "fps_kernel":
+                key = ("fps_kernel", a[0], a[1], a[2])  # (b, n, m)
+            else:
+                key = ("sa_mlp_max_kernel", a[0], a[2], a[3], a[4], a[5], a[6])  # (b, s, k, c1, c2, c3)
+            by.setdefault(key, []).append(s.elapsed_time(e) * 1e-3)
+        # key -> (mean seconds per launch, launches per step)
+        return {k: (sum(v) / len(v), len(v) / max(passes, 1)) for k, v in by.items()}
+
+
+def roofline_of(key, sec, per_step):
+    """Roofline entry of one kernel: algorithmic work per launch / measured launch duration."""
+    if key[0] == "sa_mlp_max_kernel":
+        _, B, S, K, C1, C2, C3 = key
+        flops = 2.0 * B * S * K * (C1 * C2 + C2 * C3)  # the two MFMA layers the kernel executes per (s,k) position
+        return {"bound": "mfma", "kernel": "sa_mlp_max_kernel<%d,%d,%d> (B=%d,S=%d,K=%d)" % (C1, C2, C3, B, S, K),
+                "achieved": round(flops / sec / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step}
+    _, B, N, M = key
+    kb = B * (12 * N + 4 * M)  # SURVEY.md 8(d): FPS bytes = B(12N + 4M)
+    return {"bound": "hbm", "kernel": "fps_kernel (B=%d,N=%d,M=%d)" % (B, N, M), "achieved": round(kb / sec / 1e9, 3),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb / sec / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+            "bytes_per_launch": kb, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step,
+            "us_per_fps_iteration": round(sec * 1e6 / max(M - 1, 1), 4),
+            "note": "bound by its M-step dependency chain, not by HBM (SURVEY.md section 7, hard part 2)"}
 
 
 def cpu_baseline(npoints, budget_s=20.0, max_frames=200):
@@ -165,8 +180,7 @@ def main():
     model = build_model(dev, elide=not args.no_elide)
     data = _to(synthetic_frames(1000 + rank, args.batch, args.npoints), dev)  # seeded per rank, resident in HBM
 
-    timer = KernelTimer(hip_ops, "furthest_point_sample")
-    timer.install()
+    timer = KernelTimer()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -227,12 +241,12 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         # separate short eager pass for the per-kernel HIP-event timing (events perturb the async pipeline)
-        timer.enabled = True
-        for _ in range(min(args.steps, 20)):
+        timed_passes = min(args.steps, 20)
+        timer.start()
+        for _ in range(timed_passes):
             model(data, dict(FLAGS))
         torch.cuda.synchronize()
-        timer.enabled = False
-    timer.remove()
+        timer.stop()
     assert all(torch.isfinite(o["pred_kp"]).all() for o in outs)
 
     if world > 1:
@@ -244,19 +258,22 @@ def main():
         frames = args.batch * world * args.steps
         fps = frames / dt
         alg_bytes = ALG_BYTES_PER_FRAME_1024 if args.npoints == 1024 else None
-        # dominant hand-written kernel today: FPS of sa1 (one workgroup per cloud, M-step dependency chain)
-        ks = timer.summary()
-        key = max(ks, key=lambda m: ks[m][0]) if ks else None
+        # dominant hand-written kernel = largest (mean launch time x launches per step) among the hooked kernels
+        ks = timer.summary(timed_passes)
+        per_kernel = sorted(({"key": k, "sec": v[0], "per_step": v[1]} for k, v in ks.items()),
+                            key=lambda r: -r["sec"] * r["per_step"])
+        # group launches of the same kernel instantiation (q1/q2 share the 128-128-192 instance at two K)
+        inst = {}
+        for r in per_kernel:
+            name = r["key"][0] + (str(r["key"][4:]) if r["key"][0] == "sa_mlp_max_kernel" else "")
+            inst.setdefault(name, []).append(r)
+        dom = max(inst.values(), key=lambda rs: sum(r["sec"] * r["per_step"] for r in rs)) if inst else []
         roof = None
-        if key is not None:
-            B, N, _, M = key
-            sec = ks[key][0]
-            kb = B * (12 * N + 4 * M)  # FPS bytes = B(12N + 4M)
-            roof = {"bound": "hbm", "kernel": f"fps_kernel (B={B},N={N},M={M})", "achieved": round(kb / sec / 1e9, 3),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb / sec / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                    "us_per_launch": round(sec * 1e6, 2), "us_per_fps_iteration": round(sec * 1e6 / max(M - 1, 1), 4),
-                    "launches_timed": ks[key][1],
-                    "note": "FPS is bound by its M-step dependency chain, not HBM (SURVEY.md 7 hard part 2)"}
+        if dom:
+            top = max(dom, key=lambda r: r["sec"] * r["per_step"])
+            roof = roofline_of(top["key"], top["sec"], top["per_step"])
+            roof["instance_us_per_step"] = round(sum(r["sec"] * r["per_step"] for r in dom) * 1e6, 1)
+        other = [roofline_of(r["key"], r["sec"], r["per_step"]) for r in per_kernel]
         res = {
             "metric": "HandTrackNet point-cloud frames/sec (N=%d)" % args.npoints, "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -271,6 +288,7 @@ def main():
             "frame_alg_bytes": alg_bytes,
             "frame_hbm_frac": None if alg_bytes is None else round(alg_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 6),
             "roofline": roof,
+            "kernels": other,
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.npoints)

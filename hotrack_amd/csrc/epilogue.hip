@@ -96,3 +96,35 @@ extern "C" int pn2x_gather_rows(int b, int n, int m, int c, const float *src, co
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, m, c, src, idx, out, total);
     return check_launch();
 }
+
+namespace pn2 {
+// out[b, ch] = max_r x[b, r, ch]   (x (b, r, c) point-major: lanes walk channels -> coalesced rows)
+__global__ void __launch_bounds__(256)
+max_rows_kernel(int r, int c, const float *__restrict__ x, float *__restrict__ out, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / c;
+        const int ch = (int)(e - b * c);
+        const float *p = x + (size_t)b * r * c + ch;
+        float m0 = p[0], m1 = m0, m2 = m0, m3 = m0;
+        int i = 0;
+        for (; i + 3 < r; i += 4) {
+            m0 = fmaxf(m0, p[(size_t)i * c]); m1 = fmaxf(m1, p[(size_t)(i + 1) * c]);
+            m2 = fmaxf(m2, p[(size_t)(i + 2) * c]); m3 = fmaxf(m3, p[(size_t)(i + 3) * c]);
+        }
+        for (; i < r; ++i) m0 = fmaxf(m0, p[(size_t)i * c]);
+        out[e] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    }
+}
+}  // namespace pn2
+
+extern "C" int pn2x_max_rows(int b, int r, int c, const float *x, float *out, void *stream) {
+    using namespace pn2;
+    if (b < 0 || r < 1 || c < 0) return PN2_EINVAL;
+    if (b == 0 || c == 0) return PN2_OK;
+    if (!x || !out) return PN2_ENULL;
+    const long total = (long)b * c;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(max_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, c, x, out, total);
+    return check_launch();
+}

@@ -223,7 +223,10 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
         hipLaunchKernelGGL(fps_large_kernel, dim3(b), dim3(1024), 0, st, n, m, xyz, temp, idx);
         return check_launch();
     }
-    int T = next_pow2(slots);
+    // One lane per point (T = slots) minimises VALU work per iteration, but the iteration is a latency
+    // chain (DPP reduce -> LDS exchange -> barrier), and 4 waves per SIMD serialise it: measured on MI355X
+    // (B=64): N=1024 T=1024 107 us, T=256 89 us; N=256 T=256 40 us, T=64 29 us.  So: 4 points per lane.
+    int T = next_pow2((slots + 3) / 4);
     if (T < 64) T = 64;
     if (T > 1024) T = 1024;
     if (force_threads == 64 || force_threads == 256 || force_threads == 1024) {
@@ -232,10 +235,9 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
     const int P = next_pow2((slots + T - 1) / T);
 #define PN2_FPS_CASE(TT, PP) \
     if (T == TT && P == PP) return launch_fps<TT, PP>(b, n, m, bs, lg, Q, xyz, idx, st);
-    PN2_FPS_CASE(64, 1) PN2_FPS_CASE(64, 2) PN2_FPS_CASE(64, 4) PN2_FPS_CASE(64, 8) PN2_FPS_CASE(64, 16)
-    PN2_FPS_CASE(128, 1) PN2_FPS_CASE(512, 1)
-    PN2_FPS_CASE(256, 1) PN2_FPS_CASE(256, 2) PN2_FPS_CASE(256, 4) PN2_FPS_CASE(256, 8) PN2_FPS_CASE(256, 16)
-    PN2_FPS_CASE(1024, 1) PN2_FPS_CASE(1024, 2) PN2_FPS_CASE(1024, 4) PN2_FPS_CASE(1024, 8) PN2_FPS_CASE(1024, 16)
+#define PN2_FPS_ROW(TT) PN2_FPS_CASE(TT, 1) PN2_FPS_CASE(TT, 2) PN2_FPS_CASE(TT, 4) PN2_FPS_CASE(TT, 8) PN2_FPS_CASE(TT, 16)
+    PN2_FPS_ROW(64) PN2_FPS_ROW(128) PN2_FPS_ROW(256) PN2_FPS_ROW(512) PN2_FPS_ROW(1024)
+#undef PN2_FPS_ROW
 #undef PN2_FPS_CASE
     return PN2_ERANGE;
 }

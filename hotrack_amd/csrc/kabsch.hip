@@ -36,11 +36,15 @@ kabsch_kernel(int b, int xb, int num, const float *__restrict__ x_all, const flo
     for (int r = 1; r < 4; ++r)
         for (int c = 0; c < r; ++c) A[r][c] = A[c][r];
     double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    double diag2 = 0;
+    for (int p = 0; p < 4; ++p)
+        for (int q = 0; q < 4; ++q) diag2 += A[p][q] * A[p][q];
     for (int sweep = 0; sweep < 12; ++sweep) {
         double off = 0;
         for (int p = 0; p < 3; ++p)
             for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
-        if (off < 1e-300) break;
+        // converged to fp64 round-off relative to the matrix norm (quadratic convergence: ~4-5 sweeps)
+        if (off <= 1e-30 * diag2) break;
         for (int p = 0; p < 3; ++p)
             for (int q = p + 1; q < 4; ++q) {
                 if (fabs(A[p][q]) < 1e-300) continue;

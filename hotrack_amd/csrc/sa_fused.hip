@@ -41,8 +41,11 @@ struct SaArgs {
     int num_tiles, tiles_per_cloud;
 };
 
-template <int C1, int C2, int C3, int WC>
-__global__ void __launch_bounds__(256)
+// RTC = row tiles (of 16 positions) whose accumulators are live at once: 4 -> fewest passes over the
+// register-resident weights; 2 halves the accumulator / A-fragment registers so that two workgroups fit
+// on a CU (one gathers while the other feeds the matrix cores).
+template <int C1, int C2, int C3, int WC, int RTC, int MINW>
+__global__ void __launch_bounds__(256, MINW)
 sa_mlp_max_kernel(const SaArgs A) {
     const int N = A.N, S = A.S, K = A.K, lgK = A.lgK;
     const float *__restrict__ W2 = A.w2, *__restrict__ b2 = A.b2, *__restrict__ W3 = A.w3, *__restrict__ b3 = A.b3;
@@ -140,22 +143,23 @@ sa_mlp_max_kernel(const SaArgs A) {
         __syncthreads();
 
         // ---- phase 2: layer 2 on the matrix cores ----------------------------------------------------
-        {
-            f32x4 acc[4][NT2];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+        for (int r0 = 0; r0 < 4; r0 += RTC) {
+            f32x4 acc[RTC][NT2];
+#pragma unroll
+            for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < NT2; ++ct) acc[rt][ct] = (f32x4){bias2[ct], bias2[ct], bias2[ct], bias2[ct]};
-            const float *arow = H1 + (wp * 64 + li) * LD1 + 4 * g;
+            const float *arow = H1 + (wp * 64 + r0 * 16 + li) * LD1 + 4 * g;
 #pragma unroll
             for (int tq = 0; tq < C1 / 16; ++tq) {
-                float4 a[4];
+                float4 a[RTC];
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1 + 16 * tq);
+                for (int rt = 0; rt < RTC; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1 + 16 * tq);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
+                    for (int rt = 0; rt < RTC; ++rt) {
                         const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
 #pragma unroll
                         for (int ct = 0; ct < NT2; ++ct)
@@ -164,10 +168,10 @@ sa_mlp_max_kernel(const SaArgs A) {
             }
             // relu -> H2 (D tile: row = g*4 + r, col = li)
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < NT2; ++ct) {
-                    float *dst = H2 + (wp * 64 + rt * 16 + g * 4) * LD2 + (wc * NT2 + ct) * 16 + li;
+                    float *dst = H2 + (wp * 64 + (r0 + rt) * 16 + g * 4) * LD2 + (wc * NT2 + ct) * 16 + li;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dst[r * LD2] = fmaxf(acc[rt][ct][r], 0.f);
                 }
@@ -176,34 +180,36 @@ sa_mlp_max_kernel(const SaArgs A) {
 
         // ---- phase 3: layer 3 + max over the K neighbours ---------------------------------------------
         {
-            f32x4 acc[4][NT3];
+            float m[4][NT3];  // per row tile: max over its 16 positions (still spread over the 4 lane groups)
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+            for (int r0 = 0; r0 < 4; r0 += RTC) {
+                f32x4 acc[RTC][NT3];
 #pragma unroll
-                for (int ct = 0; ct < NT3; ++ct) acc[rt][ct] = (f32x4){bias3[ct], bias3[ct], bias3[ct], bias3[ct]};
-            const float *arow = H2 + (wp * 64 + li) * LD2 + 4 * g;
+                for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
-            for (int tq = 0; tq < C2 / 16; ++tq) {
-                float4 a[4];
+                    for (int ct = 0; ct < NT3; ++ct) acc[rt][ct] = (f32x4){bias3[ct], bias3[ct], bias3[ct], bias3[ct]};
+                const float *arow = H2 + (wp * 64 + r0 * 16 + li) * LD2 + 4 * g;
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD2 + 16 * tq);
+                for (int tq = 0; tq < C2 / 16; ++tq) {
+                    float4 a[RTC];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int rt = 0; rt < RTC; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD2 + 16 * tq);
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
-                        const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int ct = 0; ct < NT3; ++ct)
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w3r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
-                    }
+                        for (int rt = 0; rt < RTC; ++rt) {
+                            const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
+#pragma unroll
+                            for (int ct = 0; ct < NT3; ++ct)
+                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w3r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
+                        }
+                }
+#pragma unroll
+                for (int rt = 0; rt < RTC; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < NT3; ++ct)
+                        m[r0 + rt][ct] = fmaxf(fmaxf(acc[rt][ct][0], acc[rt][ct][1]), fmaxf(acc[rt][ct][2], acc[rt][ct][3]));
             }
-            // per row-tile max over its 16 positions: 4 registers in-lane, then the 4 lane groups
-            float m[4][NT3];
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < NT3; ++ct)
-                    m[rt][ct] = fmaxf(fmaxf(acc[rt][ct][0], acc[rt][ct][1]), fmaxf(acc[rt][ct][2], acc[rt][ct][3]));
             // combine row tiles that belong to the same centroid (K = 16 -> 1, 32 -> 2, 64 -> 4 tiles)
             if (K >= 32) {
 #pragma unroll
@@ -237,7 +243,7 @@ sa_mlp_max_kernel(const SaArgs A) {
     }
 }
 
-template <int C1, int C2, int C3, int WC>
+template <int C1, int C2, int C3, int WC, int RTC, int MINW>
 static int launch_sa(int b, SaArgs a, hipStream_t st) {
     constexpr int WP = 4 / WC, TM = WP * 64;
     const int sk = a.S * a.K;
@@ -248,14 +254,14 @@ static int launch_sa(int b, SaArgs a, hipStream_t st) {
     a.lgK = 0;
     while ((1 << a.lgK) < a.K) ++a.lgK;
     const size_t lds = (size_t)TM * (C1 + 4 + C2 + 4) * sizeof(float);
-    auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC>;
+    auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW>;
     static bool attr_set = false;  // once per instantiation; never during a later stream capture
     if (lds > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     // persistent workgroups: weights are loaded into registers once per workgroup
-    const int max_wg = 256 * (lds > 80 * 1024 ? 1 : 2);
+    const int max_wg = 256 * (lds > 80 * 1024 ? 1 : MINW);
     const int grid = a.num_tiles < max_wg ? a.num_tiles : max_wg;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
     return check_launch();
@@ -283,9 +289,9 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
     a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out; a.out_b = out_b; a.out_s = out_s; a.out_c = out_c;
     a.num_tiles = 0; a.tiles_per_cloud = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2>(b, a, st);
-    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4>(b, a, st);
-    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4>(b, a, st);
+    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2, 4, 2>(b, a, st);
+    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4, 4, 2>(b, a, st);
+    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4, 2, 2>(b, a, st);
     return PN2_ERANGE;
 }
 

@@ -88,8 +88,9 @@ def sa_mlp_max(idx: torch.Tensor, w2, b2, w3, b3, *, a1f=None, xyz=None, cxyz=No
         po, ld = _rows(out, "out", C3)
         ob, os_, oc = out.stride(0), ld, 1
     with torch.cuda.device(idx.device):
-        _native._check(_lib.pn2x_sa_mlp_max(B, N, S, K, C1, C2, C3, pa, lda, px, pcx, pwx, pb1, pc, ldc, pi, pw2, pb2, pw3,
-                                            pb3, po, ob, os_, oc, _native._stream(idx)), "sa_mlp_max")
+        _native._check(_native._call(_lib.pn2x_sa_mlp_max, "sa_mlp_max_kernel", None, B, N, S, K, C1, C2, C3, pa, lda, px, pcx,
+                                     pwx, pb1, pc, ldc, pi, pw2, pb2, pw3, pb3, po, ob, os_, oc, _native._stream(idx)),
+                       "sa_mlp_max")
     return out
 
 
@@ -154,3 +155,17 @@ def bias_act_(y: torch.Tensor, bias: torch.Tensor, relu: bool = True) -> torch.T
     with torch.cuda.device(y.device):
         _native._check(_lib.pn2x_bias_act(B, C, N, py, pb, 1 if relu else 0, _native._stream(y)), "bias_act")
     return y
+
+
+_lib.pn2x_max_rows.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp]
+_lib.pn2x_max_rows.restype = _ci
+
+
+def max_rows(x: torch.Tensor) -> torch.Tensor:
+    """x (B,R,C) contiguous -> (B,C) max over the R rows."""
+    B, R, C = x.shape
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _native._check(_lib.pn2x_max_rows(B, R, C, _native._ptr(x, "x", torch.float32, B * R * C), out.data_ptr(),
+                                          _native._stream(x)), "max_rows")
+    return out

@@ -59,6 +59,24 @@ ABI_VERSION = _lib.pn2_abi_version()
 KNN_MAX_K = 200  # interpolate_gpu.cu:30-31
 
 
+# Optional profiling hook (bench.py): when set to a list, every C-ABI call appends
+# (name, start_event, end_event) with the two HIP events recorded IMMEDIATELY around the enqueue on the
+# launching stream, so the bracket holds the kernel and ~nothing else.
+PROFILE = None
+
+
+def _call(fn, name, stream_handle, *args):
+    if PROFILE is None:
+        return fn(*args)
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn(*args)
+    e.record()
+    PROFILE.append((name, args, s, e))
+    return rc
+
+
 class Pn2Error(RuntimeError):
     """A C-ABI call returned a negative PN2_E* code."""
 
@@ -97,7 +115,7 @@ def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     o = _ptr(idx, "idx", _i32, b * m)
     t = None if temp is None else _ptr(temp, "temp", _f32, b * n)
     with torch.cuda.device(points.device):
-        _check(_lib.pn2_furthest_point_sampling(b, n, m, p, t, o, _stream(points)), "furthest_point_sampling")
+        _check(_call(_lib.pn2_furthest_point_sampling, "fps_kernel", None, b, n, m, p, t, o, _stream(points)), "furthest_point_sampling")
     return 1
 
 

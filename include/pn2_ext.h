@@ -93,6 +93,12 @@ int pn2x_gather_rows(int b, int n, int m, int c, const float *src, const int *id
  */
 int pn2x_bias_act_pm(long rows, int c, float *y, int ldy, const float *bias, long rows_per_bias, int relu, void *stream);
 
+/*
+ * out[b, ch] = max over the r rows of point-major x (b, r, c): the max over N of the reference's group-all
+ * set-abstraction layer (pointnet_utils.py:508, torch.max over the point axis).
+ */
+int pn2x_max_rows(int b, int r, int c, const float *x, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,7 +151,7 @@ class FastEval:
         x = torch.cat([l2_xyz, l2_feat], dim=2).view(B * S2, -1)
         for W, b in P["sa3"]:
             x = _lin_relu(x, W, b)
-        l3 = x.view(B, S2, -1).max(dim=1)[0]  # (B,512)
+        l3 = ext.max_rows(x.view(B, S2, -1))  # (B,512)
 
         # ---- fp3: S == 1 -> the global feature is broadcast; first layer split so it is applied once per cloud
         p = P["fp3"]
@@ -186,10 +186,10 @@ class FastEval:
         # ---- q1 / q2: kNN (16 / 64) neighbourhoods of the 21 keypoints ------------------------------------
         aq = F.linear(src2, P["wq"]).view(B, N, -1)  # (B,N,4*128): per-point layer-1 halves of q1s0,q1s1,q2s0,q2s1
         q = P["q"]
-        idxs = []
-        for i in range(2):
-            _, gi = ops.knn(q[("q1", i)]["K"], xyz1, xyz2)
-            idxs.append(gi)
+        # kNN lists are sorted by (distance, index): the K=16 list is the prefix of the K=64 list -> one search
+        Ks = [q[("q1", i)]["K"] for i in range(2)]
+        _, gi = ops.knn(max(Ks), xyz1, xyz2)
+        idxs = [gi if K == max(Ks) else gi[:, :, :K].contiguous() for K in Ks]
         c_q = q[("q1", 0)]["l3"][0].shape[0]
         c1q = q[("q1", 0)]["l2"][0].shape[1]
         f11 = torch.empty((B, J, 2 * c_q), **f32)
