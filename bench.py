@@ -274,6 +274,18 @@ def main():
             roof = roofline_of(top["key"], top["sec"], top["per_step"])
             roof["instance_us_per_step"] = round(sum(r["sec"] * r["per_step"] for r in dom) * 1e6, 1)
         other = [roofline_of(r["key"], r["sec"], r["per_step"]) for r in per_kernel]
+        # HBM traffic per launch cannot be sampled from inside the process: it comes from the committed
+        # rocprofv3 PMC passes of this same command (scripts/pmc_summary.py -> profiles/r01_pmc_traffic.json)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if roof is not None and roof["bound"] == "mfma":
+                tag = "sa_mlp_max_kernel<%d, %d, %d" % top["key"][4:7]
+                cands = [e for e in pmc["kernels"] if tag in e["kernel"]]
+                if cands:  # the K=64 launch is the larger-grid one of the instance
+                    roof["traffic"] = max(cands, key=lambda e: e["grid_threads"])["hbm_bytes"]
+                    roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, reads x2 per MI355X_MICROARCH.md)"
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "HandTrackNet point-cloud frames/sec (N=%d)" % args.npoints, "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
