@@ -23,6 +23,14 @@
 namespace pn2 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+// 12-byte xyz record read as ONE global_load_dwordx3 (dword alignment is enough): next to a running MFMA
+// stream every vector-memory instruction costs the issuing wave ~100-185 cycles, so the LOAD role counts them.
+__device__ __forceinline__ f32x3 load_xyz(const float *p) {
+    f32x3 v;
+    __builtin_memcpy(&v, p, 12);
+    return v;
+}
 
 struct SaArgs {
     int N, S, K, lgK;
@@ -39,13 +47,18 @@ struct SaArgs {
     long out_b;
     int out_s, out_c;
     int num_tiles, tiles_per_cloud;
+    long long *trace;   // debug: per-phase s_memtime stamps of workgroup 0 (nullptr = off)
 };
 
-// RTC = row tiles (of 16 positions) whose accumulators are live at once: 4 -> fewest passes over the
-// register-resident weights; 2 halves the accumulator / A-fragment registers so that two workgroups fit
-// on a CU (one gathers while the other feeds the matrix cores).
+// Workgroup = 8 waves with fixed roles (wave specialisation):
+//   waves 0-3  COMPUTE: layers 2 and 3 on the matrix cores, weights register-resident, max over K, store;
+//   waves 4-7  LOAD:    gather + layer-1 epilogue of the NEXT tile into the other half of a double-buffered
+//                       LDS tile, so the matrix cores never wait for the row gather.
+// Two s_barriers per tile keep the roles in step (H1[next] complete / H2 reusable).
+// RTC = row tiles (of 16 positions) whose accumulators are live at once (4 = fewest passes over the weight
+// registers, 2 = half the accumulator / A-fragment registers).  MINW = waves per SIMD for __launch_bounds__.
 template <int C1, int C2, int C3, int WC, int RTC, int MINW>
-__global__ void __launch_bounds__(256, MINW)
+__global__ void __launch_bounds__(512, MINW)
 sa_mlp_max_kernel(const SaArgs A) {
     const int N = A.N, S = A.S, K = A.K, lgK = A.lgK;
     const float *__restrict__ W2 = A.w2, *__restrict__ b2 = A.b2, *__restrict__ W3 = A.w3, *__restrict__ b3 = A.b3;
@@ -57,129 +70,200 @@ sa_mlp_max_kernel(const SaArgs A) {
     constexpr int NT2 = C2 / (16 * WC), NT3 = C3 / (16 * WC);
     static_assert(C2 % (16 * WC) == 0 && C3 % (16 * WC) == 0 && C1 % 16 == 0, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *H1 = smem;
-    float *H2 = smem + TM * LD1;
+    float *H1a = smem;
+    float *H1b = smem + TM * LD1;
+    float *H2 = smem + 2 * TM * LD1;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
-    const int wc = w % WC, wp = w / WC;
+    const bool compute = w < 4;  // wave-uniform role
+    const int wc = (w & 3) % WC, wp = (w & 3) / WC;
     const int li = lane & 15, g = lane >> 4;
+    const int SK = S * K;
 
-    // ---- weights -> registers (B operand: lane holds W[out = tile*16 + li][in = 16*tq + 4*g + j]) -------
-    float w2r[NT2][C1 / 4], w3r[NT3][C2 / 4];
-    float bias2[NT2], bias3[NT3];
-#pragma unroll
-    for (int ct = 0; ct < NT2; ++ct) {
-        const int oc = (wc * NT2 + ct) * 16 + li;
-        bias2[ct] = b2[oc];
-#pragma unroll
-        for (int tq = 0; tq < C1 / 16; ++tq) {
-            const float4 v = *reinterpret_cast<const float4 *>(W2 + (size_t)oc * C1 + 16 * tq + 4 * g);
-            w2r[ct][4 * tq + 0] = v.x; w2r[ct][4 * tq + 1] = v.y; w2r[ct][4 * tq + 2] = v.z; w2r[ct][4 * tq + 3] = v.w;
-        }
-    }
-#pragma unroll
-    for (int ct = 0; ct < NT3; ++ct) {
-        const int oc = (wc * NT3 + ct) * 16 + li;
-        bias3[ct] = b3[oc];
-#pragma unroll
-        for (int tq = 0; tq < C2 / 16; ++tq) {
-            const float4 v = *reinterpret_cast<const float4 *>(W3 + (size_t)oc * C2 + 16 * tq + 4 * g);
-            w3r[ct][4 * tq + 0] = v.x; w3r[ct][4 * tq + 1] = v.y; w3r[ct][4 * tq + 2] = v.z; w3r[ct][4 * tq + 3] = v.w;
-        }
-    }
-
-    // phase-1 role of this thread: 4 consecutive layer-1 channels (fixed), rows tid/Q1 + i*(256/Q1)
+    // ---- LOAD role: 4 consecutive layer-1 channels per thread (fixed), rows lt/Q1 + i*(256/Q1) ----------
     constexpr int Q1 = C1 / 4;
-    static_assert(256 % Q1 == 0, "a thread keeps its channel quad across phase-1 iterations");
-    const int c4 = tid % Q1;
+    static_assert(256 % Q1 == 0, "a loader thread keeps its channel quad across rows");
+    const int lt = tid & 255;
+    const int c4 = lt % Q1;
+    // layer-1 constants of this loader thread's channel quad (registers; the LOAD role's loop is separate from
+    // the COMPUTE role's, so they do not compete with the resident weights)
     float wxr[4][3] = {{0.f}};
     float4 b1r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (A.xyz) {
+    if (!compute) {
+        if (A.xyz) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) wxr[i][d] = A.wx[(4 * c4 + i) * 3 + d];
-    }
-    if (A.b1) b1r = *reinterpret_cast<const float4 *>(A.b1 + 4 * c4);
-
-    const int SK = S * K;
-    for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_cloud;
-        const int pos0 = (tile - b * tiles_per_cloud) * TM;
-        const int *__restrict__ idxb = A.idx + (size_t)b * SK;
-
-        // ---- phase 1: h1 = relu(a1f[idx] + Wx (p_idx - c_s) + b1 + cadd_s) -> LDS (row = position) ---------
-#pragma unroll 4
-        for (int row = tid / Q1; row < TM; row += 256 / Q1) {
-            const int p = pos0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < SK) {
-                const int j = idxb[p];
-                const int s = p >> lgK;
-                v = b1r;
-                if (A.a1f) {
-                    const float4 a = *reinterpret_cast<const float4 *>(A.a1f + ((size_t)b * N + j) * A.a1f_ld + 4 * c4);
-                    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-                }
-                if (A.xyz) {
-                    const float *pj = A.xyz + ((size_t)b * N + j) * 3;
-                    const float *cs = A.cxyz + ((size_t)b * S + s) * 3;
-                    const float dx = pj[0] - cs[0], dy = pj[1] - cs[1], dz = pj[2] - cs[2];
-                    v.x += wxr[0][0] * dx + wxr[0][1] * dy + wxr[0][2] * dz;
-                    v.y += wxr[1][0] * dx + wxr[1][1] * dy + wxr[1][2] * dz;
-                    v.z += wxr[2][0] * dx + wxr[2][1] * dy + wxr[2][2] * dz;
-                    v.w += wxr[3][0] * dx + wxr[3][1] * dy + wxr[3][2] * dz;
-                }
-                if (A.cadd) {
-                    const float4 c = *reinterpret_cast<const float4 *>(A.cadd + ((size_t)b * S + s) * A.cadd_ld + 4 * c4);
-                    v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
-                }
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            *reinterpret_cast<float4 *>(H1 + row * LD1 + 4 * c4) = v;
+                for (int k = 0; k < 3; ++k) wxr[i][k] = A.wx[(4 * c4 + i) * 3 + k];
         }
-        __syncthreads();
+        if (A.b1) b1r = *reinterpret_cast<const float4 *>(A.b1 + 4 * c4);
+    }
 
-        // ---- phase 2: layer 2 on the matrix cores ----------------------------------------------------
+    // h1 = relu(a1f[idx] + Wx (p_idx - c_s) + b1 + cadd_s) for HALF h (rows h*TM/2 ...) of `tile` -> LDS.
+    // All of a thread's loads are issued back-to-back, group by group (indices, then every row's gathers),
+    // with clamped (always valid) addresses and no per-row branches: a row costs one memory round trip for
+    // its index + one for its data instead of a serial chain per row (measured: 20k -> ~3k cycles per half).
+    constexpr int RPT = (TM / 2) / (256 / Q1);  // rows per loader thread per half tile
+    static_assert((TM / 2) % (256 / Q1) == 0, "half tile rows split evenly over the loader threads");
+    auto gather = [&](int tile, float *__restrict__ H1, int h) {
+        const int b = tile / tiles_per_cloud;
+        const int pos0 = (tile - b * tiles_per_cloud) * TM + h * (TM / 2);
+        const int *__restrict__ idxb = A.idx + (size_t)b * SK;
+        const int row0 = lt / Q1;
+        int jj[RPT], ss[RPT];
 #pragma unroll
-        for (int r0 = 0; r0 < 4; r0 += RTC) {
-            f32x4 acc[RTC][NT2];
+        for (int r = 0; r < RPT; ++r) {
+            int p = pos0 + row0 + r * (256 / Q1);
+            p = p < SK ? p : SK - 1;  // rows past the end belong to no centroid: computed, never stored
+            jj[r] = idxb[p];
+            ss[r] = p >> lgK;
+        }
+        // every load of the half tile is in flight before the first use: ONE further round trip after the indices
+        float4 a[RPT], c[RPT];
+        f32x3 pj[RPT], cs[RPT];
+        if (A.a1f) {
 #pragma unroll
-            for (int rt = 0; rt < RTC; ++rt)
+            for (int r = 0; r < RPT; ++r)
+                a[r] = *reinterpret_cast<const float4 *>(A.a1f + ((size_t)b * N + jj[r]) * A.a1f_ld + 4 * c4);
+        }
+        if (A.cadd) {
 #pragma unroll
-                for (int ct = 0; ct < NT2; ++ct) acc[rt][ct] = (f32x4){bias2[ct], bias2[ct], bias2[ct], bias2[ct]};
-            const float *arow = H1 + (wp * 64 + r0 * 16 + li) * LD1 + 4 * g;
+            for (int r = 0; r < RPT; ++r)
+                c[r] = *reinterpret_cast<const float4 *>(A.cadd + ((size_t)b * S + ss[r]) * A.cadd_ld + 4 * c4);
+        }
+        if (A.xyz) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                pj[r] = load_xyz(A.xyz + ((size_t)b * N + jj[r]) * 3);
+                cs[r] = load_xyz(A.cxyz + ((size_t)b * S + ss[r]) * 3);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            float4 v = b1r;
+            if (A.a1f) { v.x += a[r].x; v.y += a[r].y; v.z += a[r].z; v.w += a[r].w; }
+            if (A.cadd) { v.x += c[r].x; v.y += c[r].y; v.z += c[r].z; v.w += c[r].w; }
+            if (A.xyz) {
+                const float dx = pj[r].x - cs[r].x, dy = pj[r].y - cs[r].y, dz = pj[r].z - cs[r].z;
+                v.x += wxr[0][0] * dx + wxr[0][1] * dy + wxr[0][2] * dz;
+                v.y += wxr[1][0] * dx + wxr[1][1] * dy + wxr[1][2] * dz;
+                v.z += wxr[2][0] * dx + wxr[2][1] * dy + wxr[2][2] * dz;
+                v.w += wxr[3][0] * dx + wxr[3][1] * dy + wxr[3][2] * dz;
+            }
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r * (256 / Q1)) * LD1 + 4 * c4) = v;
+        }
+    };
+
+    // ---- COMPUTE role: weights -> registers (B operand: lane holds W[out = tile*16 + li][in = 16*tq + 4*g + j])
+    float w2r[NT2][C1 / 4], w3r[NT3][C2 / 4];
+    float bias2[NT2], bias3[NT3];
+    if (compute) {
+#pragma unroll
+        for (int ct = 0; ct < NT2; ++ct) {
+            const int oc = (wc * NT2 + ct) * 16 + li;
+            bias2[ct] = b2[oc];
 #pragma unroll
             for (int tq = 0; tq < C1 / 16; ++tq) {
-                float4 a[RTC];
+                const float4 v = *reinterpret_cast<const float4 *>(W2 + (size_t)oc * C1 + 16 * tq + 4 * g);
+                w2r[ct][4 * tq + 0] = v.x; w2r[ct][4 * tq + 1] = v.y; w2r[ct][4 * tq + 2] = v.z; w2r[ct][4 * tq + 3] = v.w;
+            }
+        }
 #pragma unroll
-                for (int rt = 0; rt < RTC; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1 + 16 * tq);
+        for (int ct = 0; ct < NT3; ++ct) {
+            const int oc = (wc * NT3 + ct) * 16 + li;
+            bias3[ct] = b3[oc];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int tq = 0; tq < C2 / 16; ++tq) {
+                const float4 v = *reinterpret_cast<const float4 *>(W3 + (size_t)oc * C2 + 16 * tq + 4 * g);
+                w3r[ct][4 * tq + 0] = v.x; w3r[ct][4 * tq + 1] = v.y; w3r[ct][4 * tq + 2] = v.z; w3r[ct][4 * tq + 3] = v.w;
+            }
+        }
+    } else {
+        if ((int)blockIdx.x < num_tiles) {  // prologue: first tile
+            gather(blockIdx.x, H1a, 0);
+            gather(blockIdx.x, H1a, 1);
+        }
+    }
+    __syncthreads();
+
+    // debug trace: stamp(slot) records the shader clock for (workgroup 0, lane 0 of waves 0 and 4)
+    auto stamp = [&](int it, int slot) {
+        if (A.trace && blockIdx.x == 0 && lane == 0 && (w == 0 || w == 4) && it < 8)
+            A.trace[((w >> 2) * 8 + it) * 8 + slot] = (long long)__builtin_readcyclecounter();
+    };
+    // The two roles run SEPARATE loops (same trip count, two s_barriers per tile each), so the register
+    // allocator does not have to keep the COMPUTE role's resident weights alive through the LOAD role's code.
+    if (!compute) {
+        // the LOAD waves issue few instructions but each is latency-critical: let them win issue arbitration
+        // against the co-resident MFMA stream (measured: gather 12k -> ~5k cycles per half tile)
+        __builtin_amdgcn_s_setprio(3);
+        int it = 0;
+        for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, ++it) {
+            stamp(it, 0);
+            float *H1n = (it & 1) ? H1a : H1b;
+            const int next = tile + gridDim.x;
+            if (next < num_tiles) gather(next, H1n, 0);
+            stamp(it, 2);
+            __syncthreads();  // B1
+            stamp(it, 3);
+            if (next < num_tiles) gather(next, H1n, 1);
+            stamp(it, 5);
+            __syncthreads();  // B2
+            stamp(it, 6);
+        }
+        return;
+    }
+    int it = 0;
+    for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, ++it) {
+        stamp(it, 0);
+        float *H1 = (it & 1) ? H1b : H1a;
+        const int b = tile / tiles_per_cloud;
+        const int pos0 = (tile - b * tiles_per_cloud) * TM;
+        {
+            // ---- layer 2 on the matrix cores ------------------------------------------------------------
 #pragma unroll
-                    for (int rt = 0; rt < RTC; ++rt) {
-                        const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
+            for (int r0 = 0; r0 < 4; r0 += RTC) {
+                f32x4 acc[RTC][NT2];
 #pragma unroll
-                        for (int ct = 0; ct < NT2; ++ct)
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
+                for (int rt = 0; rt < RTC; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < NT2; ++ct) acc[rt][ct] = (f32x4){bias2[ct], bias2[ct], bias2[ct], bias2[ct]};
+                const float *arow = H1 + (wp * 64 + r0 * 16 + li) * LD1 + 4 * g;
+#pragma unroll
+                for (int tq = 0; tq < C1 / 16; ++tq) {
+                    float4 a[RTC];
+#pragma unroll
+                    for (int rt = 0; rt < RTC; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1 + 16 * tq);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int rt = 0; rt < RTC; ++rt) {
+                            const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
+#pragma unroll
+                            for (int ct = 0; ct < NT2; ++ct)
+                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
+                        }
+                }
+                if (r0 + RTC >= 4) stamp(it, 1);
+                // relu -> H2 (D tile: row = g*4 + r, col = li)
+#pragma unroll
+                for (int rt = 0; rt < RTC; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < NT2; ++ct) {
+                        float *dst = H2 + (wp * 64 + (r0 + rt) * 16 + g * 4) * LD2 + (wc * NT2 + ct) * 16 + li;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[r * LD2] = fmaxf(acc[rt][ct][r], 0.f);
                     }
             }
-            // relu -> H2 (D tile: row = g*4 + r, col = li)
-#pragma unroll
-            for (int rt = 0; rt < RTC; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < NT2; ++ct) {
-                    float *dst = H2 + (wp * 64 + (r0 + rt) * 16 + g * 4) * LD2 + (wc * NT2 + ct) * 16 + li;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[r * LD2] = fmaxf(acc[rt][ct][r], 0.f);
-                }
         }
-        __syncthreads();
-
-        // ---- phase 3: layer 3 + max over the K neighbours ---------------------------------------------
+        stamp(it, 2);
+        __syncthreads();  // B1: H2 complete
+        stamp(it, 3);
         {
+            // ---- layer 3 + max over the K neighbours ----------------------------------------------------
             float m[4][NT3];  // per row tile: max over its 16 positions (still spread over the 4 lane groups)
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0 += RTC) {
@@ -210,6 +294,7 @@ sa_mlp_max_kernel(const SaArgs A) {
                     for (int ct = 0; ct < NT3; ++ct)
                         m[r0 + rt][ct] = fmaxf(fmaxf(acc[rt][ct][0], acc[rt][ct][1]), fmaxf(acc[rt][ct][2], acc[rt][ct][3]));
             }
+            stamp(it, 4);
             // combine row tiles that belong to the same centroid (K = 16 -> 1, 32 -> 2, 64 -> 4 tiles)
             if (K >= 32) {
 #pragma unroll
@@ -239,7 +324,9 @@ sa_mlp_max_kernel(const SaArgs A) {
                 }
             }
         }
-        // no third barrier: H1 is next written after this tile's 2nd barrier, H2 after the next tile's 1st
+        stamp(it, 5);
+        __syncthreads();  // B2: H1[next] complete, H2 reusable
+        stamp(it, 6);
     }
 }
 
@@ -253,7 +340,7 @@ static int launch_sa(int b, SaArgs a, hipStream_t st) {
     a.num_tiles = (int)num_tiles_l;
     a.lgK = 0;
     while ((1 << a.lgK) < a.K) ++a.lgK;
-    const size_t lds = (size_t)TM * (C1 + 4 + C2 + 4) * sizeof(float);
+    const size_t lds = (size_t)TM * (2 * (C1 + 4) + C2 + 4) * sizeof(float);
     auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW>;
     static bool attr_set = false;  // once per instantiation; never during a later stream capture
     if (lds > 64 * 1024 && !attr_set) {
@@ -261,13 +348,17 @@ static int launch_sa(int b, SaArgs a, hipStream_t st) {
         attr_set = true;
     }
     // persistent workgroups: weights are loaded into registers once per workgroup
-    const int max_wg = 256 * (lds > 80 * 1024 ? 1 : MINW);
+    const int wg_per_cu = (int)((160 * 1024) / lds) < MINW / 2 ? (int)((160 * 1024) / lds) : MINW / 2;
+    const int max_wg = 256 * (wg_per_cu < 1 ? 1 : wg_per_cu);
     const int grid = a.num_tiles < max_wg ? a.num_tiles : max_wg;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a);
     return check_launch();
 }
 
+static long long *g_sa_trace = nullptr;
 }  // namespace pn2
+
+extern "C" void pn2x_debug_set_sa_trace(void *device_buffer_2x8x8_int64) { pn2::g_sa_trace = (long long *)device_buffer_2x8x8_int64; }
 
 extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c3, const float *a1f, int a1f_ld,
                                const float *xyz, const float *cxyz, const float *wx, const float *b1, const float *cadd,
@@ -287,10 +378,10 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
     a.N = n; a.S = s; a.K = k; a.lgK = 0;
     a.a1f = a1f; a.a1f_ld = a1f_ld; a.cadd_ld = cadd_ld; a.xyz = xyz; a.cxyz = cxyz; a.wx = wx; a.b1 = b1; a.cadd = cadd; a.idx = idx;
     a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out; a.out_b = out_b; a.out_s = out_s; a.out_c = out_c;
-    a.num_tiles = 0; a.tiles_per_cloud = 0;
+    a.num_tiles = 0; a.tiles_per_cloud = 0; a.trace = g_sa_trace;
     hipStream_t st = (hipStream_t)stream;
-    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2, 4, 2>(b, a, st);
-    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4, 4, 2>(b, a, st);
+    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2, 4, 4>(b, a, st);
+    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4, 2, 4>(b, a, st);
     if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4, 2, 2>(b, a, st);
     return PN2_ERANGE;
 }
