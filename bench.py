@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--no-elide", action="store_true", help="also compute the attention the reference discards")
     ap.add_argument("--no-fused", action="store_true", help="disable the fused SA kernels (unfused torch MLPs)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--inflight", type=int, default=2, help="number of batches in flight: step i is replayed on HIP stream "
+                    "i %% inflight (each stream has its own captured graph and buffers), so one batch's FPS / small "
+                    "kernels overlap another batch's GEMMs")
     ap.add_argument("--chunks", type=int, default=1, help="split the per-GPU batch into this many sub-batches that run "
                     "concurrently on separate HIP streams inside the captured graph")
     args = ap.parse_args()
@@ -226,14 +229,45 @@ def main():
                 forward_all()
             torch.cuda.synchronize()
             eager_ms = (time.perf_counter() - t0) / 5 * 1e3
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                forward_all()
-            step = graph.replay
+            ninf = max(1, args.inflight)
+            graphs, gstreams = [], [torch.cuda.Stream() for _ in range(ninf)]
+            for _ in range(ninf):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    forward_all()
+                graphs.append(g)
+
+            def make_step(n):
+                counter = [0]
+
+                def step():
+                    i = counter[0] % n
+                    counter[0] += 1
+                    if n == 1:
+                        graphs[0].replay()
+                    else:
+                        with torch.cuda.stream(gstreams[i]):
+                            graphs[i].replay()
+                return step
+            step = make_step(ninf)
             for _ in range(args.warmup):
                 step()
         else:
+            ninf = 1
             step = forward_all
+            make_step = None
+        single_ms = None
+        if use_graph and ninf > 1:  # informational: the same K steps strictly one after another on one stream
+            one = make_step(1)
+            sync_all()  # a graph must never be replayed while an earlier replay of it is still running
+            for _ in range(3):
+                one()
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                one()
+            sync_all()
+            single_ms = (time.perf_counter() - t0) / args.steps * 1e3
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -295,7 +329,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "npoints": args.npoints,
                        "parallelism": "dp%d (independent batches, no collective)" % world,
                        "dead_attention_elided": not args.no_elide, "fused_sa_kernels": fused_on,
-                       "launch": "hipGraph replay" if use_graph else "eager", "concurrent_sub_batches": nchunk, "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),
+                       "launch": "hipGraph replay" if use_graph else "eager", "concurrent_sub_batches": nchunk, "batches_in_flight": ninf, "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4), "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),
                        "weights": "deterministic random init (no checkpoint available offline)"},
             "frame_alg_bytes": alg_bytes,
             "frame_hbm_frac": None if alg_bytes is None else round(alg_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 6),
