@@ -45,11 +45,9 @@ def L1_loss(x, y, mask=None, check_dim_in=3):
     return (((x - y) * mask).abs().mean(dim=1).sum(dim=-1) / torch.clamp(mask.sum(dim=-1), min=1).squeeze()).mean()
 
 
-def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, fast: bool) -> torch.Tensor:
-    """Conv1d(kernel 1) on (B,C,J) with J = 21 keypoints.  fast: one token-major GEMM with the bias
-    in its epilogue (F.linear) instead of a convolution-library call; same arithmetic."""
-    if not fast:
-        return conv(x)
+def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, fast: bool = True) -> torch.Tensor:
+    """Conv1d(kernel 1) on (B,C,J) with J = 21 keypoints as one token-major GEMM with the bias in its
+    epilogue (F.linear) instead of a convolution-library call; same arithmetic, differentiable."""
     return F.linear(x.transpose(1, 2), conv.weight.squeeze(-1), conv.bias).transpose(1, 2)
 
 
@@ -135,18 +133,14 @@ class HandTrackNet(nn.Module):
                 and not torch.is_grad_enabled())
         src2 = self.bhand(xyz2)  # (B,C,N)
         f11, group_idx = self.q1(xyz2, src2, xyz1, None, return_group_idx=True)
-        f12 = self.r1(f11, fast)
+        f12 = self.r1(f11, True)
         f13 = self.q2(xyz2, src2, xyz1, f12, pre_group_idx=group_idx)
-        f14 = self.r2(f13, fast)
+        f14 = self.r2(f13, True)
         f15, f251 = self.transt(src1=f14, pos1=pos1, src2=src2, pos2=pos2, attn=False, elide_dead=elide,
                                 need_result2=not elide)
         fused = self.c3(f15, pos1, f251, pos2, attn=False, elide_dead=elide)
 
-        if fast:
-            h = F.relu(_conv1x1(self.final_mlp[0], fused, True))
-            delta = _conv1x1(self.final_mlp[2], h, True)
-        else:
-            delta = self.final_mlp(fused)
+        delta = _conv1x1(self.final_mlp[2], F.relu(_conv1x1(self.final_mlp[0], fused)))
         ret["pred_kp_handframe"] = delta + xyz1  # (B,3,kp)
         ret["init_kp_handframe"] = xyz1
         ret["points_handframe"] = xyz2
