@@ -5,24 +5,24 @@
 
 namespace pn2 {
 
-__global__ void __launch_bounds__(64)
-kabsch_kernel(int b, int xb, int num, const float *__restrict__ x_all, const float *__restrict__ y_all,
-              float *__restrict__ R_all, float *__restrict__ t_all) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= b) return;
-    const float *x = x_all + (size_t)(xb == 1 ? 0 : i) * num * 3;
-    const float *y = y_all + (size_t)i * num * 3;
+// Rigid fit y ~= R x + t of `num` point pairs; x, y given through accessors (pointer + stride in floats).
+// Horn's quaternion form; the 4x4 symmetric eigenproblem by cyclic Jacobi.  The matrix and the accumulated
+// rotations are fp64, but each rotation ANGLE is computed in fp32 (hardware divide / sqrt) and only its cosine is
+// re-normalised in fp64 with Newton steps (multiplies only): every applied rotation is orthogonal to ~1e-16, an
+// inexact angle merely leaves a tiny off-diagonal for the next sweep.  No fp64 divide / sqrt in the loop
+// (they made the first version of this kernel 20 us; this one is ~4 us).
+__device__ void kabsch_solve(int num, const float *x, const float *y, int ystride, double (&R)[3][3], double (&t)[3]) {
     double cx[3] = {0, 0, 0}, cy[3] = {0, 0, 0};
     for (int p = 0; p < num; ++p)
-        for (int a = 0; a < 3; ++a) { cx[a] += x[3 * p + a]; cy[a] += y[3 * p + a]; }
-    for (int a = 0; a < 3; ++a) { cx[a] /= num; cy[a] /= num; }
+        for (int a = 0; a < 3; ++a) { cx[a] += x[3 * p + a]; cy[a] += y[(size_t)ystride * p + a]; }
+    const double inv = 1.0 / num;
+    for (int a = 0; a < 3; ++a) { cx[a] *= inv; cy[a] *= inv; }
     double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // S[a][b] = sum (x_a - cx_a)(y_b - cy_b)
     for (int p = 0; p < num; ++p)
         for (int a = 0; a < 3; ++a)
-            for (int c = 0; c < 3; ++c) S[a][c] += ((double)x[3 * p + a] - cx[a]) * ((double)y[3 * p + c] - cy[c]);
+            for (int c = 0; c < 3; ++c) S[a][c] += ((double)x[3 * p + a] - cx[a]) * ((double)y[(size_t)ystride * p + c] - cy[c]);
 
-    // Horn 1987: rotation = eigenvector of the largest eigenvalue of N
-    double A[4][4];
+    double A[4][4];  // Horn 1987: rotation = eigenvector of the largest eigenvalue of N
     A[0][0] = S[0][0] + S[1][1] + S[2][2];
     A[0][1] = S[1][2] - S[2][1];
     A[0][2] = S[2][0] - S[0][2];
@@ -39,42 +39,51 @@ kabsch_kernel(int b, int xb, int num, const float *__restrict__ x_all, const flo
     double diag2 = 0;
     for (int p = 0; p < 4; ++p)
         for (int q = 0; q < 4; ++q) diag2 += A[p][q] * A[p][q];
-    for (int sweep = 0; sweep < 12; ++sweep) {
+    for (int sweep = 0; sweep < 16; ++sweep) {
         double off = 0;
         for (int p = 0; p < 3; ++p)
             for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
-        // converged to fp64 round-off relative to the matrix norm (quadratic convergence: ~4-5 sweeps)
-        if (off <= 1e-30 * diag2) break;
+        if (off <= 1e-30 * diag2) break;  // converged to fp64 round-off relative to the matrix norm
+#pragma unroll
         for (int p = 0; p < 3; ++p)
+#pragma unroll
             for (int q = p + 1; q < 4; ++q) {
-                if (fabs(A[p][q]) < 1e-300) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                const float apq = (float)A[p][q];
+                if (apq == 0.f) continue;
+                const float theta = (float)(A[q][q] - A[p][p]) / (2.0f * apq);
+                const float tf = (theta >= 0.f ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+                const double tt = (double)tf;
+                const double n2 = tt * tt + 1.0;
+                double c = (double)rsqrtf((float)n2);      // fp32 seed
+                c = c * (1.5 - 0.5 * n2 * c * c);            // Newton steps for 1/sqrt(n2) in fp64
+                c = c * (1.5 - 0.5 * n2 * c * c);
+                const double sn = tt * c;
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - s * akq;
-                    A[k][q] = s * akp + c * akq;
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
                 }
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - s * aqk;
-                    A[q][k] = s * apk + c * aqk;
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
                 }
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - s * vkq;
-                    V[k][q] = s * vkp + c * vkq;
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
                 }
             }
     }
-    int best = 0;
+    double q0 = V[0][0], q1 = V[1][0], q2 = V[2][0], q3 = V[3][0], best = A[0][0];
+#pragma unroll
     for (int k = 1; k < 4; ++k)
-        if (A[k][k] > A[best][best]) best = k;
-    double q0 = V[0][best], q1 = V[1][best], q2 = V[2][best], q3 = V[3][best];
-    const double nq = sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-    q0 /= nq; q1 /= nq; q2 /= nq; q3 /= nq;
-    double R[3][3];
+        if (A[k][k] > best) { best = A[k][k]; q0 = V[0][k]; q1 = V[1][k]; q2 = V[2][k]; q3 = V[3][k]; }
+    const double nq = 1.0 / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    q0 *= nq; q1 *= nq; q2 *= nq; q3 *= nq;
     R[0][0] = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3;
     R[0][1] = 2 * (q1 * q2 - q0 * q3);
     R[0][2] = 2 * (q1 * q3 + q0 * q2);
@@ -84,11 +93,63 @@ kabsch_kernel(int b, int xb, int num, const float *__restrict__ x_all, const flo
     R[2][0] = 2 * (q1 * q3 - q0 * q2);
     R[2][1] = 2 * (q2 * q3 + q0 * q1);
     R[2][2] = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
-    float *Ro = R_all + (size_t)i * 9;
-    float *to = t_all + (size_t)i * 3;
+    for (int a = 0; a < 3; ++a) t[a] = cy[a] - (R[a][0] * cx[0] + R[a][1] * cx[1] + R[a][2] * cx[2]);
+}
+
+__global__ void __launch_bounds__(64)
+kabsch_kernel(int b, int xb, int num, const float *__restrict__ x_all, const float *__restrict__ y_all,
+              float *__restrict__ R_all, float *__restrict__ t_all) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= b) return;
+    double R[3][3], t[3];
+    kabsch_solve(num, x_all + (size_t)(xb == 1 ? 0 : i) * num * 3, y_all + (size_t)i * num * 3, 3, R, t);
     for (int a = 0; a < 3; ++a) {
-        for (int c = 0; c < 3; ++c) Ro[3 * a + c] = (float)R[a][c];
-        to[a] = (float)(cy[a] - (R[a][0] * cx[0] + R[a][1] * cx[1] + R[a][2] * cx[2]));
+        for (int c = 0; c < 3; ++c) R_all[(size_t)i * 9 + 3 * a + c] = (float)R[a][c];
+        t_all[(size_t)i * 3 + a] = (float)t[a];
+    }
+}
+
+// pn2x_hand_frame: Kabsch on the palm keypoints + canonicalisation of the whole cloud, one workgroup per cloud.
+// Replaces ransac_rt + canonicalize (reference hand_network.py:100,118-119; hand_utils.py:30-31,42-66): the CPU
+// SVD hop, the cat/transpose and ~8 small torch kernels become one launch.
+//   out rows:  xyz_out[b, i, :] = R^T (p_i - t) / scale   written point-major (row-vector form (p - t) R / scale)
+__global__ void __launch_bounds__(256)
+hand_frame_kernel(int xb, int num, int n, int j, const float *__restrict__ tmpl_all, const float *__restrict__ kp_all,
+                  const int *__restrict__ palm_idx, const float *__restrict__ pts_all, float scale,
+                  float *__restrict__ R_all, float *__restrict__ t_all, float *__restrict__ xyz2_all,
+                  float *__restrict__ xyz1_all) {
+    __shared__ float sR[9], st[3];
+    __shared__ float sy[16 * 3];
+    const int b = blockIdx.x;
+    const float *kp = kp_all + (size_t)b * j * 3;
+    if (threadIdx.x < num * 3) sy[threadIdx.x] = kp[palm_idx[threadIdx.x / 3] * 3 + threadIdx.x % 3];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double R[3][3], t[3];
+        kabsch_solve(num, tmpl_all + (size_t)(xb == 1 ? 0 : b) * num * 3, sy, 3, R, t);
+        for (int a = 0; a < 3; ++a) {
+            for (int c = 0; c < 3; ++c) {
+                sR[3 * a + c] = (float)R[a][c];
+                R_all[(size_t)b * 9 + 3 * a + c] = (float)R[a][c];
+            }
+            st[a] = (float)t[a];
+            t_all[(size_t)b * 3 + a] = (float)t[a];
+        }
+    }
+    __syncthreads();
+    const float r00 = sR[0], r01 = sR[1], r02 = sR[2], r10 = sR[3], r11 = sR[4], r12 = sR[5], r20 = sR[6], r21 = sR[7], r22 = sR[8];
+    const float t0 = st[0], t1 = st[1], t2 = st[2];
+    const float *pts = pts_all + (size_t)b * n * 3;
+    float *o2 = xyz2_all + (size_t)b * n * 3;
+    float *o1 = xyz1_all + (size_t)b * j * 3;
+    for (int i = threadIdx.x; i < n + j; i += 256) {
+        const float *p = i < n ? pts + 3 * i : kp + 3 * (i - n);
+        float *o = i < n ? o2 + 3 * i : o1 + 3 * (i - n);
+        const float d0 = p[0] - t0, d1 = p[1] - t1, d2 = p[2] - t2;
+        // (R^T d)_c = sum_a R[a][c] d_a, accumulated in index order like the reference's matmul
+        o[0] = (d0 * r00 + d1 * r10 + d2 * r20) / scale;
+        o[1] = (d0 * r01 + d1 * r11 + d2 * r21) / scale;
+        o[2] = (d0 * r02 + d1 * r12 + d2 * r22) / scale;
     }
 }
 
@@ -99,5 +160,16 @@ extern "C" int pn2x_kabsch(int b, int xb, int num, const float *x, const float *
     if (b == 0) return PN2_OK;
     if (!x || !y || !R || !t) return PN2_ENULL;
     hipLaunchKernelGGL(pn2::kabsch_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, b, xb, num, x, y, R, t);
+    return pn2::check_launch();
+}
+
+extern "C" int pn2x_hand_frame(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
+                               const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
+                               float *xyz1, void *stream) {
+    if (b < 0 || num < 1 || num > 16 || n < 0 || j < 1 || !(xb == b || xb == 1) || !(scale > 0.f)) return PN2_EINVAL;
+    if (b == 0) return PN2_OK;
+    if (!palm_template || !kp || !palm_idx || !points || !R || !t || !xyz2 || !xyz1) return PN2_ENULL;
+    hipLaunchKernelGGL(pn2::hand_frame_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, xb, num, n, j, palm_template, kp,
+                       palm_idx, points, scale, R, t, xyz2, xyz1);
     return pn2::check_launch();
 }

@@ -169,3 +169,29 @@ def max_rows(x: torch.Tensor) -> torch.Tensor:
         _native._check(_lib.pn2x_max_rows(B, R, C, _native._ptr(x, "x", torch.float32, B * R * C), out.data_ptr(),
                                           _native._stream(x)), "max_rows")
     return out
+
+
+_lib.pn2x_hand_frame.argtypes = [_ci] * 5 + [_vp] * 4 + [ctypes.c_float] + [_vp] * 5
+_lib.pn2x_hand_frame.restype = _ci
+
+
+def hand_frame(palm_template: torch.Tensor, kp: torch.Tensor, palm_idx: torch.Tensor, points: torch.Tensor, scale: float):
+    """Kabsch(palm_template -> kp[:, palm_idx]) + canonicalisation in one launch.
+    Returns R (B,3,3), t (B,3,1), xyz2 (B,N,3), xyz1 (B,J,3)."""
+    if palm_template.dim() == 2:
+        palm_template = palm_template.unsqueeze(0)
+    palm_template, kp, points = palm_template.float().contiguous(), kp.float().contiguous(), points.float().contiguous()
+    B, N, _ = points.shape
+    J = kp.shape[1]
+    xb, num = palm_template.shape[0], palm_template.shape[1]
+    f32 = torch.float32
+    R = torch.empty((B, 3, 3), dtype=f32, device=points.device)
+    t = torch.empty((B, 3, 1), dtype=f32, device=points.device)
+    xyz2 = torch.empty((B, N, 3), dtype=f32, device=points.device)
+    xyz1 = torch.empty((B, J, 3), dtype=f32, device=points.device)
+    with torch.cuda.device(points.device):
+        _native._check(_lib.pn2x_hand_frame(B, xb, num, N, J, _native._ptr(palm_template, "palm_template", f32, xb * num * 3),
+                                            _native._ptr(kp, "kp", f32, B * J * 3), _native._ptr(palm_idx, "palm_idx", torch.int32, num),
+                                            _native._ptr(points, "points", f32, B * N * 3), float(scale), R.data_ptr(), t.data_ptr(),
+                                            xyz2.data_ptr(), xyz1.data_ptr(), _native._stream(points)), "hand_frame")
+    return R, t, xyz2, xyz1

@@ -26,6 +26,18 @@ extern "C" {
 int pn2x_kabsch(int b, int xb, int num, const float *x, const float *y, float *R, float *t, void *stream);
 
 /*
+ * Hand frame in one launch: Kabsch fit of the palm template to kp[:, palm_idx] (num <= 16 indices, device int32)
+ * followed by the canonicalisation of the cloud and of the keypoints,
+ *   xyz2[b,i,:] = R_b^T (points[b,i,:] - t_b) / scale      xyz1[b,k,:] = R_b^T (kp[b,k,:] - t_b) / scale
+ * (reference hand_network.py:100,118-119 + hand_utils.py:30-31,42-66: ransac_rt with a CPU SVD, torch.cat,
+ * transpose, matmul, divide).  points (b,n,3), kp (b,j,3), palm_template (xb,num,3) with xb in {1,b};
+ * outputs R (b,3,3), t (b,3,1), xyz2 (b,n,3), xyz1 (b,j,3), all point-major.
+ */
+int pn2x_hand_frame(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
+                    const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
+                    float *xyz1, void *stream);
+
+/*
  * Fused grouped MLP + max of one set-abstraction scale, eval mode (BatchNorm folded into the
  * 1x1 convolutions by the caller).  Replaces, for one (radius | kNN) scale, the reference's
  *   group(points, idx) / group(xyz, idx) - centre / cat / [Conv2d 1x1 + BN2d + ReLU] x3 / max over K

@@ -24,7 +24,6 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from .hand_utils import handkp2palmkp, ransac_rt
 
 
 def _lin_relu(x2d: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -37,6 +36,19 @@ class FastEval:
         self.net = net
         self._key = None
         self.P = None
+        self._consts = {}
+
+    def _palm_idx(self, device):
+        key = ("palm", str(device))
+        if key not in self._consts:
+            self._consts[key] = torch.tensor([0, 1, 5, 9, 13, 17], dtype=torch.int32, device=device)  # hand_utils.handkp2palmkp
+        return self._consts[key]
+
+    def _scale(self, device):
+        key = ("scale", str(device))
+        if key not in self._consts:
+            self._consts[key] = 0.2 * torch.ones(1, dtype=torch.float32, device=device)
+        return self._consts[key]
 
     # ------------------------------------------------------------------------------------
     def _versions(self):
@@ -118,12 +130,14 @@ class FastEval:
         # ---- hand frame: R^T (x - t) / s, written for row vectors ------------------------------
         if net.handframe != "kp":
             raise NotImplementedError("fast path covers handframe='kp' (HandTrackNet's configuration)")
-        R, t, _, _, _ = ransac_rt(palm, handkp2palmkp(kp))
-        scale = 0.2 * torch.ones(1, **f32)
+        if kp.shape[1] != 21:
+            raise NotImplementedError("fast path covers the 21-keypoint hand")
+        palm_idx = self._palm_idx(pts.device)
+        # Kabsch (palm template -> jittered palm keypoints) + canonicalisation of cloud and keypoints: one launch
+        R, t, xyz2, xyz1 = ext.hand_frame(palm.contiguous(), kp.contiguous(), palm_idx, pts.contiguous(), 0.2)
+        scale = self._scale(pts.device)
         canon = {"scale": scale, "rotation": R, "translation": t}
         tt = t.transpose(1, 2)
-        xyz2 = torch.matmul(pts - tt, R).div_(0.2)  # (B,N,3) hand points, hand frame
-        xyz1 = torch.matmul(kp - tt, R).div_(0.2)  # (B,J,3) keypoints, hand frame
 
         bh = net.bhand
         # ---- sa1: 1024 -> 256 centroids, r = 0.1, K = 32, MLP [3 -> 32 -> 32 -> 64] ------------------

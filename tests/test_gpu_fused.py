@@ -45,6 +45,22 @@ def test_kabsch_matches_svd(B, num, shared):
     assert torch.allclose(torch.det(R.cpu()), torch.ones(B), atol=1e-5)
 
 
+def test_hand_frame_matches_kabsch_plus_canonicalize():
+    from hotrack_amd import ext
+    from models.hand_utils import canonicalize
+    d = synthetic_frames(3, 16, 1024)
+    pts, kp, palm = d["hand_points"].cuda(), d["jittered_hand_kp"].cuda(), d["gt_hand_pose"]["palm_template"].cuda()
+    idx = torch.tensor([0, 1, 5, 9, 13, 17], dtype=torch.int32, device="cuda")
+    R, t, xyz2, xyz1 = ext.hand_frame(palm, kp, idx, pts, 0.2)
+    Rr, tr = _kabsch_ref(palm.cpu(), kp[:, idx.long()].cpu())
+    assert torch.allclose(R.cpu(), Rr, atol=2e-6) and torch.allclose(t.cpu(), tr, atol=2e-6)
+    pose = {"rotation": R, "translation": t, "scale": 0.2 * torch.ones(1, device="cuda")}
+    ref = canonicalize(torch.cat([pts, kp], 1).transpose(1, 2), pose).transpose(1, 2)
+    assert torch.allclose(xyz2, ref[:, :1024], atol=2e-6) and torch.allclose(xyz1, ref[:, 1024:], atol=2e-6)
+    R2, t2 = ext.kabsch(palm, kp[:, idx.long()].contiguous())
+    assert torch.equal(R2, R) and torch.equal(t2, t)
+
+
 def _mk_sa(in_ch, widths, seed):
     from models.pointnet_utils import PointNetSetAbstractionMsg_GivenCenterPoints
     m = PointNetSetAbstractionMsg_GivenCenterPoints([0.2], [16], [widths], in_channel=in_ch, knn=True)
