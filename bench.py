@@ -160,11 +160,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("PN2_BENCH_BACKEND", "nccl")  # "gloo": lets N ranks share one GPU (harness self-test only)
+    if backend == "nccl":
+        assert local < ndev, f"LOCAL_RANK {local} but only {ndev} GPUs are visible"
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI; only used for the barrier / max-time reduce
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from _netinit import synthetic_frames
@@ -284,7 +292,7 @@ def main():
     assert all(torch.isfinite(o["pred_kp"]).all() for o in outs)
 
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
