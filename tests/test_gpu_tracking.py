@@ -61,3 +61,29 @@ def test_test_py_entry_point_on_gpu(tmp_path, monkeypatch):
     a = p.parse_args(["--config", "handtracknet_test_SimGrasp.yml"])
     a.num_points, a.synthetic_frames = 1024, 5
     test_entry.main(a)
+
+
+def test_loader_side_fps_batched_equals_per_cloud(oracle):
+    import numpy as np
+    from datasets.data_utils import farthest_point_sample_batch
+    rng = np.random.default_rng(0)
+    clouds = [rng.random((n, 3)).astype(np.float32) for n in (6000, 9000, 2000, 5120, 700)]
+    npoint = 512
+
+    class Fixed:  # deterministic "random" permutation so both calls see the same pre-subsample
+        def __init__(self):
+            self.r = np.random.default_rng(1)
+
+        def permutation(self, n):
+            return self.r.permutation(n)
+    batched = farthest_point_sample_batch(clouds, npoint, "cuda", rng=Fixed())
+    f = Fixed()
+    single = [farthest_point_sample_batch([c], npoint, "cuda", rng=f)[0] for c in clouds]
+    for b, s, c in zip(batched, single, clouds):
+        assert len(b) == npoint and len(set(b.tolist())) == npoint and b.max() < len(c)
+        np.testing.assert_array_equal(b, s)
+    # the sampled subset is exactly the oracle's FPS of the pre-subsampled cloud
+    f = Fixed()
+    keep = f.permutation(6000)[:5 * npoint]
+    ref = oracle.furthest_point_sample(clouds[0][keep][None], npoint)[0]
+    np.testing.assert_array_equal(batched[0], keep[ref])
