@@ -57,7 +57,7 @@ struct SaArgs {
 // Two s_barriers per tile keep the roles in step (H1[next] complete / H2 reusable).
 // RTC = row tiles (of 16 positions) whose accumulators are live at once (4 = fewest passes over the weight
 // registers, 2 = half the accumulator / A-fragment registers).  MINW = waves per SIMD for __launch_bounds__.
-template <int C1, int C2, int C3, int WC, int RTC, int MINW>
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1>
 __global__ void __launch_bounds__(512, MINW)
 sa_mlp_max_kernel(const SaArgs A) {
     const int N = A.N, S = A.S, K = A.K, lgK = A.lgK;
@@ -70,9 +70,10 @@ sa_mlp_max_kernel(const SaArgs A) {
     constexpr int NT2 = C2 / (16 * WC), NT3 = C3 / (16 * WC);
     static_assert(C2 % (16 * WC) == 0 && C3 % (16 * WC) == 0 && C1 % 16 == 0, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *H1a = smem;
-    float *H1b = smem + TM * LD1;
-    float *H2 = smem + 2 * TM * LD1;
+    // H1 ring of NB1 tiles: the LOAD role runs NB1-1 tiles ahead of the COMPUTE role, so a slow gather (HBM miss,
+    // issue arbitration against the MFMA stream) is absorbed by the ring instead of stalling the matrix cores
+    float *H1ring = smem;
+    float *H2 = smem + NB1 * TM * LD1;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,7 +111,13 @@ sa_mlp_max_kernel(const SaArgs A) {
     auto gather = [&](int tile, float *__restrict__ H1, int h) {
         const int b = tile / tiles_per_cloud;
         const int pos0 = (tile - b * tiles_per_cloud) * TM + h * (TM / 2);
+        // wave-uniform (scalar) per-cloud bases + 32-bit per-lane offsets: the LOAD role's address arithmetic is
+        // a handful of 32-bit VALU ops per row (it competes with the MFMA stream for issue slots)
         const int *__restrict__ idxb = A.idx + (size_t)b * SK;
+        const float *__restrict__ a1b = A.a1f ? A.a1f + (size_t)b * N * A.a1f_ld : nullptr;
+        const float *__restrict__ cab = A.cadd ? A.cadd + (size_t)b * S * A.cadd_ld : nullptr;
+        const float *__restrict__ xb_ = A.xyz ? A.xyz + (size_t)b * N * 3 : nullptr;
+        const float *__restrict__ cb_ = A.xyz ? A.cxyz + (size_t)b * S * 3 : nullptr;
         const int row0 = lt / Q1;
         int jj[RPT], ss[RPT];
 #pragma unroll
@@ -126,18 +133,18 @@ sa_mlp_max_kernel(const SaArgs A) {
         if (A.a1f) {
 #pragma unroll
             for (int r = 0; r < RPT; ++r)
-                a[r] = *reinterpret_cast<const float4 *>(A.a1f + ((size_t)b * N + jj[r]) * A.a1f_ld + 4 * c4);
+                a[r] = *reinterpret_cast<const float4 *>(a1b + (unsigned)(jj[r] * A.a1f_ld + 4 * c4));
         }
         if (A.cadd) {
 #pragma unroll
             for (int r = 0; r < RPT; ++r)
-                c[r] = *reinterpret_cast<const float4 *>(A.cadd + ((size_t)b * S + ss[r]) * A.cadd_ld + 4 * c4);
+                c[r] = *reinterpret_cast<const float4 *>(cab + (unsigned)(ss[r] * A.cadd_ld + 4 * c4));
         }
         if (A.xyz) {
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
-                pj[r] = load_xyz(A.xyz + ((size_t)b * N + jj[r]) * 3);
-                cs[r] = load_xyz(A.cxyz + ((size_t)b * S + ss[r]) * 3);
+                pj[r] = load_xyz(xb_ + (unsigned)(jj[r] * 3));
+                cs[r] = load_xyz(cb_ + (unsigned)(ss[r] * 3));
             }
         }
 #pragma unroll
@@ -182,9 +189,12 @@ sa_mlp_max_kernel(const SaArgs A) {
             }
         }
     } else {
-        if ((int)blockIdx.x < num_tiles) {  // prologue: first tile
-            gather(blockIdx.x, H1a, 0);
-            gather(blockIdx.x, H1a, 1);
+        for (int a = 0; a < NB1 - 1; ++a) {  // prologue: the first NB1-1 tiles of this workgroup
+            const int tile = blockIdx.x + a * gridDim.x;
+            if (tile < num_tiles) {
+                gather(tile, H1ring + a * TM * LD1, 0);
+                gather(tile, H1ring + a * TM * LD1, 1);
+            }
         }
     }
     __syncthreads();
@@ -203,8 +213,8 @@ sa_mlp_max_kernel(const SaArgs A) {
         int it = 0;
         for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, ++it) {
             stamp(it, 0);
-            float *H1n = (it & 1) ? H1a : H1b;
-            const int next = tile + gridDim.x;
+            float *H1n = H1ring + ((it + NB1 - 1) % NB1) * TM * LD1;  // last read by COMPUTE in iteration it-1
+            const int next = tile + (NB1 - 1) * gridDim.x;
             if (next < num_tiles) gather(next, H1n, 0);
             stamp(it, 2);
             __syncthreads();  // B1
@@ -219,7 +229,7 @@ sa_mlp_max_kernel(const SaArgs A) {
     int it = 0;
     for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, ++it) {
         stamp(it, 0);
-        float *H1 = (it & 1) ? H1b : H1a;
+        float *H1 = H1ring + (it % NB1) * TM * LD1;
         const int b = tile / tiles_per_cloud;
         const int pos0 = (tile - b * tiles_per_cloud) * TM;
         {
@@ -330,7 +340,7 @@ sa_mlp_max_kernel(const SaArgs A) {
     }
 }
 
-template <int C1, int C2, int C3, int WC, int RTC, int MINW>
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1>
 static int launch_sa(int b, SaArgs a, hipStream_t st) {
     constexpr int WP = 4 / WC, TM = WP * 64;
     const int sk = a.S * a.K;
@@ -340,8 +350,8 @@ static int launch_sa(int b, SaArgs a, hipStream_t st) {
     a.num_tiles = (int)num_tiles_l;
     a.lgK = 0;
     while ((1 << a.lgK) < a.K) ++a.lgK;
-    const size_t lds = (size_t)TM * (2 * (C1 + 4) + C2 + 4) * sizeof(float);
-    auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW>;
+    const size_t lds = (size_t)TM * (NB1 * (C1 + 4) + C2 + 4) * sizeof(float);
+    auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW, NB1>;
     static bool attr_set = false;  // once per instantiation; never during a later stream capture
     if (lds > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -380,9 +390,9 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
     a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out; a.out_b = out_b; a.out_s = out_s; a.out_c = out_c;
     a.num_tiles = 0; a.tiles_per_cloud = 0; a.trace = g_sa_trace;
     hipStream_t st = (hipStream_t)stream;
-    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2, 4, 4>(b, a, st);
-    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4, 2, 4>(b, a, st);
-    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4, 2, 2>(b, a, st);
+    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2, 4, 4, 2>(b, a, st);
+    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4, 2, 4, 2>(b, a, st);
+    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4, 2, 2, 2>(b, a, st);
     return PN2_ERANGE;
 }
 
