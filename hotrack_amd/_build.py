@@ -16,6 +16,8 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # the only fused multiply-adds are the explicit __builtin_fmaf calls (index parity)
     "-ffp-contract=off",
+    # IEEE-correct fp32 '/' and sqrtf (the hipcc default, stated because sdf.hip's bit parity depends on it)
+    "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
 ]
 
@@ -53,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr)):
             return obj
-        cmd = [hipcc, *HIPCC_FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *HIPCC_FLAGS, *os.environ.get("PN2_EXTRA_HIPCC_FLAGS", "").split(), "-c", src, "-o", obj]  # env: tuning sweeps
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

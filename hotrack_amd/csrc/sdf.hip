@@ -1,0 +1,499 @@
+// sdf.hip -- the particle optimisers' signed-distance-volume lookups (include/pn2_sdf.h).
+//
+// Gather-bound work: every (particle, point) pair costs one 3x3 transform, a few dozen fp32 ops and 8 (trilinear)
+// or 1 (nearest) reads of a 2-byte voxel.  The volume (201^3 fp16 = 16 MB) and the cloud (N x 12 B) are shared by
+// all particles and stay in L2 / Infinity Cache; nothing of size P x N is ever written.  One workgroup per
+// particle (P = 2048..5120 >> 256 CUs), 256 threads striding over the points, one block reduction per particle.
+//
+// Arithmetic follows the reference's torch expressions operation for operation (fp32, true division, same
+// association; compiled with -ffp-contract=off), so Distance() is bit-identical to the reference.
+#include <hip/hip_fp16.h>
+
+#include "pn2_common.h"
+#include "../../include/pn2_sdf.h"
+
+namespace pn2 {
+
+struct SdfVol {
+    const void *p;
+    int res;
+    float bbox_min, stride, lo, hi;
+};
+
+template <bool F16>
+__device__ __forceinline__ float vol_at(const void *v, int i) {
+    if constexpr (F16) return __half2float(reinterpret_cast<const __half *>(v)[i]);
+    else return reinterpret_cast<const float *>(v)[i];
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {  // torch.clamp: min(max(v, lo), hi)
+    v = v < lo ? lo : v;
+    return v > hi ? hi : v;
+}
+
+// One point of gf_optimize_obj.Distance (optimization_obj.py:184-228), in three steps so that callers can issue
+// the gathers of several points before blending any of them (the kernel is gather-latency bound).
+struct TriPoint {
+    int i000;
+    float x, y, z;  // fractional parts
+};
+
+__device__ __forceinline__ TriPoint tri_setup(const SdfVol &A, float vx, float vy, float vz) {
+    const float top = (float)(A.res - 1);
+    float x = clampf((vx - A.bbox_min) / A.stride, 0.0f, top);
+    float y = clampf((vy - A.bbox_min) / A.stride, 0.0f, top);
+    float z = clampf((vz - A.bbox_min) / A.stride, 0.0f, top);
+    const int xi = (int)x, yi = (int)y, zi = (int)z;  // x >= 0: trunc == floor
+    TriPoint t;
+    t.x = x - (float)xi;
+    t.y = y - (float)yi;
+    t.z = z - (float)zi;
+    t.i000 = (xi * A.res + yi) * A.res + zi;
+    return t;
+}
+
+#ifndef SDF_PAIR
+#define SDF_PAIR 1
+#endif
+#ifndef SDF_U
+#define SDF_U 1  /* measured: 1, 2, 4 within 1% once SDF_PAIR is on (profiles/r01_sdf_sweep.txt) */
+#endif
+
+// Two z-adjacent voxels (i, i+1) with ONE load: the kernel is bound by the number of divergent gather lanes the
+// texture-address path has to process, and z-neighbours are adjacent in memory (2-byte aligned only: memcpy lets
+// the compiler pick an unaligned dword load, which gfx950 global memory supports).
+template <bool F16>
+__device__ __forceinline__ void vol_pair(const void *v, int i, float &a, float &b) {
+    if constexpr (F16) {
+        unsigned w;
+        __builtin_memcpy(&w, reinterpret_cast<const __half *>(v) + i, 4);
+        a = __half2float(__ushort_as_half((unsigned short)(w & 0xffffu)));
+        b = __half2float(__ushort_as_half((unsigned short)(w >> 16)));
+    } else {
+        float2 w;
+        __builtin_memcpy(&w, reinterpret_cast<const float *>(v) + i, 8);
+        a = w.x;
+        b = w.y;
+    }
+}
+
+template <bool F16>
+__device__ __forceinline__ void tri_gather(const SdfVol &A, const TriPoint &t, float *d) {
+    const int R = A.res, RR = R * R, last = RR * R - 1, i = t.i000;
+    if (SDF_PAIR && i + 1 + R + RR <= last) {  // everywhere except the volume's last corner
+        vol_pair<F16>(A.p, i, d[0], d[1]);
+        vol_pair<F16>(A.p, i + R, d[2], d[3]);
+        vol_pair<F16>(A.p, i + RR, d[4], d[5]);
+        vol_pair<F16>(A.p, i + R + RR, d[6], d[7]);
+        return;
+    }
+    // the reference clamps each corner index to [0, res^3 - 1] (:215-222); only the upper clamp can bind
+    d[0] = vol_at<F16>(A.p, i);                          d[1] = vol_at<F16>(A.p, min(i + 1, last));
+    d[2] = vol_at<F16>(A.p, min(i + R, last));           d[3] = vol_at<F16>(A.p, min(i + 1 + R, last));
+    d[4] = vol_at<F16>(A.p, min(i + RR, last));          d[5] = vol_at<F16>(A.p, min(i + 1 + RR, last));
+    d[6] = vol_at<F16>(A.p, min(i + R + RR, last));      d[7] = vol_at<F16>(A.p, min(i + 1 + R + RR, last));
+}
+
+__device__ __forceinline__ float tri_blend(const SdfVol &A, const TriPoint &t, const float *d) {
+    const float mx = 1.0f - t.x, my = 1.0f - t.y, mz = 1.0f - t.z;
+    const float lo = ((d[0] * mz + d[1] * t.z) * my + (d[2] * mz + d[3] * t.z) * t.y) * mx;  // :223-226, same association
+    const float hi = ((d[4] * mz + d[5] * t.z) * my + (d[6] * mz + d[7] * t.z) * t.y) * t.x;
+    return clampf(lo + hi, A.lo, A.hi);
+}
+
+template <bool F16>
+__device__ __forceinline__ float trilinear(const SdfVol &A, float vx, float vy, float vz) {
+    const TriPoint t = tri_setup(A, vx, vy, vz);
+    float d[8];
+    tri_gather<F16>(A, t, d);
+    return tri_blend(A, t, d);
+}
+
+// (p - t) @ R with the fixed chain o_j = fma(q2, R2j, fma(q1, R1j, q0*R0j)) (same chain in oracle/sdf_oracle.c).
+__device__ __forceinline__ void to_object_frame(float px, float py, float pz, const float *t, const float *R, float &ox,
+                                                float &oy, float &oz) {
+    const float q0 = px - t[0], q1 = py - t[1], q2 = pz - t[2];
+    ox = fmaf(q2, R[6], fmaf(q1, R[3], q0 * R[0]));
+    oy = fmaf(q2, R[7], fmaf(q1, R[4], q0 * R[1]));
+    oz = fmaf(q2, R[8], fmaf(q1, R[5], q0 * R[2]));
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float *sm) {  // sm: >= 4 floats of LDS; all threads get the sum
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return r;
+}
+
+template <bool F16>
+__global__ void __launch_bounds__(256) sdf_trilinear_kernel(int m, const float *__restrict__ V, SdfVol A, float *__restrict__ out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256)
+        out[i] = trilinear<F16>(A, V[3 * i], V[3 * i + 1], V[3 * i + 2]);
+}
+
+// mean_j |Distance((pcld_j - t) @ R)| for the calling block's particle; every thread returns the value.
+template <bool F16>
+__device__ __forceinline__ float particle_sdf_energy(int n, const float *__restrict__ pcld, const float *R, const float *t,
+                                                     const SdfVol &A, float *sm) {
+    constexpr int U = SDF_U;  // points per thread whose gathers are all issued before any blend
+    float acc = 0.0f;
+    for (int j0 = threadIdx.x; j0 < n; j0 += 256 * U) {
+        TriPoint tp[U];
+        float d[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(j0 + 256 * u, n - 1);  // out-of-range slots re-read the last point and are masked below
+            float ox, oy, oz;
+            to_object_frame(pcld[3 * j], pcld[3 * j + 1], pcld[3 * j + 2], t, R, ox, oy, oz);
+            tp[u] = tri_setup(A, ox, oy, oz);
+            tri_gather<F16>(A, tp[u], d[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float v = fabsf(tri_blend(A, tp[u], d[u]));
+            acc += (j0 + 256 * u < n) ? v : 0.0f;
+        }
+    }
+    return block_sum_256(acc, sm) / (float)n;
+}
+
+template <bool F16>
+__global__ void __launch_bounds__(256)
+sdf_particle_energy_kernel(int n, const float *__restrict__ pcld, const float *__restrict__ rot, const float *__restrict__ trans,
+                           SdfVol A, float *__restrict__ sdf_energy) {
+    __shared__ float sm[4];
+    const int i = blockIdx.x;
+    float R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = rot[9 * i + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = trans[3 * i + k];
+    const float e = particle_sdf_energy<F16>(n, pcld, R, t, A, sm);
+    if (threadIdx.x == 0) sdf_energy[i] = e;
+}
+
+// ---- gf_optimize_obj.optimize's particle loop (optimization_obj.py:253-301) ----------------------------------------
+// work layout (floats): [0..5] search size, [6..11] previous search size, [12] previous-success flag,
+// [13] "previous search size is still the Python scalar c1" flag, [14] ticket counter (u32), [15] pad,
+// [16 .. 16+p) per-particle sdf_energy.
+constexpr int W_SEARCH = 0, W_PREV = 6, W_PREV_OK = 12, W_PREV_SCALAR = 13, W_TICKET = 14, W_ENERGY = 16;
+
+__device__ __forceinline__ void quat_to_matrix(float w, float x, float y, float z, float *m) {  // rotations.py:105-113
+    m[0] = 1.0f - 2.0f * y * y - 2.0f * z * z;  m[1] = 2.0f * x * y - 2.0f * z * w;         m[2] = 2.0f * x * z + 2.0f * y * w;
+    m[3] = 2.0f * x * y + 2.0f * z * w;         m[4] = 1.0f - 2.0f * x * x - 2.0f * z * z;  m[5] = 2.0f * y * z - 2.0f * x * w;
+    m[6] = 2.0f * x * z - 2.0f * y * w;         m[7] = 2.0f * y * z + 2.0f * x * w;         m[8] = 1.0f - 2.0f * x * x - 2.0f * y * y;
+}
+
+__device__ __forceinline__ void mat3_mul(const float *a, const float *b, float *o) {  // o = a @ b, fixed fma chain
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[3 * i + j] = fmaf(a[3 * i + 2], b[6 + j], fmaf(a[3 * i + 1], b[3 + j], a[3 * i] * b[j]));
+}
+
+// sample = [qw, pre*search] (:259-261)
+__device__ __forceinline__ void particle_sample(const float *__restrict__ pre, int i, const float *search, float *s) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[1 + k] = pre[6 * i + k] * search[k];
+    s[0] = sqrtf(1.0f - s[1] * s[1] - s[2] * s[2] - s[3] * s[3]);
+}
+
+__device__ __forceinline__ void normalize3(float *v) {  // rotations.py:328-340
+    const float mag = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (mag > 1e-8f) {
+        v[0] /= mag; v[1] /= mag; v[2] /= mag;
+    } else {
+        v[0] = 1.0f; v[1] = 0.0f; v[2] = 0.0f;
+    }
+}
+
+struct OptArgs {
+    int p, n;
+    const float *pcld, *pre;
+    SdfVol V;
+    float c2, beta, one_minus_beta, carry0;
+    float *pose, *work;
+};
+
+__global__ void opt_init_kernel(float *work, float c1) {
+    const int t = threadIdx.x;
+    if (t < 6) work[W_SEARCH + t] = c1;
+    if (t >= 6 && t < 12) work[t] = c1;
+    if (t == 12) work[W_PREV_OK] = 1.0f;
+    if (t == 13) work[W_PREV_SCALAR] = 1.0f;
+    if (t == 14) reinterpret_cast<unsigned *>(work)[W_TICKET] = 0u;
+}
+
+template <bool F16>
+__global__ void __launch_bounds__(256) obj_optimize_kernel(const OptArgs A) {
+    __shared__ float sm[4];
+    __shared__ float red[9 * 4 + 4];
+    __shared__ int is_last;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    float *__restrict__ work = A.work;
+    float *__restrict__ energy = work + W_ENERGY;
+
+    float search[6], R0[9], t0[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) search[k] = work[W_SEARCH + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R0[k] = A.pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t0[k] = A.pose[9 + k];
+    {
+        float s[7], S[9], R[9], t[3];
+        particle_sample(A.pre, i, search, s);
+        quat_to_matrix(s[0], s[1], s[2], s[3], S);
+        mat3_mul(R0, S, R);  // :263
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = t0[k] + s[4 + k];  // :264
+        const float e = particle_sdf_energy<F16>(A.n, A.pcld, R, t, A.V, sm);
+        // agent-scope (write-through) store: visible to every XCD without an L2 write-back
+        if (tid == 0) __hip_atomic_store(&energy[i], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the last workgroup to finish performs the pose / search-size update of this iteration --------------------
+    // No fences: a release/acquire pair at agent scope costs an L2 write-back / invalidate per workgroup on this
+    // multi-XCD part (measured: 163 us per iteration instead of ~40, the shared volume keeps being evicted).
+    // Instead energy[] is written and read with agent-scope atomics (coherent per location), and the store is
+    // complete (vmcnt(0)) before this workgroup takes its ticket, so whoever draws the last ticket sees them all.
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(work) + W_TICKET, 1u, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (ticket == (unsigned)A.p - 1u);
+    }
+    __syncthreads();
+    if (!is_last) return;
+
+    const float origin_sdf = __hip_atomic_load(&energy[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float origin = origin_sdf * 500.0f;  // :236
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0f;
+    int any = 0;
+    for (int q = tid; q < A.p; q += 256) {
+        const float se = __hip_atomic_load(&energy[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float en = se * 500.0f;
+        const bool better = en < origin;  // :271
+        const float w = better ? origin - en : 0.0f;
+        any |= better;
+        float s[7];
+        particle_sample(A.pre, q, search, s);
+        acc[0] += w;
+        acc[1] += se * w;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[2 + k] += s[k] * w;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 32; o; o >>= 1) v += __shfl_down(v, o);
+        if ((tid & 63) == 0) red[k * 4 + (tid >> 6)] = v;
+    }
+    const unsigned long long any_b = __ballot(any);
+    if ((tid & 63) == 0) red[36 + (tid >> 6)] = any_b ? 1.0f : 0.0f;
+    __syncthreads();
+    if (tid != 0) return;
+
+    float sum[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sum[k] = (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
+    const bool success = (red[36] + red[37] + red[38] + red[39]) > 0.0f;
+    const float wsum = sum[0] + 1e-5f;  // :273
+    float mean_sdf, mt[7];
+    if (success) {
+        mean_sdf = sum[1] / wsum;  // :275
+#pragma unroll
+        for (int k = 0; k < 7; ++k) mt[k] = sum[2 + k] / wsum;  // :283
+        const float qn = sqrtf(mt[0] * mt[0] + mt[1] * mt[1] + mt[2] * mt[2] + mt[3] * mt[3]) + 1e-8f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mt[k] /= qn;  // :284
+        float S[9], Rn[9];
+        quat_to_matrix(mt[0], mt[1], mt[2], mt[3], S);
+        mat3_mul(R0, S, Rn);  // :285
+        // SO(3) re-projection: Gram-Schmidt on the first two ROWS (:287, rotations.py:356-369 + transpose)
+        float x[3] = {Rn[0], Rn[1], Rn[2]}, yr[3] = {Rn[3], Rn[4], Rn[5]}, z[3], y[3];
+        normalize3(x);
+        z[0] = x[1] * yr[2] - x[2] * yr[1]; z[1] = x[2] * yr[0] - x[0] * yr[2]; z[2] = x[0] * yr[1] - x[1] * yr[0];
+        normalize3(z);
+        y[0] = z[1] * x[2] - z[2] * x[1]; y[1] = z[2] * x[0] - z[0] * x[2]; y[2] = z[0] * x[1] - z[1] * x[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            A.pose[k] = x[k];
+            A.pose[3 + k] = y[k];
+            A.pose[6 + k] = z[k];
+            A.pose[9 + k] = t0[k] + mt[4 + k];  // :288
+        }
+    } else {
+        mean_sdf = origin_sdf;  // :278
+#pragma unroll
+        for (int k = 0; k < 7; ++k) mt[k] = 0.0f;
+    }
+    // update_seach_size (:239-242) and its smoothing (:293-299)
+    float s[6], nrm = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        s[k] = fabsf(mt[1 + k]) + 1e-3f;
+        nrm += s[k] * s[k];
+    }
+    nrm = sqrtf(nrm);
+    const bool prev_ok = work[W_PREV_OK] != 0.0f, prev_scalar = work[W_PREV_SCALAR] != 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float ns = mean_sdf * A.c2 * s[k] / nrm + 1e-3f;
+        if (prev_ok && success) {
+            const float carry = prev_scalar ? A.carry0 : A.one_minus_beta * work[W_PREV + k];
+            ns = A.beta * ns + carry;
+        }
+        work[W_SEARCH + k] = ns;
+        if (success) work[W_PREV + k] = ns;
+    }
+    if (success) work[W_PREV_SCALAR] = 0.0f;
+    work[W_PREV_OK] = success ? 1.0f : 0.0f;
+    reinterpret_cast<unsigned *>(work)[W_TICKET] = 0u;
+}
+
+// ---- gf_optimize_hand_pose.query_sdf (+ get_penetration_loss) (optimization_hand.py:252-268) -----------------------
+__device__ __forceinline__ float div_floor(float a, float b) {  // c10::div_floor_floating: torch's `tensor // scalar`
+    const float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if (mod != 0.0f && ((b < 0.0f) != (mod < 0.0f))) div -= 1.0f;
+    float fl;
+    if (div != 0.0f) {
+        fl = floorf(div);
+        if (div - fl > 0.5f) fl += 1.0f;
+    } else {
+        fl = copysignf(0.0f, a / b);
+    }
+    return fl;
+}
+
+template <bool F16>
+__global__ void __launch_bounds__(256)
+sdf_nearest_kernel(int n, const float *__restrict__ hand, const float *__restrict__ obj_r, const float *__restrict__ obj_t,
+                   const void *__restrict__ vol, int res, float voxel_scale, int *__restrict__ out_idx,
+                   void *__restrict__ out_sdf, void *__restrict__ out_pen) {
+    __shared__ float sm[4];
+    const int b = blockIdx.x;
+    float R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = obj_r[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = obj_t[k];
+    const int half = res / 2;
+    const float fh = (float)half;
+    float pen = 0.0f;
+    constexpr int U = 4;
+    for (int j0 = threadIdx.x; j0 < n; j0 += 256 * U) {
+        int flat[U];
+        float v[U];
+        __half h[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t e = (size_t)b * n + min(j0 + 256 * u, n - 1);
+            float ox, oy, oz;
+            to_object_frame(hand[3 * e], hand[3 * e + 1], hand[3 * e + 2], t, R, ox, oy, oz);
+            const int ix = (int)clampf(div_floor(ox, voxel_scale), -fh, fh) + half;
+            const int iy = (int)clampf(div_floor(oy, voxel_scale), -fh, fh) + half;
+            const int iz = (int)clampf(div_floor(oz, voxel_scale), -fh, fh) + half;
+            flat[u] = (ix * res + iy) * res + iz;
+            if constexpr (F16) h[u] = reinterpret_cast<const __half *>(vol)[flat[u]];
+            else v[u] = reinterpret_cast<const float *>(vol)[flat[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j0 + 256 * u >= n) continue;
+            const size_t e = (size_t)b * n + j0 + 256 * u;
+            if (out_idx) out_idx[e] = flat[u];
+            if constexpr (F16) {
+                if (out_sdf) reinterpret_cast<__half *>(out_sdf)[e] = h[u];
+                v[u] = __half2float(h[u]);
+            } else {
+                if (out_sdf) reinterpret_cast<float *>(out_sdf)[e] = v[u];
+            }
+            if (v[u] < 0.0f) pen = fmaxf(pen, -v[u]);
+        }
+    }
+    if (!out_pen) return;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) pen = fmaxf(pen, __shfl_down(pen, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = pen;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        if constexpr (F16) reinterpret_cast<__half *>(out_pen)[b] = __float2half(m);  // exact: m is a half value
+        else reinterpret_cast<float *>(out_pen)[b] = m;
+    }
+}
+
+inline bool vol_args_ok(int res, float stride) { return res >= 2 && res <= 1024 && stride > 0.0f; }
+
+}  // namespace pn2
+
+using namespace pn2;
+
+extern "C" int pn2s_trilinear(int m, const float *V, const void *vol, int vol_f16, int res, float bbox_min, float stride,
+                              float clamp_lo, float clamp_hi, float *out, void *stream) {
+    if (m < 0 || !vol_args_ok(res, stride)) return PN2_EINVAL;
+    if (m == 0) return PN2_OK;
+    if (!V || !vol || !out) return PN2_ENULL;
+    const SdfVol A{vol, res, bbox_min, stride, clamp_lo, clamp_hi};
+    const unsigned blocks = (unsigned)min((m + 255) / 256, 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (vol_f16) hipLaunchKernelGGL(sdf_trilinear_kernel<true>, dim3(blocks), dim3(256), 0, st, m, V, A, out);
+    else hipLaunchKernelGGL(sdf_trilinear_kernel<false>, dim3(blocks), dim3(256), 0, st, m, V, A, out);
+    return check_launch();
+}
+
+extern "C" int pn2s_particle_energy(int p, int n, const float *pcld, const float *rot, const float *trans, const void *vol,
+                                    int vol_f16, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi,
+                                    float *sdf_energy, void *stream) {
+    if (p < 0 || n < 1 || !vol_args_ok(res, stride)) return PN2_EINVAL;
+    if (p == 0) return PN2_OK;
+    if (!pcld || !rot || !trans || !vol || !sdf_energy) return PN2_ENULL;
+    const SdfVol A{vol, res, bbox_min, stride, clamp_lo, clamp_hi};
+    hipStream_t st = (hipStream_t)stream;
+    if (vol_f16) hipLaunchKernelGGL(sdf_particle_energy_kernel<true>, dim3(p), dim3(256), 0, st, n, pcld, rot, trans, A, sdf_energy);
+    else hipLaunchKernelGGL(sdf_particle_energy_kernel<false>, dim3(p), dim3(256), 0, st, n, pcld, rot, trans, A, sdf_energy);
+    return check_launch();
+}
+
+extern "C" int pn2s_obj_optimize_work_floats(int p) { return p < 0 ? PN2_EINVAL : W_ENERGY + p; }
+
+extern "C" int pn2s_obj_optimize(int p, int n, int iterations, const float *pcld, const float *pre_sampled, const void *vol,
+                                 int vol_f16, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi, float c1,
+                                 float c2, float beta, float *pose, float *work, void *stream) {
+    if (p < 1 || n < 1 || iterations < 0 || !vol_args_ok(res, stride)) return PN2_EINVAL;
+    if (!pcld || !pre_sampled || !vol || !pose || !work) return PN2_ENULL;
+    OptArgs A;
+    A.p = p; A.n = n; A.pcld = pcld; A.pre = pre_sampled;
+    A.V = SdfVol{vol, res, bbox_min, stride, clamp_lo, clamp_hi};
+    A.c2 = c2; A.beta = beta;
+    // the reference mixes a Python double scalar into fp32 tensors here (:295): (1-beta) is rounded to fp32 when it
+    // multiplies a tensor, but (1-beta)*c1 is a double product rounded once while prev_search_size is still c1
+    A.one_minus_beta = (float)(1.0 - (double)beta);
+    A.carry0 = (float)((1.0 - (double)beta) * (double)c1);
+    A.pose = pose; A.work = work;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(opt_init_kernel, dim3(1), dim3(64), 0, st, work, c1);
+    for (int it = 0; it < iterations; ++it) {
+        if (vol_f16) hipLaunchKernelGGL(obj_optimize_kernel<true>, dim3(p), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(obj_optimize_kernel<false>, dim3(p), dim3(256), 0, st, A);
+    }
+    return check_launch();
+}
+
+extern "C" int pn2s_nearest(int b, int n, const float *hand, const float *obj_r, const float *obj_t, const void *vol,
+                            int vol_f16, int res, float voxel_scale, int *out_idx, void *out_sdf, void *out_pen, void *stream) {
+    if (b < 0 || n < 1 || res < 1 || res > 1024 || (res & 1) == 0 || !(voxel_scale > 0.0f)) return PN2_EINVAL;
+    if (b == 0) return PN2_OK;
+    if (!hand || !obj_r || !obj_t || !vol) return PN2_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (vol_f16) hipLaunchKernelGGL(sdf_nearest_kernel<true>, dim3(b), dim3(256), 0, st, n, hand, obj_r, obj_t, vol, res, voxel_scale, out_idx, out_sdf, out_pen);
+    else hipLaunchKernelGGL(sdf_nearest_kernel<false>, dim3(b), dim3(256), 0, st, n, hand, obj_r, obj_t, vol, res, voxel_scale, out_idx, out_sdf, out_pen);
+    return check_launch();
+}

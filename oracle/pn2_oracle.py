@@ -22,8 +22,8 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 
 def build(force: bool = False) -> str:
     """Compile the C restatement with gcc (seconds).  Returns the .so path."""
-    src = os.path.join(_HERE, "pn2_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("pn2_oracle.c", "sdf_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpn2_oracle.so"])
     return _SO
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(pn2x?_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(pn2[xs]?_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_headers_declare_the_reference_surface():
@@ -25,7 +25,7 @@ def test_headers_declare_the_reference_surface():
 
 def test_library_exports_every_declared_symbol(hip_lib_path):
     lib = ctypes.CDLL(hip_lib_path)
-    for header in ("pn2_hip.h", "pn2_ext.h"):
+    for header in ("pn2_hip.h", "pn2_ext.h", "pn2_sdf.h"):
         for name in _declared(header):
             assert hasattr(lib, name), f"{name} declared in {header} but not exported"
     lib.pn2_abi_version.restype = ctypes.c_int
@@ -49,6 +49,13 @@ def test_argument_validation_without_gpu(hip_lib_path):
     assert lib.pn2_ball_query(1, 16, 4, 0.1, 0, None, None, None, None) == -1       # nsample < 1
     lib.pn2_group_points.argtypes = [ctypes.c_int] * 5 + [vp] * 4
     assert lib.pn2_group_points(2, 0, 16, 4, 4, None, None, None, None) == 0        # C == 0 is legal (sa1)
+    cf, ci = ctypes.c_float, ctypes.c_int
+    lib.pn2s_nearest.argtypes = [ci, ci, vp, vp, vp, vp, ci, ci, cf, vp, vp, vp, vp]
+    assert lib.pn2s_nearest(4, 8, None, None, None, None, 1, 150, 0.003, None, None, None, None) == -1   # even res
+    assert lib.pn2s_nearest(4, 8, None, None, None, None, 1, 151, 0.003, None, None, None, None) == -2   # NULL pointers
+    lib.pn2s_trilinear.argtypes = [ci, vp, vp, ci, ci, cf, cf, cf, cf, vp, vp]
+    assert lib.pn2s_trilinear(8, None, None, 1, 201, -0.2, 0.0, -0.05, 0.05, None, None) == -1           # stride <= 0
+    assert lib.pn2s_trilinear(0, None, None, 1, 201, -0.2, 0.002, -0.05, 0.05, None, None) == 0          # empty is a no-op
 
 
 def test_python_boundary_exports_reference_names():
