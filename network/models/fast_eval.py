@@ -60,7 +60,9 @@ class FastEval:
         key = self._versions()
         if not force and self._key == key:
             return self.P
+        from hotrack_amd import gemm_tuning
         from hotrack_amd.fused import fold_conv_bn as fold
+        gemm_tuning.enable()  # gfx950 solution table for the library GEMMs below (no-op if absent / disabled)
         net, bh = self.net, self.net.bhand
         P = {}
 

@@ -91,3 +91,13 @@ def test_product_code_never_imports_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "pn2_oracle" in txt:
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_tuned_gemm_table_is_well_formed():
+    from hotrack_amd import gemm_tuning
+    rows = [l.strip().split(",") for l in open(gemm_tuning.RESULTS) if l.strip()]
+    assert any(r[0] == "Validator" and r[1] == "GCN_ARCH_NAME" and r[2].startswith("gfx950") for r in rows)
+    ops = [r for r in rows if r[0] != "Validator"]
+    assert len(ops) > 50 and all(len(r) >= 3 and r[0].startswith("Gemm") for r in ops)
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable() is False  # no GPU: nothing is touched

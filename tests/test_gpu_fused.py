@@ -198,3 +198,15 @@ def test_network_with_fused_backend_matches_reference_golden():
         pointnet_utils.set_fused_backend(None)
     np.testing.assert_allclose(ret["pred_kp"].cpu().numpy(), gold["eval_pred_kp"], atol=2e-4)
     np.testing.assert_allclose(ret["pred_kp_handframe"].cpu().numpy(), gold["eval_pred_kp_handframe"], atol=2e-4)
+
+
+def test_tuned_gemm_table_loads():
+    """hotrack_amd/tunableop_gfx950.csv was recorded for this image / GPU: TunableOp must accept it (validators match)."""
+    import os
+    if os.environ.get("PN2_TUNED_GEMMS", "1") == "0":
+        pytest.skip("tuned table disabled by PN2_TUNED_GEMMS=0")
+    import torch.cuda.tunable as tunable
+    from hotrack_amd import gemm_tuning
+    assert gemm_tuning.enable() is True
+    assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+    assert len(tunable.get_results()) > 50
