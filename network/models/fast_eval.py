@@ -37,6 +37,7 @@ class FastEval:
         self._key = None
         self.P = None
         self._consts = {}
+        self._idents = {}
 
     def _palm_idx(self, device):
         key = ("palm", str(device))
@@ -93,12 +94,30 @@ class FastEval:
                 q[(name, i)] = dict(wx=W1[:, C:C + 3].contiguous(), b1=b1, l2=l2, l3=l3, K=mod.nsample_list[i],
                                     wc=W1[:, C + 3:] if W1.shape[1] > C + 3 else None)
         P["q"] = q
-        P["wq"] = torch.cat(wq, dim=0).contiguous()  # (4*128, C): all four per-point layer-1 GEMMs at once
+        # Layer 1 of a keypoint branch is linear in the per-point feature, so it is a GEMM over POINTS for branches
+        # whose J*K neighbour slots outnumber the points (K = 64: 1344 slots > 1024 points) and a GEMM over the
+        # GATHERED slots for the small ones (K = 16: 336 rows instead of 1024).  Branch order inside each block:
+        # (q1, i), (q2, i) for the i's of that kind.
+        P["wq"] = wq  # per branch, order q1s0, q1s1, q2s0, q2s1
         P["wc2"] = torch.cat([q[("q2", 0)]["wc"], q[("q2", 1)]["wc"]], dim=0).contiguous()  # (2*128, C)
         P["r1"] = (net.r1.linear.weight.detach().squeeze(-1), net.r1.linear.bias.detach(), net.r1._perm.t().contiguous())
         P["r2"] = (net.r2.linear.weight.detach().squeeze(-1), net.r2.linear.bias.detach(), net.r2._perm.t().contiguous())
         self.P, self._key = P, key
         return P
+
+    def _wcat(self, i):
+        """Cache of the per-scale layer-1 feature weights [q1 scale i | q2 scale i] (lives in P: rebuilt with the parameters)."""
+        c = self.P.setdefault("_wcat", {})
+        if i not in c:
+            c[i] = torch.cat([self.P["wq"][i], self.P["wq"][2 + i]], dim=0).contiguous()
+        return c[i]
+
+    def _ident(self, B, J, K, dev):
+        """(B, J, K) int32 identity neighbour index for slot-major gathered rows (row j*K + k of each cloud)."""
+        key = (B, J, K, str(dev))
+        if key not in self._idents:
+            self._idents[key] = torch.arange(J * K, dtype=torch.int32, device=dev).view(1, J, K).expand(B, J, K).contiguous()
+        return self._idents[key]
 
     # ------------------------------------------------------------------------------------
     @staticmethod
@@ -200,26 +219,37 @@ class FastEval:
         C = src2.shape[1]
 
         # ---- q1 / q2: kNN (16 / 64) neighbourhoods of the 21 keypoints ------------------------------------
-        aq = F.linear(src2, P["wq"]).view(B, N, -1)  # (B,N,4*128): per-point layer-1 halves of q1s0,q1s1,q2s0,q2s1
         q = P["q"]
         # kNN lists are sorted by (distance, index): the K=16 list is the prefix of the K=64 list -> one search
         Ks = [q[("q1", i)]["K"] for i in range(2)]
         _, gi = ops.knn(max(Ks), xyz1, xyz2)
-        idxs = [gi if K == max(Ks) else gi[:, :, :K].contiguous() for K in Ks]
         c_q = q[("q1", 0)]["l3"][0].shape[0]
         c1q = q[("q1", 0)]["l2"][0].shape[1]
+        src3 = src2.view(B, N, C)
+        # per scale i: neighbour index, feature rows the layer-1 GEMM runs over, the coordinates that go with them
+        plan = []
+        for i, K in enumerate(Ks):
+            W = self._wcat(i)  # (2*c1q, C): layer-1 feature weights of q1 | q2 at this scale
+            # few slots and a batch large enough that the GEMM, not the launch count, is what costs (measured: pays from B ~ 32)
+            if J * K * 2 <= N and B * N >= 32768:  # gather the J*K feature rows, then the GEMM (slot-major rows, identity index)
+                flat = gi[:, :, :K].reshape(B, J * K)
+                a = F.linear(ext.gather_rows(src3, flat).view(B * J * K, C), W).view(B, J * K, -1)
+                plan.append((self._ident(B, J, K, dev), a, ext.gather_rows(xyz2, flat)))
+            else:
+                idx = gi if K == gi.shape[2] else gi[:, :, :K].contiguous()
+                plan.append((idx, F.linear(src2, W).view(B, N, -1), xyz2))
         f11 = torch.empty((B, J, 2 * c_q), **f32)
-        for i in range(2):
+        for i, (idx, a, nb_xyz) in enumerate(plan):
             p = q[("q1", i)]
-            ext.sa_mlp_max(idxs[i], *p["l2"], *p["l3"], a1f=aq[:, :, i * c1q:(i + 1) * c1q], xyz=xyz2, cxyz=xyz1,
+            ext.sa_mlp_max(idx, *p["l2"], *p["l3"], a1f=a[:, :, :c1q], xyz=nb_xyz, cxyz=xyz1,
                            wx=p["wx"], b1=p["b1"], out=f11[:, :, i * c_q:(i + 1) * c_q])
         Wr, br, perm = P["r1"]
         f12 = F.linear(f11[:, perm].reshape(B * J, -1), Wr, br)  # (B*J, C)
         cadd = F.linear(f12, P["wc2"]).view(B, J, -1)
         f13 = torch.empty((B, J, 2 * c_q), **f32)
-        for i in range(2):
+        for i, (idx, a, nb_xyz) in enumerate(plan):
             p = q[("q2", i)]
-            ext.sa_mlp_max(idxs[i], *p["l2"], *p["l3"], a1f=aq[:, :, (2 + i) * c1q:(3 + i) * c1q], xyz=xyz2, cxyz=xyz1,
+            ext.sa_mlp_max(idx, *p["l2"], *p["l3"], a1f=a[:, :, c1q:2 * c1q], xyz=nb_xyz, cxyz=xyz1,
                            wx=p["wx"], b1=p["b1"], cadd=cadd[:, :, i * c1q:(i + 1) * c1q], out=f13[:, :, i * c_q:(i + 1) * c_q])
         Wr, br, perm = P["r2"]
         f14 = F.linear(f13[:, perm].reshape(B * J, -1), Wr, br)
