@@ -360,7 +360,11 @@ static int launch_sa(int b, SaArgs a, hipStream_t st) {
     // persistent workgroups: weights are loaded into registers once per workgroup
     const int wg_per_cu = (int)((160 * 1024) / lds) < MINW / 2 ? (int)((160 * 1024) / lds) : MINW / 2;
     const int max_wg = 256 * (wg_per_cu < 1 ? 1 : wg_per_cu);
-    const int grid = a.num_tiles < max_wg ? a.num_tiles : max_wg;
+    // Balanced persistent grid: every workgroup runs the same number of tiles (ceil(tiles / rounds)), so the launch
+    // takes `rounds` tile-times either way but leaves the CUs a ragged last round would idle to concurrent streams
+    // (1344 tiles: 224 workgroups x 6 instead of 256 of which 64 run 6 and 192 run 5).
+    const int rounds = (a.num_tiles + max_wg - 1) / max_wg;
+    const int grid = (a.num_tiles + rounds - 1) / rounds;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a);
     return check_launch();
 }
