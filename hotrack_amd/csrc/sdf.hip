@@ -20,9 +20,9 @@ struct SdfVol {
     float bbox_min, stride, lo, hi;
 };
 
-template <bool F16>
+template <int FMT>
 __device__ __forceinline__ float vol_at(const void *v, int i) {
-    if constexpr (F16) return __half2float(reinterpret_cast<const __half *>(v)[i]);
+    if constexpr (FMT & 1) return __half2float(reinterpret_cast<const __half *>(v)[i]);
     else return reinterpret_cast<const float *>(v)[i];
 }
 
@@ -62,9 +62,9 @@ __device__ __forceinline__ TriPoint tri_setup(const SdfVol &A, float vx, float v
 // Two z-adjacent voxels (i, i+1) with ONE load: the kernel is bound by the number of divergent gather lanes the
 // texture-address path has to process, and z-neighbours are adjacent in memory (2-byte aligned only: memcpy lets
 // the compiler pick an unaligned dword load, which gfx950 global memory supports).
-template <bool F16>
+template <int FMT>
 __device__ __forceinline__ void vol_pair(const void *v, int i, float &a, float &b) {
-    if constexpr (F16) {
+    if constexpr (FMT & 1) {
         unsigned w;
         __builtin_memcpy(&w, reinterpret_cast<const __half *>(v) + i, 4);
         a = __half2float(__ushort_as_half((unsigned short)(w & 0xffffu)));
@@ -77,21 +77,39 @@ __device__ __forceinline__ void vol_pair(const void *v, int i, float &a, float &
     }
 }
 
-template <bool F16>
+template <int FMT>
 __device__ __forceinline__ void tri_gather(const SdfVol &A, const TriPoint &t, float *d) {
     const int R = A.res, RR = R * R, last = RR * R - 1, i = t.i000;
+    if constexpr (FMT >= 2) {
+        // corner layout (pn2s_build_corner_volume): cell i holds the eight values the reference would fetch for
+        // i000 == i, already clamped its way -> ONE 16-byte (fp16) or two 16-byte (fp32) loads per point
+        if constexpr (FMT == 3) {
+            const uint4 w = reinterpret_cast<const uint4 *>(A.p)[i];
+            const unsigned u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[2 * k] = __half2float(__ushort_as_half((unsigned short)(u[k] & 0xffffu)));
+                d[2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(u[k] >> 16)));
+            }
+        } else {
+            const float4 a = reinterpret_cast<const float4 *>(A.p)[2 * (size_t)i], b = reinterpret_cast<const float4 *>(A.p)[2 * (size_t)i + 1];
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+            d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        }
+        return;
+    }
     if (SDF_PAIR && i + 1 + R + RR <= last) {  // everywhere except the volume's last corner
-        vol_pair<F16>(A.p, i, d[0], d[1]);
-        vol_pair<F16>(A.p, i + R, d[2], d[3]);
-        vol_pair<F16>(A.p, i + RR, d[4], d[5]);
-        vol_pair<F16>(A.p, i + R + RR, d[6], d[7]);
+        vol_pair<FMT>(A.p, i, d[0], d[1]);
+        vol_pair<FMT>(A.p, i + R, d[2], d[3]);
+        vol_pair<FMT>(A.p, i + RR, d[4], d[5]);
+        vol_pair<FMT>(A.p, i + R + RR, d[6], d[7]);
         return;
     }
     // the reference clamps each corner index to [0, res^3 - 1] (:215-222); only the upper clamp can bind
-    d[0] = vol_at<F16>(A.p, i);                          d[1] = vol_at<F16>(A.p, min(i + 1, last));
-    d[2] = vol_at<F16>(A.p, min(i + R, last));           d[3] = vol_at<F16>(A.p, min(i + 1 + R, last));
-    d[4] = vol_at<F16>(A.p, min(i + RR, last));          d[5] = vol_at<F16>(A.p, min(i + 1 + RR, last));
-    d[6] = vol_at<F16>(A.p, min(i + R + RR, last));      d[7] = vol_at<F16>(A.p, min(i + 1 + R + RR, last));
+    d[0] = vol_at<FMT>(A.p, i);                          d[1] = vol_at<FMT>(A.p, min(i + 1, last));
+    d[2] = vol_at<FMT>(A.p, min(i + R, last));           d[3] = vol_at<FMT>(A.p, min(i + 1 + R, last));
+    d[4] = vol_at<FMT>(A.p, min(i + RR, last));          d[5] = vol_at<FMT>(A.p, min(i + 1 + RR, last));
+    d[6] = vol_at<FMT>(A.p, min(i + R + RR, last));      d[7] = vol_at<FMT>(A.p, min(i + 1 + R + RR, last));
 }
 
 __device__ __forceinline__ float tri_blend(const SdfVol &A, const TriPoint &t, const float *d) {
@@ -101,11 +119,11 @@ __device__ __forceinline__ float tri_blend(const SdfVol &A, const TriPoint &t, c
     return clampf(lo + hi, A.lo, A.hi);
 }
 
-template <bool F16>
+template <int FMT>
 __device__ __forceinline__ float trilinear(const SdfVol &A, float vx, float vy, float vz) {
     const TriPoint t = tri_setup(A, vx, vy, vz);
     float d[8];
-    tri_gather<F16>(A, t, d);
+    tri_gather<FMT>(A, t, d);
     return tri_blend(A, t, d);
 }
 
@@ -128,14 +146,14 @@ __device__ __forceinline__ float block_sum_256(float v, float *sm) {  // sm: >= 
     return r;
 }
 
-template <bool F16>
+template <int FMT>
 __global__ void __launch_bounds__(256) sdf_trilinear_kernel(int m, const float *__restrict__ V, SdfVol A, float *__restrict__ out) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256)
-        out[i] = trilinear<F16>(A, V[3 * i], V[3 * i + 1], V[3 * i + 2]);
+        out[i] = trilinear<FMT>(A, V[3 * i], V[3 * i + 1], V[3 * i + 2]);
 }
 
 // mean_j |Distance((pcld_j - t) @ R)| for the calling block's particle; every thread returns the value.
-template <bool F16>
+template <int FMT>
 __device__ __forceinline__ float particle_sdf_energy(int n, const float *__restrict__ pcld, const float *R, const float *t,
                                                      const SdfVol &A, float *sm) {
     constexpr int U = SDF_U;  // points per thread whose gathers are all issued before any blend
@@ -149,7 +167,7 @@ __device__ __forceinline__ float particle_sdf_energy(int n, const float *__restr
             float ox, oy, oz;
             to_object_frame(pcld[3 * j], pcld[3 * j + 1], pcld[3 * j + 2], t, R, ox, oy, oz);
             tp[u] = tri_setup(A, ox, oy, oz);
-            tri_gather<F16>(A, tp[u], d[u]);
+            tri_gather<FMT>(A, tp[u], d[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -160,7 +178,7 @@ __device__ __forceinline__ float particle_sdf_energy(int n, const float *__restr
     return block_sum_256(acc, sm) / (float)n;
 }
 
-template <bool F16>
+template <int FMT>
 __global__ void __launch_bounds__(256)
 sdf_particle_energy_kernel(int n, const float *__restrict__ pcld, const float *__restrict__ rot, const float *__restrict__ trans,
                            SdfVol A, float *__restrict__ sdf_energy) {
@@ -171,7 +189,7 @@ sdf_particle_energy_kernel(int n, const float *__restrict__ pcld, const float *_
     for (int k = 0; k < 9; ++k) R[k] = rot[9 * i + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) t[k] = trans[3 * i + k];
-    const float e = particle_sdf_energy<F16>(n, pcld, R, t, A, sm);
+    const float e = particle_sdf_energy<FMT>(n, pcld, R, t, A, sm);
     if (threadIdx.x == 0) sdf_energy[i] = e;
 }
 
@@ -227,7 +245,7 @@ __global__ void opt_init_kernel(float *work, float c1) {
     if (t == 14) reinterpret_cast<unsigned *>(work)[W_TICKET] = 0u;
 }
 
-template <bool F16>
+template <int FMT>
 __global__ void __launch_bounds__(256) obj_optimize_kernel(const OptArgs A) {
     __shared__ float sm[4];
     __shared__ float red[9 * 4 + 4];
@@ -250,7 +268,7 @@ __global__ void __launch_bounds__(256) obj_optimize_kernel(const OptArgs A) {
         mat3_mul(R0, S, R);  // :263
 #pragma unroll
         for (int k = 0; k < 3; ++k) t[k] = t0[k] + s[4 + k];  // :264
-        const float e = particle_sdf_energy<F16>(A.n, A.pcld, R, t, A.V, sm);
+        const float e = particle_sdf_energy<FMT>(A.n, A.pcld, R, t, A.V, sm);
         // agent-scope (write-through) store: visible to every XCD without an L2 write-back
         if (tid == 0) __hip_atomic_store(&energy[i], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -274,18 +292,34 @@ __global__ void __launch_bounds__(256) obj_optimize_kernel(const OptArgs A) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0f;
     int any = 0;
-    for (int q = tid; q < A.p; q += 256) {
-        const float se = __hip_atomic_load(&energy[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float en = se * 500.0f;
-        const bool better = en < origin;  // :271
-        const float w = better ? origin - en : 0.0f;
-        any |= better;
-        float s[7];
-        particle_sample(A.pre, q, search, s);
-        acc[0] += w;
-        acc[1] += se * w;
+    // one workgroup walks all p energies: issue 8 independent loads per thread before using any (a dependent
+    // load-use chain per particle made this tail ~15 us of a ~40 us iteration)
+    constexpr int UQ = 8;
+    for (int q0 = tid; q0 < A.p; q0 += 256 * UQ) {
+        float se[UQ], pr[UQ][6];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc[2 + k] += s[k] * w;
+        for (int u = 0; u < UQ; ++u) {
+            const int q = min(q0 + 256 * u, A.p - 1);
+            se[u] = __hip_atomic_load(&energy[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pr[u][k] = A.pre[6 * q + k];
+        }
+#pragma unroll
+        for (int u = 0; u < UQ; ++u) {
+            if (q0 + 256 * u >= A.p) continue;
+            const float en = se[u] * 500.0f;
+            const bool better = en < origin;  // :271
+            const float w = better ? origin - en : 0.0f;
+            any |= better;
+            float s[7];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s[1 + k] = pr[u][k] * search[k];  // == particle_sample
+            s[0] = sqrtf(1.0f - s[1] * s[1] - s[2] * s[2] - s[3] * s[3]);
+            acc[0] += w;
+            acc[1] += se[u] * w;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) acc[2 + k] += s[k] * w;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -430,44 +464,89 @@ sdf_nearest_kernel(int n, const float *__restrict__ hand, const float *__restric
     }
 }
 
+// Corner layout: cell i = the eight corner values the reference's Distance() fetches when i000 == i, with ITS index
+// arithmetic (flat +1 / +R / +R^2 offsets, each clamped to the last element, optimization_obj.py:206-222), so a
+// lookup through this layout is bit-identical to one through the linear volume for every input.
+template <bool F16>
+__global__ void __launch_bounds__(256) corner_volume_kernel(const void *__restrict__ vol, int res, void *__restrict__ out) {
+    const int R = res, RR = R * R, last = RR * R - 1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i <= last; i += gridDim.x * 256) {
+        const int id[8] = {i, min(i + 1, last), min(i + R, last), min(i + 1 + R, last),
+                           min(i + RR, last), min(i + 1 + RR, last), min(i + R + RR, last), min(i + 1 + R + RR, last)};
+        if constexpr (F16) {
+            const unsigned short *v = reinterpret_cast<const unsigned short *>(vol);
+            uint4 w;
+            w.x = v[id[0]] | ((unsigned)v[id[1]] << 16);
+            w.y = v[id[2]] | ((unsigned)v[id[3]] << 16);
+            w.z = v[id[4]] | ((unsigned)v[id[5]] << 16);
+            w.w = v[id[6]] | ((unsigned)v[id[7]] << 16);
+            reinterpret_cast<uint4 *>(out)[i] = w;
+        } else {
+            const float *v = reinterpret_cast<const float *>(vol);
+            reinterpret_cast<float4 *>(out)[2 * (size_t)i] = make_float4(v[id[0]], v[id[1]], v[id[2]], v[id[3]]);
+            reinterpret_cast<float4 *>(out)[2 * (size_t)i + 1] = make_float4(v[id[4]], v[id[5]], v[id[6]], v[id[7]]);
+        }
+    }
+}
+
 inline bool vol_args_ok(int res, float stride) { return res >= 2 && res <= 1024 && stride > 0.0f; }
 
 }  // namespace pn2
 
 using namespace pn2;
 
-extern "C" int pn2s_trilinear(int m, const float *V, const void *vol, int vol_f16, int res, float bbox_min, float stride,
+#define SDF_FMT_DISPATCH(fmt, CALL)                   \
+    switch (fmt) {                                    \
+        case 0: { constexpr int FMT = 0; CALL; } break; \
+        case 1: { constexpr int FMT = 1; CALL; } break; \
+        case 2: { constexpr int FMT = 2; CALL; } break; \
+        case 3: { constexpr int FMT = 3; CALL; } break; \
+        default: return PN2_EINVAL;                   \
+    }
+
+extern "C" long pn2s_corner_volume_elems(int res) { return (res < 2 || res > 1024) ? (long)PN2_EINVAL : 8L * res * res * res; }
+
+extern "C" int pn2s_build_corner_volume(const void *vol, int vol_f16, int res, void *out, void *stream) {
+    if (res < 2 || res > 1024 || (vol_f16 != 0 && vol_f16 != 1)) return PN2_EINVAL;
+    if (!vol || !out) return PN2_ENULL;
+    const long cells = (long)res * res * res;
+    const unsigned blocks = (unsigned)min((cells + 255) / 256, 65536L);
+    hipStream_t st = (hipStream_t)stream;
+    if (vol_f16) hipLaunchKernelGGL(corner_volume_kernel<true>, dim3(blocks), dim3(256), 0, st, vol, res, out);
+    else hipLaunchKernelGGL(corner_volume_kernel<false>, dim3(blocks), dim3(256), 0, st, vol, res, out);
+    return check_launch();
+}
+
+extern "C" int pn2s_trilinear(int m, const float *V, const void *vol, int vol_fmt, int res, float bbox_min, float stride,
                               float clamp_lo, float clamp_hi, float *out, void *stream) {
     if (m < 0 || !vol_args_ok(res, stride)) return PN2_EINVAL;
-    if (m == 0) return PN2_OK;
+    if (m == 0) return (vol_fmt < 0 || vol_fmt > 3) ? PN2_EINVAL : PN2_OK;
     if (!V || !vol || !out) return PN2_ENULL;
     const SdfVol A{vol, res, bbox_min, stride, clamp_lo, clamp_hi};
     const unsigned blocks = (unsigned)min((m + 255) / 256, 16384);
     hipStream_t st = (hipStream_t)stream;
-    if (vol_f16) hipLaunchKernelGGL(sdf_trilinear_kernel<true>, dim3(blocks), dim3(256), 0, st, m, V, A, out);
-    else hipLaunchKernelGGL(sdf_trilinear_kernel<false>, dim3(blocks), dim3(256), 0, st, m, V, A, out);
+    SDF_FMT_DISPATCH(vol_fmt, hipLaunchKernelGGL(sdf_trilinear_kernel<FMT>, dim3(blocks), dim3(256), 0, st, m, V, A, out))
     return check_launch();
 }
 
 extern "C" int pn2s_particle_energy(int p, int n, const float *pcld, const float *rot, const float *trans, const void *vol,
-                                    int vol_f16, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi,
+                                    int vol_fmt, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi,
                                     float *sdf_energy, void *stream) {
     if (p < 0 || n < 1 || !vol_args_ok(res, stride)) return PN2_EINVAL;
-    if (p == 0) return PN2_OK;
+    if (p == 0) return (vol_fmt < 0 || vol_fmt > 3) ? PN2_EINVAL : PN2_OK;
     if (!pcld || !rot || !trans || !vol || !sdf_energy) return PN2_ENULL;
     const SdfVol A{vol, res, bbox_min, stride, clamp_lo, clamp_hi};
     hipStream_t st = (hipStream_t)stream;
-    if (vol_f16) hipLaunchKernelGGL(sdf_particle_energy_kernel<true>, dim3(p), dim3(256), 0, st, n, pcld, rot, trans, A, sdf_energy);
-    else hipLaunchKernelGGL(sdf_particle_energy_kernel<false>, dim3(p), dim3(256), 0, st, n, pcld, rot, trans, A, sdf_energy);
+    SDF_FMT_DISPATCH(vol_fmt, hipLaunchKernelGGL(sdf_particle_energy_kernel<FMT>, dim3(p), dim3(256), 0, st, n, pcld, rot, trans, A, sdf_energy))
     return check_launch();
 }
 
 extern "C" int pn2s_obj_optimize_work_floats(int p) { return p < 0 ? PN2_EINVAL : W_ENERGY + p; }
 
 extern "C" int pn2s_obj_optimize(int p, int n, int iterations, const float *pcld, const float *pre_sampled, const void *vol,
-                                 int vol_f16, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi, float c1,
+                                 int vol_fmt, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi, float c1,
                                  float c2, float beta, float *pose, float *work, void *stream) {
-    if (p < 1 || n < 1 || iterations < 0 || !vol_args_ok(res, stride)) return PN2_EINVAL;
+    if (p < 1 || n < 1 || iterations < 0 || !vol_args_ok(res, stride) || vol_fmt < 0 || vol_fmt > 3) return PN2_EINVAL;
     if (!pcld || !pre_sampled || !vol || !pose || !work) return PN2_ENULL;
     OptArgs A;
     A.p = p; A.n = n; A.pcld = pcld; A.pre = pre_sampled;
@@ -481,8 +560,7 @@ extern "C" int pn2s_obj_optimize(int p, int n, int iterations, const float *pcld
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(opt_init_kernel, dim3(1), dim3(64), 0, st, work, c1);
     for (int it = 0; it < iterations; ++it) {
-        if (vol_f16) hipLaunchKernelGGL(obj_optimize_kernel<true>, dim3(p), dim3(256), 0, st, A);
-        else hipLaunchKernelGGL(obj_optimize_kernel<false>, dim3(p), dim3(256), 0, st, A);
+        SDF_FMT_DISPATCH(vol_fmt, hipLaunchKernelGGL(obj_optimize_kernel<FMT>, dim3(p), dim3(256), 0, st, A))
     }
     return check_launch();
 }

@@ -25,12 +25,40 @@ _lib.pn2s_nearest.argtypes = [_ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _cf, _vp, 
 for _n in ("pn2s_trilinear", "pn2s_particle_energy", "pn2s_obj_optimize", "pn2s_obj_optimize_work_floats", "pn2s_nearest"):
     getattr(_lib, _n).restype = _ci
 
+_lib.pn2s_build_corner_volume.argtypes = [_vp, _ci, _ci, _vp, _vp]
+_lib.pn2s_build_corner_volume.restype = _ci
+_lib.pn2s_corner_volume_elems.argtypes = [_ci]
+_lib.pn2s_corner_volume_elems.restype = ctypes.c_long
+
 BBOX_MIN = -0.2  # optimization_obj.py:186
 CLAMP = (-0.05, 0.05)  # optimization_obj.py:227
 _f32 = torch.float32
 
 
-def _volume(vol: torch.Tensor):
+class CornerVolume:
+    """Corner-layout copy of an SDF volume for the trilinear entries (include/pn2_sdf.h: pn2s_build_corner_volume):
+    cell i holds the eight corner values Distance() fetches for base index i, so a lookup is one 16-byte load.
+    Bit-identical results, ~3x faster lookups, 8x the memory; build once per object and pass it wherever a
+    `sdf_volume` is accepted by distance / particle_energy / obj_optimize."""
+
+    def __init__(self, sdf_volume: torch.Tensor):
+        pv, f16, res = _linear_volume(sdf_volume)
+        self.res, self.f16, self.source = res, f16, sdf_volume
+        self.data = torch.empty((res ** 3, 8), dtype=sdf_volume.dtype, device=sdf_volume.device)
+        assert _lib.pn2s_corner_volume_elems(res) == self.data.numel()
+        with torch.cuda.device(sdf_volume.device):
+            rc = _lib.pn2s_build_corner_volume(pv, f16, res, self.data.data_ptr(), _native._stream(sdf_volume))
+        _native._check(rc, "sdf.CornerVolume")
+
+
+def _volume(vol):
+    """-> (device pointer, vol_fmt, res) for a linear volume tensor or a CornerVolume."""
+    if isinstance(vol, CornerVolume):
+        return vol.data.data_ptr(), 2 + vol.f16, vol.res
+    return _linear_volume(vol)
+
+
+def _linear_volume(vol: torch.Tensor):
     """Validate an SDF volume: (res,res,res) or flat res^3, fp16 or fp32, contiguous, on the GPU."""
     if not isinstance(vol, torch.Tensor) or not vol.is_cuda:
         raise RuntimeError("sdf volume must be a GPU (HIP) tensor -- hotrack_amd has no CPU path")
@@ -111,7 +139,7 @@ def query_sdf(hand: torch.Tensor, obj_r: torch.Tensor, obj_t: torch.Tensor, sdf_
               with_penetration: bool = False, with_index: bool = False):
     """Nearest-voxel SDF of hand (B,N,3) in the object frame (== gf_optimize_hand_pose.query_sdf), dtype of the
     volume.  with_penetration: also the fused get_penetration_loss (B,).  with_index: also the flat voxel index."""
-    pv, f16, res = _volume(sdf_volume)
+    pv, f16, res = _linear_volume(sdf_volume)
     if hand.dim() != 3 or hand.shape[2] != 3:
         raise ValueError(f"hand must be (B,N,3), got {tuple(hand.shape)}")
     hand = hand.contiguous()

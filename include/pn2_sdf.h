@@ -15,7 +15,9 @@
  * asynchronous on `stream` (hipStream_t as void*, NULL = default stream), returns PN2_OK or a negative PN2_E*
  * code (pn2_strerror), nothing is retained after return.  Volumes: res^3 elements, element (ix,iy,iz) at
  * (ix*res + iy)*res + iz, IEEE binary16 (`vol_f16` = 1, the reference's storage type) or fp32 (`vol_f16` = 0, the
- * type the reference's volume has after `update_shape`, optimization_obj.py:400).  Arithmetic is fp32 and follows
+ * type the reference's volume has after `update_shape`, optimization_obj.py:400).  The trilinear entries take a
+ * `vol_fmt` instead: 0 / 1 = that linear layout in fp32 / fp16, 2 / 3 = the CORNER layout built from it by
+ * pn2s_build_corner_volume (fp32 / fp16), which they read ~3x faster.  Arithmetic is fp32 and follows
  * the reference's torch expressions operation for operation (true division, same association); the 3x3
  * transforms use the fixed chain  o_j = fma(q2, R2j, fma(q1, R1j, q0*R0j)).
  */
@@ -29,12 +31,23 @@ extern "C" {
 #endif
 
 /*
+ * Corner layout for the trilinear entries ("memory laid out for the lookup"): cell i (16 bytes in fp16, 32 in fp32)
+ * holds the eight corner values d000..d111 that Distance() fetches when its base index i000 == i, gathered with the
+ * reference's own index arithmetic and clamps (optimization_obj.py:206-222).  A lookup becomes ONE aligned 16-byte
+ * load per point instead of eight scattered 2-byte reads in four cache lines, and is bit-identical to a lookup in
+ * the linear volume for every input.  8x the memory (201^3 fp16: 130 MB of 288 GB), built once per object.
+ *   out: pn2s_corner_volume_elems(res) elements of the volume's type (= 8 * res^3), 16-byte aligned.
+ */
+long pn2s_corner_volume_elems(int res);
+int pn2s_build_corner_volume(const void *vol, int vol_f16, int res, void *out, void *stream);
+
+/*
  * Distance(V)  (optimization_obj.py:184-228): trilinear SDF at m points.
  *   V (m,3) object-frame coordinates; out (m).  x = clamp((v - bbox_min)/stride, 0, res-1) per axis, the eight
  *   corner indices clamped to [0, res^3-1] exactly as the reference does, result clamped to [clamp_lo, clamp_hi]
  *   (reference constants: bbox_min -0.2, clamps -0.05 / 0.05).
  */
-int pn2s_trilinear(int m, const float *V, const void *vol, int vol_f16, int res, float bbox_min, float stride,
+int pn2s_trilinear(int m, const float *V, const void *vol, int vol_fmt, int res, float bbox_min, float stride,
                    float clamp_lo, float clamp_hi, float *out, void *stream);
 
 /*
@@ -44,7 +57,7 @@ int pn2s_trilinear(int m, const float *V, const void *vol, int vol_f16, int res,
  * 500 * sdf_energy (left to the caller).
  */
 int pn2s_particle_energy(int p, int n, const float *pcld, const float *rot, const float *trans, const void *vol,
-                         int vol_f16, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi,
+                         int vol_fmt, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi,
                          float *sdf_energy, void *stream);
 
 /*
@@ -61,7 +74,7 @@ int pn2s_particle_energy(int p, int n, const float *pcld, const float *rot, cons
  *   c1, c2, beta: scaling_coefficient1 (0.02), scaling_coefficient2 (2), beta (0.9).
  */
 int pn2s_obj_optimize(int p, int n, int iterations, const float *pcld, const float *pre_sampled, const void *vol,
-                      int vol_f16, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi, float c1,
+                      int vol_fmt, int res, float bbox_min, float stride, float clamp_lo, float clamp_hi, float c1,
                       float c2, float beta, float *pose, float *work, void *stream);
 int pn2s_obj_optimize_work_floats(int p);
 

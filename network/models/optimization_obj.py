@@ -46,13 +46,14 @@ class gf_optimize_obj:
         if voxel_scale is not None:
             self.voxel_scale = float(voxel_scale)
         self.sdf_volume = sdf_volume.to(self.device).contiguous()
+        self._corners = _sdf.CornerVolume(self.sdf_volume)  # lookup layout (8x memory, same results), built once per object
 
     def Distance(self, V):  # noqa: N802 (reference name)
-        return _sdf.distance(V.float(), self.sdf_volume, self.voxel_scale)
+        return _sdf.distance(V.float(), self._corners, self.voxel_scale)
 
     def evaluate(self, pcld, r, t):
         """pcld (1,N,3), r (P,3,3), t (P,3,1) -> (energy, sdf_energy), each (P,)."""
-        sdf_energy = _sdf.particle_energy(pcld.float(), r.float(), t.float(), self.sdf_volume, self.voxel_scale)
+        sdf_energy = _sdf.particle_energy(pcld.float(), r.float(), t.float(), self._corners, self.voxel_scale)
         return sdf_energy * 500, sdf_energy
 
     def update_seach_size(self, tsdf, mean_transform):  # reference spelling
@@ -68,7 +69,7 @@ class gf_optimize_obj:
         need = 16 + self.pre_sampled_particle.shape[0]
         if self._work is None or self._work.numel() < need:
             self._work = torch.empty(need, dtype=torch.float32, device=self.device)
-        R, t = _sdf.obj_optimize(pcld, rotation, translation, self.pre_sampled_particle, self.sdf_volume, self.voxel_scale,
+        R, t = _sdf.obj_optimize(pcld, rotation, translation, self.pre_sampled_particle, self._corners, self.voxel_scale,
                                  iterations=self.iteration, scaling_coefficient1=self.scaling_coefficient1,
                                  scaling_coefficient2=float(self.scaling_coefficient2), beta=self.beta, work=self._work)
         return {"rotation": R, "translation": t.reshape(1, 3, 1)}

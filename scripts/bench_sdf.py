@@ -55,6 +55,10 @@ def main():
     pre[0] = 0
     dvol, dcam, drot, dtr, dpre = d(vol), d(cam), d(rot), d(tr), d(pre)
     dR0, dt0 = d(R0), d(t0)
+    t_eval_lin = gpu_time(lambda: sdf.particle_energy(dcam, drot, dtr, dvol, stride))
+    t_opt_lin = gpu_time(lambda: sdf.obj_optimize(dcam, dR0, dt0, dpre, dvol, stride), iters=20)
+    t_build = gpu_time(lambda: sdf.CornerVolume(dvol), iters=10, warm=2)
+    lin, dvol = dvol, sdf.CornerVolume(dvol)  # everything below uses the corner layout
     t_eval = gpu_time(lambda: sdf.particle_energy(dcam, drot, dtr, dvol, stride))
     t_opt = gpu_time(lambda: sdf.obj_optimize(dcam, dR0, dt0, dpre, dvol, stride), iters=20)
     # Distance() alone on what the reference passes it: the cloud in every particle's object frame, (P*N, 3)
@@ -68,6 +72,9 @@ def main():
     unfused = pairs * (3 * 4 * 4 + 3 * (4 * 8) + 3 * 8 * 3 + 8 * (8 * 3 + 8 + 2) + 15 * 12)
     out["object"] = {
         "config": f"{P} particles x {N} points, {res}^3 fp16 volume, trilinear",
+        "layout": "corner cells (16 B per voxel, one load per lookup); linear-layout figures kept beside",
+        "corner_volume_build_us": t_build * 1e6, "evaluate_linear_layout_us": t_eval_lin * 1e6,
+        "optimize_10_iterations_linear_layout_us": t_opt_lin * 1e6,
         "evaluate_us": t_eval * 1e6, "evaluate_Gpairs_per_s": pairs / t_eval / 1e9,
         "evaluate_l2_gather_GBps": pairs * 16 / t_eval / 1e9,
         "distance_only_us": t_dist * 1e6, "distance_Gpoints_per_s": pairs / t_dist / 1e9,

@@ -74,3 +74,42 @@ def test_fuzz_group_gather_interp(ops, oracle):
             g2 = rng.normal(size=(B, C, n)).astype(np.float32)
             o2.backward(dev(g2))
             np.testing.assert_allclose(f2.grad.cpu().numpy(), oracle.three_interpolate_grad(g2, i3, w, N), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_sdf_fuzz(seed):
+    """Randomised SDF-lookup cases (volume size / dtype / counts / out-of-volume queries) against the oracle."""
+    from hotrack_amd import sdf
+    from oracle import sdf_oracle as S
+    rng = np.random.default_rng(7000 + seed)
+    res = int(rng.choice([2, 3, 5, 17, 32, 41, 64]))
+    dt = np.float16 if seed % 2 == 0 else np.float32
+    stride = float(rng.choice([0.002, 0.01, 0.05, 0.2]))
+    vol = rng.uniform(-0.1, 0.1, res ** 3).astype(dt)
+    dv = torch.from_numpy(vol).cuda()
+    m = int(rng.integers(1, 3000))
+    ext = stride * res
+    V = np.concatenate([rng.uniform(-0.2 - 0.3 * ext, -0.2 + 1.3 * ext, (m, 3)),
+                        -0.2 + rng.integers(0, res, (64, 3)) * stride]).astype(np.float32)
+    got = sdf.distance(torch.from_numpy(V).cuda(), dv, stride).cpu().numpy()
+    want = S.distance(V, vol, stride)
+    assert np.array_equal(got.view(np.int32), want.view(np.int32)), (res, dt, stride)
+    # particle energy: ragged n, any P
+    n, P = int(rng.integers(1, 700)), int(rng.integers(1, 40))
+    pc = rng.uniform(-0.2, -0.2 + ext, (n, 3)).astype(np.float32)
+    q = rng.standard_normal((P, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rot = S.quat_to_matrix(q.astype(np.float32))
+    tr = rng.normal(0, 0.1 * ext, (P, 3)).astype(np.float32)
+    e = sdf.particle_energy(torch.from_numpy(pc).cuda(), torch.from_numpy(rot).cuda(), torch.from_numpy(tr).cuda(), dv, stride)
+    np.testing.assert_allclose(e.cpu().numpy(), S.particle_energy(pc, rot, tr, vol, stride), rtol=3e-6, atol=1e-9)
+    # nearest voxel (odd res only)
+    if res % 2 == 1:
+        B, N = int(rng.integers(1, 20)), int(rng.integers(1, 600))
+        hand = rng.uniform(-0.8 * ext, 0.8 * ext, (B, N, 3)).astype(np.float32)
+        R0, t0 = rot[0], tr[0]
+        qs, pen, idx = sdf.query_sdf(torch.from_numpy(hand).cuda(), torch.from_numpy(R0).cuda(), torch.from_numpy(t0).cuda(), dv, stride,
+                                     with_penetration=True, with_index=True)
+        oi, osdf, open_ = S.nearest(hand, R0, t0, vol, stride)
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.array_equal(qs.cpu().numpy().view(np.uint8), osdf.view(np.uint8))
+        assert np.array_equal(pen.cpu().numpy().view(np.uint8), open_.view(np.uint8))

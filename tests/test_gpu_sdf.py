@@ -214,3 +214,37 @@ def test_reference_class_surface(sdf):
     pen = h.get_penetration_loss(qs)
     qs2, pen2 = h.query_sdf_and_penetration(_d(q["q0_hand"]))
     assert torch.equal(qs, qs2) and torch.equal(pen, pen2)
+
+
+@pytest.mark.parametrize("dt", [np.float16, np.float32])
+def test_corner_layout_is_bit_identical(sdf, S, dt):
+    """pn2s_build_corner_volume: lookups through the corner layout == lookups through the linear volume, every bit,
+    including the reference's flat-index wrap at the top faces and the clamp at the last element."""
+    for res, stride in ((2, 0.2), (5, 0.08), (41, 0.01), (101, 0.004)):
+        rng = np.random.default_rng(res)
+        vol = rng.uniform(-0.1, 0.1, res ** 3).astype(dt)      # rough volume: any indexing slip shows
+        dv = _d(vol)
+        cv = sdf.CornerVolume(dv)
+        ext = res * stride
+        V = np.concatenate([rng.uniform(-0.2 - 0.2 * ext, -0.2 + 1.2 * ext, (50000, 3)),
+                            -0.2 + rng.integers(0, res, (4000, 3)) * stride,
+                            np.full((8, 3), -0.2 + (res - 1) * stride)]).astype(np.float32)
+        a = sdf.distance(_d(V), dv, stride).cpu().numpy()
+        b = sdf.distance(_d(V), cv, stride).cpu().numpy()
+        assert np.array_equal(a.view(np.int32), b.view(np.int32))
+        assert np.array_equal(a.view(np.int32), S.distance(V, vol, stride).view(np.int32))
+        # the cells themselves: the eight values the reference indexes for every base index
+        cells = cv.data.cpu().numpy()
+        R, last = res, res ** 3 - 1
+        i = np.arange(res ** 3)
+        for k, off in enumerate((0, 1, R, 1 + R, R * R, 1 + R * R, R + R * R, 1 + R + R * R)):
+            assert np.array_equal(cells[:, k], vol[np.minimum(i + off, last)])
+    # fused entries accept it too and agree exactly with the linear path (same arithmetic, same reduction order)
+    z = np.load(os.path.join(G, "sdf_optimize.npz"))
+    _, stride = z["o0_meta"]
+    dv = _d(z["o0_vol"].astype(dt))
+    cv = sdf.CornerVolume(dv)
+    args = (_d(z["o0_pcld"]), _d(z["o0_R_init"]), _d(z["o0_t_init"]), _d(z["o0_pre"]))
+    Ra, ta = sdf.obj_optimize(*args, dv, float(stride))
+    Rb, tb = sdf.obj_optimize(*args, cv, float(stride))
+    assert torch.equal(Ra, Rb) and torch.equal(ta, tb)
