@@ -392,18 +392,21 @@ __global__ void __launch_bounds__(256) obj_optimize_kernel(const OptArgs A) {
 }
 
 // ---- gf_optimize_hand_pose.query_sdf (+ get_penetration_loss) (optimization_hand.py:252-268) -----------------------
-__device__ __forceinline__ float div_floor(float a, float b) {  // c10::div_floor_floating: torch's `tensor // scalar`
-    const float mod = fmodf(a, b);
-    float div = (a - mod) / b;
-    if (mod != 0.0f && ((b < 0.0f) != (mod < 0.0f))) div -= 1.0f;
-    float fl;
-    if (div != 0.0f) {
-        fl = floorf(div);
-        if (div - fl > 0.5f) fl += 1.0f;
-    } else {
-        fl = copysignf(0.0f, a / b);
-    }
-    return fl;
+// torch's `tensor // scalar` on floats is c10::div_floor_floating: fmod, (a - mod) / b, sign fix-up, floor, and a
+// +1 if that floor fell below the rounding error -- for b > 0 and |a/b| < 2^22 that is exactly the mathematical
+// floor of the real quotient a/b (derivation in DESIGN.md section 8).  fmodf costs ~100 instructions and made this
+// kernel ALU-bound (39 us); the same integer comes from one correctly rounded division and one exact-sign FMA
+// remainder:  k = floor(RN(a/b));  r = fma(-k, b, a)  has the sign of the true remainder a - k*b (an FMA rounds
+// once and never rounds a non-zero value to zero, so its SIGN is exact -- its magnitude is not: a tiny negative a
+// gives r = b - tiny, which rounds to b, hence the second test looks at the sign of a - (k+1)*b instead of r >= b);
+// k is off by at most one, fixed by the two sign tests.  Beyond 2^22 both versions are far outside the clamp
+// range [-res/2, res/2] applied next, so the voxel index is identical for every finite input
+// (tests: bit-exact indices vs the literal restatement in oracle/sdf_oracle.c on adversarial k*b +- ulp inputs).
+__device__ __forceinline__ float div_floor(float a, float b) {
+    float k = floorf(a / b);
+    if (fmaf(-k, b, a) < 0.0f) k -= 1.0f;                  // a - k*b < 0: k is one too large
+    else if (fmaf(-(k + 1.0f), b, a) >= 0.0f) k += 1.0f;   // a - (k+1)*b >= 0: k is one too small
+    return k;
 }
 
 template <bool F16>

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from _sdf_cases import hand_particles, make_volume, object_points, particles, random_pose  # noqa: E402
+from _sdf_cases import hand_particles, hand_pose_particles, make_volume, object_points, particles, random_pose  # noqa: E402
 from hotrack_amd import sdf  # noqa: E402
 
 
@@ -94,15 +94,18 @@ def main():
 
     B, Nv, res, scale = 5120, 778, 151, 0.003
     vol = make_volume(res, scale, "capsule", np.float16)
-    hand = hand_particles(5, B, Nv, R0, t0, extent=0.25)
+    hand = hand_pose_particles(5, B, Nv, R0, t0)             # candidate hands: one blob, small rigid perturbations
     dvol, dhand = d(vol), d(hand)
     t_q = gpu_time(lambda: sdf.query_sdf(dhand, dR0, dt0, dvol, scale, with_penetration=True))
     t_q1 = gpu_time(lambda: sdf.query_sdf(dhand, dR0, dt0, dvol, scale))
+    dworst = d(hand_particles(5, B, Nv, R0, t0, extent=0.25))  # worst case: every vertex uniform over the whole volume
+    t_qw = gpu_time(lambda: sdf.query_sdf(dworst, dR0, dt0, dvol, scale, with_penetration=True))
     pairs = B * Nv
     alg = pairs * (12 + 2) + B * 2  # hand read once, sdf written once
     out["hand"] = {
         "config": f"{B} particles x {Nv} vertices, {res}^3 fp16 volume, nearest voxel",
-        "query_plus_penetration_us": t_q * 1e6, "query_only_us": t_q1 * 1e6, "Gpairs_per_s": pairs / t_q / 1e9,
+        "query_plus_penetration_us": t_q * 1e6, "query_only_us": t_q1 * 1e6,
+        "query_uniform_random_vertices_us": t_qw * 1e6, "Gpairs_per_s": pairs / t_q / 1e9,
         "algorithmic_bytes": alg, "hbm_GBps": alg / t_q / 1e9, "hbm_frac_of_8TBps": alg / t_q / 8e12,
     }
     if not a.no_cpu:

@@ -77,3 +77,20 @@ def hand_particles(seed, b, n, R0, t0, extent):
     rng = np.random.default_rng(seed)
     p_obj = rng.uniform(-extent, extent, (b, n, 3))
     return (p_obj @ R0.astype(np.float64).T + t0).astype(np.float32)
+
+
+def hand_pose_particles(seed, b, n, R0, t0, jitter_t=0.01, jitter_r=0.05):
+    """(b,n,3) camera-frame vertices of b candidate hands: one hand-sized blob of n vertices (16 x 8 x 4 cm ellipsoid
+    touching the object) under b small rigid perturbations -- the access pattern of the hand optimiser's particles
+    (optimization_hand.py:155-160 scales N(0,1) samples by a ~1 cm / few-degree search size)."""
+    rng = np.random.default_rng(seed)
+    u = rng.standard_normal((n, 3))
+    u = u / np.linalg.norm(u, axis=1, keepdims=True) * rng.uniform(0, 1, (n, 1)) ** (1 / 3)
+    verts = u * np.array([0.08, 0.04, 0.02]) + np.array([0.0, 0.06, 0.03])      # object frame, metres
+    out = np.empty((b, n, 3), np.float32)
+    for i in range(b):
+        dR = _axis_angle(rng.standard_normal(3), rng.normal(0, jitter_r)) if i else np.eye(3)
+        dt = rng.normal(0, jitter_t, 3) if i else np.zeros(3)
+        p_obj = verts @ dR.T + dt
+        out[i] = (p_obj @ R0.astype(np.float64).T + t0).astype(np.float32)
+    return out

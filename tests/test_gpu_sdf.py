@@ -248,3 +248,27 @@ def test_corner_layout_is_bit_identical(sdf, S, dt):
     Ra, ta = sdf.obj_optimize(*args, dv, float(stride))
     Rb, tb = sdf.obj_optimize(*args, cv, float(stride))
     assert torch.equal(Ra, Rb) and torch.equal(ta, tb)
+
+
+def test_query_sdf_voxel_boundaries_exact(sdf, S):
+    """Coordinates on and one ulp either side of every voxel face, huge and tiny values: the kernel's division-based
+    floor must give the voxel torch's fmod-based `//` gives (oracle = literal restatement of c10::div_floor_floating)."""
+    for res, scale in ((151, 0.003), (31, 0.015), (201, 0.002), (5, 0.1)):
+        half = res // 2
+        k = np.arange(-half - 3, half + 4, dtype=np.float64)
+        base = (k * np.float64(np.float32(scale))).astype(np.float32)          # nearest floats to k*b
+        alt = (k.astype(np.float32) * np.float32(scale)).astype(np.float32)    # fp32 products k*b
+        c = np.concatenate([base, np.nextafter(base, np.float32(np.inf)), np.nextafter(base, np.float32(-np.inf)),
+                            alt, np.nextafter(alt, np.float32(np.inf)), np.nextafter(alt, np.float32(-np.inf)),
+                            np.float32([0.0, -0.0, 1e-38, -1e-38, 1e-45, -1e-45, 3e4, -3e4, 1e10, -1e10, 3.0e38, -3.0e38])]).astype(np.float32)
+        rng = np.random.default_rng(res)
+        pts = np.stack([c, rng.permutation(c), rng.permutation(c)], axis=-1)[None]   # (1, M, 3), identity pose: q == hand
+        vol = rng.uniform(-0.1, 0.1, res ** 3).astype(np.float16)
+        eye, zero = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+        _, idx = sdf.query_sdf(_d(pts), _d(eye), _d(zero), _d(vol), scale, with_index=True)
+        oi, _, _ = S.nearest(pts, eye, zero, vol, scale)
+        assert np.array_equal(idx.cpu().numpy(), oi), (res, scale)
+        # and against torch's own floor division on the host
+        want = (torch.clamp(torch.from_numpy(pts[0]) // scale, -half, half).long() + half)
+        flat = (want[:, 0] * res + want[:, 1]) * res + want[:, 2]
+        assert np.array_equal(idx.cpu().numpy()[0], flat.numpy().astype(np.int32))
