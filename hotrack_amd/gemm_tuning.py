@@ -31,6 +31,7 @@ def enable() -> bool:
         return False
     tunable.enable(True)
     tunable.tuning_enable(False)
-    tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "pn2_tunableop_unused.csv"))  # never written: tuning is off
+    # TunableOp rewrites its table to this path at process exit; keep it away from the shipped file and per process
+    tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "pn2_tunableop_%d.csv" % os.getpid()))
     _state["on"] = bool(tunable.read_file(RESULTS))
     return _state["on"]
