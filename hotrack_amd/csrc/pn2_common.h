@@ -67,6 +67,23 @@ __device__ __forceinline__ float fmin_raw(float a, float b) {
     return r;
 }
 
+// fmaxf without the canonicalising v_max hipcc adds in IEEE mode: median(a, b, +inf) == max(a, b) for non-NaN inputs
+// and v_med3_f32 is a real instruction to the compiler (NOT inline asm: the hazard recogniser must see a VALU read
+// of MFMA accumulators to insert the required wait states -- an asm v_max here read half-written accumulators).
+__device__ __forceinline__ float fmax_raw(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+__device__ __forceinline__ float fmax3_raw(float a, float b, float c) { return fmax_raw(fmax_raw(a, b), c); }
+
+// max over the four 16-lane rows of a wave64 (lanes l, l^16, l^32, l^48), result in every lane: two gfx950
+// v_permlane{16,32}_swap + two v_max, no LDS crossbar round trip (ds_bpermute) and no wait.
+__device__ __forceinline__ float rows_max4(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // a[0]: rows {0,0,2,2}, a[1]: rows {1,1,3,3}
+    v = fmax_raw(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);  // b[0]: lower half twice, b[1]: upper half twice
+    return fmax_raw(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+
 __device__ __forceinline__ int f2i(float f) { return __builtin_bit_cast(int, f); }
 __device__ __forceinline__ float i2f(int i) { return __builtin_bit_cast(float, i); }
 

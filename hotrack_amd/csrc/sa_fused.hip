@@ -57,10 +57,13 @@ struct SaArgs {
 // Two s_barriers per tile keep the roles in step (H1[next] complete / H2 reusable).
 // RTC = row tiles (of 16 positions) whose accumulators are live at once (4 = fewest passes over the weight
 // registers, 2 = half the accumulator / A-fragment registers).  MINW = waves per SIMD for __launch_bounds__.
-template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1>
+// K (neighbours per centroid) is a template parameter: the max-combine / store part is then straight-line code.
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K>
 __global__ void __launch_bounds__(512, MINW)
 sa_mlp_max_kernel(const SaArgs A) {
-    const int N = A.N, S = A.S, K = A.K, lgK = A.lgK;
+    static_assert(K == 16 || K == 32 || K == 64, "K");
+    constexpr int lgK = K == 16 ? 4 : K == 32 ? 5 : 6;
+    const int N = A.N, S = A.S;
     const float *__restrict__ W2 = A.w2, *__restrict__ b2 = A.b2, *__restrict__ W3 = A.w3, *__restrict__ b3 = A.b3;
     float *__restrict__ out = A.out;
     const int num_tiles = A.num_tiles, tiles_per_cloud = A.tiles_per_cloud;
@@ -200,9 +203,15 @@ sa_mlp_max_kernel(const SaArgs A) {
     __syncthreads();
 
     // debug trace: stamp(slot) records the shader clock for (workgroup 0, lane 0 of waves 0 and 4)
+    // Compiled in only with -DSA_TRACE=1 (scripts/probes/sa_trace.py rebuilds with it): even a never-taken branch per
+    // stamp splits the tile body into separate scheduling regions and keeps epilogues from overlapping MFMAs.
     auto stamp = [&](int it, int slot) {
+#if defined(SA_TRACE) && SA_TRACE
         if (A.trace && blockIdx.x == 0 && lane == 0 && (w == 0 || w == 4) && it < 8)
             A.trace[((w >> 2) * 8 + it) * 8 + slot] = (long long)__builtin_readcyclecounter();
+#else
+        (void)it; (void)slot;
+#endif
     };
     // The two roles run SEPARATE loops (same trip count, two s_barriers per tile each), so the register
     // allocator does not have to keep the COMPUTE role's resident weights alive through the LOAD role's code.
@@ -302,31 +311,28 @@ sa_mlp_max_kernel(const SaArgs A) {
                 for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
                     for (int ct = 0; ct < NT3; ++ct)
-                        m[r0 + rt][ct] = fmaxf(fmaxf(acc[rt][ct][0], acc[rt][ct][1]), fmaxf(acc[rt][ct][2], acc[rt][ct][3]));
+                        m[r0 + rt][ct] = fmax_raw(fmax3_raw(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2]), acc[rt][ct][3]);
             }
             stamp(it, 4);
             // combine row tiles that belong to the same centroid (K = 16 -> 1, 32 -> 2, 64 -> 4 tiles)
-            if (K >= 32) {
+            if constexpr (K == 32) {
 #pragma unroll
                 for (int ct = 0; ct < NT3; ++ct) {
-                    m[0][ct] = fmaxf(m[0][ct], m[1][ct]);
-                    m[2][ct] = fmaxf(m[2][ct], m[3][ct]);
+                    m[0][ct] = fmax_raw(m[0][ct], m[1][ct]);
+                    m[2][ct] = fmax_raw(m[2][ct], m[3][ct]);
                 }
             }
-            if (K >= 64) {
+            if constexpr (K == 64) {
 #pragma unroll
-                for (int ct = 0; ct < NT3; ++ct) m[0][ct] = fmaxf(m[0][ct], m[2][ct]);
+                for (int ct = 0; ct < NT3; ++ct) m[0][ct] = fmax_raw(fmax3_raw(m[0][ct], m[1][ct], m[2][ct]), m[3][ct]);
             }
-            const int rstep = K >> 4;  // row tiles per centroid
+            constexpr int rstep = K >> 4;  // row tiles per centroid
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                if (rt % rstep != 0) continue;  // wave-uniform
+            for (int rt = 0; rt < 4; rt += rstep) {
                 const int s = ((pos0 + wp * 64) >> lgK) + rt / rstep;
 #pragma unroll
                 for (int ct = 0; ct < NT3; ++ct) {
-                    float v = m[rt][ct];
-                    v = fmaxf(v, __shfl_xor(v, 16));
-                    v = fmaxf(v, __shfl_xor(v, 32));
+                    const float v = rows_max4(m[rt][ct]);  // the 16 positions of a row tile sit in the 4 lane rows
                     if (g == 0 && s < S) {
                         const int oc = (wc * NT3 + ct) * 16 + li;
                         out[(size_t)b * A.out_b + (size_t)s * A.out_s + (size_t)oc * A.out_c] = fmaxf(v, 0.f);  // relu commutes with max
@@ -340,8 +346,8 @@ sa_mlp_max_kernel(const SaArgs A) {
     }
 }
 
-template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1>
-static int launch_sa(int b, SaArgs a, hipStream_t st) {
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K>
+static int launch_sa_k(int b, SaArgs a, hipStream_t st) {
     constexpr int WP = 4 / WC, TM = WP * 64;
     const int sk = a.S * a.K;
     a.tiles_per_cloud = (sk + TM - 1) / TM;
@@ -351,7 +357,7 @@ static int launch_sa(int b, SaArgs a, hipStream_t st) {
     a.lgK = 0;
     while ((1 << a.lgK) < a.K) ++a.lgK;
     const size_t lds = (size_t)TM * (NB1 * (C1 + 4) + C2 + 4) * sizeof(float);
-    auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW, NB1>;
+    auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW, NB1, K>;
     static bool attr_set = false;  // once per instantiation; never during a later stream capture
     if (lds > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -367,6 +373,16 @@ static int launch_sa(int b, SaArgs a, hipStream_t st) {
     const int grid = (a.num_tiles + rounds - 1) / rounds;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a);
     return check_launch();
+}
+
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1>
+static int launch_sa(int b, const SaArgs &a, hipStream_t st) {
+    switch (a.K) {
+        case 16: return launch_sa_k<C1, C2, C3, WC, RTC, MINW, NB1, 16>(b, a, st);
+        case 32: return launch_sa_k<C1, C2, C3, WC, RTC, MINW, NB1, 32>(b, a, st);
+        case 64: return launch_sa_k<C1, C2, C3, WC, RTC, MINW, NB1, 64>(b, a, st);
+    }
+    return PN2_ERANGE;
 }
 
 static long long *g_sa_trace = nullptr;
