@@ -58,10 +58,15 @@ struct SaArgs {
 // RTC = row tiles (of 16 positions) whose accumulators are live at once (4 = fewest passes over the weight
 // registers, 2 = half the accumulator / A-fragment registers).  MINW = waves per SIMD for __launch_bounds__.
 // K (neighbours per centroid) is a template parameter: the max-combine / store part is then straight-line code.
-template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K>
+// MODE fixes which layer-1 operands exist so the LOAD role is branch-free: 0 = xyz only (sa1), 1 = a1f + xyz,
+// 2 = a1f + xyz + cadd, 3 = any combination, tested at run time.
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
 __global__ void __launch_bounds__(512, MINW)
 sa_mlp_max_kernel(const SaArgs A) {
     static_assert(K == 16 || K == 32 || K == 64, "K");
+    const bool has_a1f = MODE == 3 ? A.a1f != nullptr : MODE >= 1;
+    const bool has_xyz = MODE == 3 ? A.xyz != nullptr : true;
+    const bool has_cadd = MODE == 3 ? A.cadd != nullptr : MODE == 2;
     constexpr int lgK = K == 16 ? 4 : K == 32 ? 5 : 6;
     const int N = A.N, S = A.S;
     const float *__restrict__ W2 = A.w2, *__restrict__ b2 = A.b2, *__restrict__ W3 = A.w3, *__restrict__ b3 = A.b3;
@@ -96,7 +101,7 @@ sa_mlp_max_kernel(const SaArgs A) {
     float wxr[4][3] = {{0.f}};
     float4 b1r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!compute) {
-        if (A.xyz) {
+        if (has_xyz) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -105,66 +110,82 @@ sa_mlp_max_kernel(const SaArgs A) {
         if (A.b1) b1r = *reinterpret_cast<const float4 *>(A.b1 + 4 * c4);
     }
 
-    // h1 = relu(a1f[idx] + Wx (p_idx - c_s) + b1 + cadd_s) for HALF h (rows h*TM/2 ...) of `tile` -> LDS.
-    // All of a thread's loads are issued back-to-back, group by group (indices, then every row's gathers),
-    // with clamped (always valid) addresses and no per-row branches: a row costs one memory round trip for
-    // its index + one for its data instead of a serial chain per row (measured: 20k -> ~3k cycles per half).
+    // h1 = relu(a1f[idx] + Wx (p_idx - c_s) + b1 + cadd_s) for HALF h (rows h*TM/2 ...) of a tile -> LDS, as three
+    // stages the LOAD loop software-pipelines: (1) neighbour indices, (2) the row gathers that depend on them,
+    // (3) arithmetic + LDS write.  A half tile costs two dependent HBM round trips (index, then rows, ~2-4k cycles
+    // each); issued back to back they made the LOAD role as slow as the matrix-core role (trace: 10.9k / 15.7k
+    // cycles per half against 9.5k / 15.1k).  In the pipeline the indices of half q+2 and the rows of half q+1 are
+    // in flight while half q is finished, so each half exposes at most the tail of one round trip.
+    // All loads use clamped (always valid) addresses and no per-row branches.
     constexpr int RPT = (TM / 2) / (256 / Q1);  // rows per loader thread per half tile
     static_assert((TM / 2) % (256 / Q1) == 0, "half tile rows split evenly over the loader threads");
-    auto gather = [&](int tile, float *__restrict__ H1, int h) {
+    // A thread's rows are STR apart, so RPC consecutive ones lie in the same K-block = the same centroid: its
+    // coordinates / additive term are loaded once per group, not per row.
+    constexpr int STR = 256 / Q1;
+    constexpr int RPC = (K / STR) < 1 ? 1 : ((K / STR) > RPT ? RPT : (K / STR));
+    const int row0 = lt / Q1;
+    struct HalfIdx { int jj[RPT], ss[RPT]; };
+    struct HalfRows { float4 a[RPT], c[RPT]; f32x3 pj[RPT], cs[RPT]; };
+    auto load_idx = [&](int tile, int h, HalfIdx &I) {
+        tile = tile < num_tiles ? tile : num_tiles - 1;  // past-the-end halves are fetched (valid addresses), never written
         const int b = tile / tiles_per_cloud;
         const int pos0 = (tile - b * tiles_per_cloud) * TM + h * (TM / 2);
-        // wave-uniform (scalar) per-cloud bases + 32-bit per-lane offsets: the LOAD role's address arithmetic is
-        // a handful of 32-bit VALU ops per row (it competes with the MFMA stream for issue slots)
         const int *__restrict__ idxb = A.idx + (size_t)b * SK;
-        const float *__restrict__ a1b = A.a1f ? A.a1f + (size_t)b * N * A.a1f_ld : nullptr;
-        const float *__restrict__ cab = A.cadd ? A.cadd + (size_t)b * S * A.cadd_ld : nullptr;
-        const float *__restrict__ xb_ = A.xyz ? A.xyz + (size_t)b * N * 3 : nullptr;
-        const float *__restrict__ cb_ = A.xyz ? A.cxyz + (size_t)b * S * 3 : nullptr;
-        const int row0 = lt / Q1;
-        int jj[RPT], ss[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            int p = pos0 + row0 + r * (256 / Q1);
+            int p = pos0 + row0 + r * STR;
             p = p < SK ? p : SK - 1;  // rows past the end belong to no centroid: computed, never stored
-            jj[r] = idxb[p];
-            ss[r] = p >> lgK;
+            I.jj[r] = idxb[p];
+            I.ss[r] = p >> lgK;
         }
-        // every load of the half tile is in flight before the first use: ONE further round trip after the indices
-        float4 a[RPT], c[RPT];
-        f32x3 pj[RPT], cs[RPT];
-        if (A.a1f) {
+    };
+    auto load_rows = [&](int tile, const HalfIdx &I, HalfRows &D) {
+        tile = tile < num_tiles ? tile : num_tiles - 1;
+        const int b = tile / tiles_per_cloud;
+        // wave-uniform (scalar) per-cloud bases + 32-bit per-lane offsets: few VALU ops per row next to the MFMA stream
+        if (has_a1f) {
+            const float *__restrict__ a1b = A.a1f + (size_t)b * N * A.a1f_ld;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r)
-                a[r] = *reinterpret_cast<const float4 *>(a1b + (unsigned)(jj[r] * A.a1f_ld + 4 * c4));
+            for (int r = 0; r < RPT; ++r) D.a[r] = *reinterpret_cast<const float4 *>(a1b + (unsigned)(I.jj[r] * A.a1f_ld + 4 * c4));
         }
-        if (A.cadd) {
+        if (has_cadd) {
+            const float *__restrict__ cab = A.cadd + (size_t)b * S * A.cadd_ld;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r)
-                c[r] = *reinterpret_cast<const float4 *>(cab + (unsigned)(ss[r] * A.cadd_ld + 4 * c4));
+            for (int r = 0; r < RPT; r += RPC) D.c[r] = *reinterpret_cast<const float4 *>(cab + (unsigned)(I.ss[r] * A.cadd_ld + 4 * c4));
         }
-        if (A.xyz) {
+        if (has_xyz) {
+            const float *__restrict__ xb_ = A.xyz + (size_t)b * N * 3;
+            const float *__restrict__ cb_ = A.cxyz + (size_t)b * S * 3;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                pj[r] = load_xyz(xb_ + (unsigned)(jj[r] * 3));
-                cs[r] = load_xyz(cb_ + (unsigned)(ss[r] * 3));
-            }
+            for (int r = 0; r < RPT; ++r) D.pj[r] = load_xyz(xb_ + (unsigned)(I.jj[r] * 3));
+#pragma unroll
+            for (int r = 0; r < RPT; r += RPC) D.cs[r] = load_xyz(cb_ + (unsigned)(I.ss[r] * 3));
         }
+    };
+    auto finish = [&](const HalfRows &D, float *__restrict__ H1, int h) {
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             float4 v = b1r;
-            if (A.a1f) { v.x += a[r].x; v.y += a[r].y; v.z += a[r].z; v.w += a[r].w; }
-            if (A.cadd) { v.x += c[r].x; v.y += c[r].y; v.z += c[r].z; v.w += c[r].w; }
-            if (A.xyz) {
-                const float dx = pj[r].x - cs[r].x, dy = pj[r].y - cs[r].y, dz = pj[r].z - cs[r].z;
+            if (has_a1f) { v.x += D.a[r].x; v.y += D.a[r].y; v.z += D.a[r].z; v.w += D.a[r].w; }
+            if (has_cadd) { const float4 c = D.c[r - r % RPC]; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+            if (has_xyz) {
+                const f32x3 cs = D.cs[r - r % RPC];
+                const float dx = D.pj[r].x - cs.x, dy = D.pj[r].y - cs.y, dz = D.pj[r].z - cs.z;
                 v.x += wxr[0][0] * dx + wxr[0][1] * dy + wxr[0][2] * dz;
                 v.y += wxr[1][0] * dx + wxr[1][1] * dy + wxr[1][2] * dz;
                 v.z += wxr[2][0] * dx + wxr[2][1] * dy + wxr[2][2] * dz;
                 v.w += wxr[3][0] * dx + wxr[3][1] * dy + wxr[3][2] * dz;
             }
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r * (256 / Q1)) * LD1 + 4 * c4) = v;
+            *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r * STR) * LD1 + 4 * c4) = v;
         }
+    };
+    auto gather = [&](int tile, float *__restrict__ H1, int h) {  // unpipelined: prologue only
+        HalfIdx I;
+        HalfRows D;
+        load_idx(tile, h, I);
+        load_rows(tile, I, D);
+        finish(D, H1, h);
     };
 
     // ---- COMPUTE role: weights -> registers (B operand: lane holds W[out = tile*16 + li][in = 16*tq + 4*g + j])
@@ -219,16 +240,27 @@ sa_mlp_max_kernel(const SaArgs A) {
         // the LOAD waves issue few instructions but each is latency-critical: let them win issue arbitration
         // against the co-resident MFMA stream (measured: gather 12k -> ~5k cycles per half tile)
         __builtin_amdgcn_s_setprio(3);
+        // pipeline fill: rows of the first half and indices of the second half of the first tile this loop gathers
+        HalfIdx I0, I1;
+        HalfRows D0, D1;
+        const int first = blockIdx.x + (NB1 - 1) * gridDim.x;
+        load_idx(first, 0, I0);
+        load_idx(first, 1, I1);
+        load_rows(first, I0, D0);
         int it = 0;
         for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, ++it) {
             stamp(it, 0);
             float *H1n = H1ring + ((it + NB1 - 1) % NB1) * TM * LD1;  // last read by COMPUTE in iteration it-1
-            const int next = tile + (NB1 - 1) * gridDim.x;
-            if (next < num_tiles) gather(next, H1n, 0);
+            const int next = tile + (NB1 - 1) * gridDim.x, after = next + gridDim.x;
+            load_rows(next, I1, D1);    // half 1 of `next`: in flight while half 0 is finished
+            load_idx(after, 0, I0);     // indices two halves ahead
+            if (next < num_tiles) finish(D0, H1n, 0);
             stamp(it, 2);
             __syncthreads();  // B1
             stamp(it, 3);
-            if (next < num_tiles) gather(next, H1n, 1);
+            load_rows(after, I0, D0);   // half 0 of the following tile
+            load_idx(after, 1, I1);
+            if (next < num_tiles) finish(D1, H1n, 1);
             stamp(it, 5);
             __syncthreads();  // B2
             stamp(it, 6);
@@ -346,8 +378,8 @@ sa_mlp_max_kernel(const SaArgs A) {
     }
 }
 
-template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K>
-static int launch_sa_k(int b, SaArgs a, hipStream_t st) {
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
+static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
     constexpr int WP = 4 / WC, TM = WP * 64;
     const int sk = a.S * a.K;
     a.tiles_per_cloud = (sk + TM - 1) / TM;
@@ -357,7 +389,7 @@ static int launch_sa_k(int b, SaArgs a, hipStream_t st) {
     a.lgK = 0;
     while ((1 << a.lgK) < a.K) ++a.lgK;
     const size_t lds = (size_t)TM * (NB1 * (C1 + 4) + C2 + 4) * sizeof(float);
-    auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW, NB1, K>;
+    auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW, NB1, K, MODE>;
     static bool attr_set = false;  // once per instantiation; never during a later stream capture
     if (lds > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -373,6 +405,15 @@ static int launch_sa_k(int b, SaArgs a, hipStream_t st) {
     const int grid = (a.num_tiles + rounds - 1) / rounds;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a);
     return check_launch();
+}
+
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K>
+static int launch_sa_k(int b, const SaArgs &a, hipStream_t st) {
+    const bool fa = a.a1f != nullptr, fx = a.xyz != nullptr, fc = a.cadd != nullptr;
+    if (!fa && fx && !fc) return launch_sa_km<C1, C2, C3, WC, RTC, MINW, NB1, K, 0>(b, a, st);
+    if (fa && fx && !fc) return launch_sa_km<C1, C2, C3, WC, RTC, MINW, NB1, K, 1>(b, a, st);
+    if (fa && fx && fc) return launch_sa_km<C1, C2, C3, WC, RTC, MINW, NB1, K, 2>(b, a, st);
+    return launch_sa_km<C1, C2, C3, WC, RTC, MINW, NB1, K, 3>(b, a, st);
 }
 
 template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1>
