@@ -98,22 +98,31 @@ extern "C" int pn2x_gather_rows(int b, int n, int m, int c, const float *src, co
 }
 
 namespace pn2 {
-// out[b, ch] = max_r x[b, r, ch]   (x (b, r, c) point-major: lanes walk channels -> coalesced rows)
+// out[b, ch] = max_r x[b, r, ch]   (x (b, r, c) point-major: lanes walk channels -> coalesced rows).
+// Block = 64 channels x 4 row groups; every thread keeps 8 independent loads in flight (one thread per channel
+// walking all r rows was a latency chain: 11.8 us for one 128 x 512 cloud), the four partial maxima meet in LDS.
 __global__ void __launch_bounds__(256)
-max_rows_kernel(int r, int c, const float *__restrict__ x, float *__restrict__ out, long total) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long b = e / c;
-        const int ch = (int)(e - b * c);
+max_rows_kernel(int r, int c, const float *__restrict__ x, float *__restrict__ out) {
+    __shared__ float part[4][64];
+    const int chunks = (c + 63) / 64;
+    const int b = blockIdx.x / chunks, ch = (blockIdx.x % chunks) * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float m = -__builtin_inff();
+    if (ch < c) {
         const float *p = x + (size_t)b * r * c + ch;
-        float m0 = p[0], m1 = m0, m2 = m0, m3 = m0;
-        int i = 0;
-        for (; i + 3 < r; i += 4) {
-            m0 = fmaxf(m0, p[(size_t)i * c]); m1 = fmaxf(m1, p[(size_t)(i + 1) * c]);
-            m2 = fmaxf(m2, p[(size_t)(i + 2) * c]); m3 = fmaxf(m3, p[(size_t)(i + 3) * c]);
+        int i = rg;
+        for (; i + 28 < r; i += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(i + 4 * u) * c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
         }
-        for (; i < r; ++i) m0 = fmaxf(m0, p[(size_t)i * c]);
-        out[e] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        for (; i < r; i += 4) m = fmaxf(m, p[(size_t)i * c]);
     }
+    part[rg][threadIdx.x & 63] = m;
+    __syncthreads();
+    if (rg == 0 && ch < c)
+        out[(size_t)b * c + ch] = fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]), fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
 }
 }  // namespace pn2
 
@@ -122,9 +131,8 @@ extern "C" int pn2x_max_rows(int b, int r, int c, const float *x, float *out, vo
     if (b < 0 || r < 1 || c < 0) return PN2_EINVAL;
     if (b == 0 || c == 0) return PN2_OK;
     if (!x || !out) return PN2_ENULL;
-    const long total = (long)b * c;
-    long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(max_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, c, x, out, total);
+    const long blocks = (long)b * ((c + 63) / 64);
+    if (blocks > 2147483647L) return PN2_ERANGE;
+    hipLaunchKernelGGL(max_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, c, x, out);
     return check_launch();
 }

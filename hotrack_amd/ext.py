@@ -195,3 +195,60 @@ def hand_frame(palm_template: torch.Tensor, kp: torch.Tensor, palm_idx: torch.Te
                                             _native._ptr(points, "points", f32, B * N * 3), float(scale), R.data_ptr(), t.data_ptr(),
                                             xyz2.data_ptr(), xyz1.data_ptr(), _native._stream(points)), "hand_frame")
     return R, t, xyz2, xyz1
+
+
+_cf = ctypes.c_float
+_lib.pn2x_add_layernorm.argtypes = [_cl, _ci, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _cf, _vp, _vp]
+_lib.pn2x_add_layernorm.restype = _ci
+_lib.pn2x_pose_head.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp]
+_lib.pn2x_pose_head.restype = _ci
+
+
+def add_layernorm(x: torch.Tensor, ln1, y: torch.Tensor = None, bias: torch.Tensor = None, ln2=None) -> torch.Tensor:
+    """LN2(LN1(x + y + bias)) over the last dim of row-major x (rows, C); ln1 / ln2 are nn.LayerNorm modules
+    (ln2 optional), y (rows, C) and bias (C,) optional.  One launch (include/pn2_ext.h: pn2x_add_layernorm)."""
+    rows, C = x.shape
+    f32 = torch.float32
+    px = _native._ptr(x, "x", f32, rows * C)
+    py = None if y is None else _native._ptr(y, "y", f32, rows * C)
+    pb = None if bias is None else _native._ptr(bias, "bias", f32, C)
+    for ln in (ln1, ln2):
+        if ln is not None and (tuple(ln.normalized_shape) != (C,) or ln.weight is None or ln.bias is None):
+            raise ValueError("add_layernorm: LayerNorm over the last dimension with affine parameters expected")
+    g1, b1 = _native._ptr(ln1.weight, "ln1.weight", f32, C), _native._ptr(ln1.bias, "ln1.bias", f32, C)
+    g2 = b2 = None
+    eps2 = 0.0
+    if ln2 is not None:
+        g2, b2, eps2 = _native._ptr(ln2.weight, "ln2.weight", f32, C), _native._ptr(ln2.bias, "ln2.bias", f32, C), ln2.eps
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _native._check(_lib.pn2x_add_layernorm(rows, C, px, py, pb, g1, b1, ln1.eps, g2, b2, eps2, out.data_ptr(), _native._stream(x)),
+                       "add_layernorm")
+    return out
+
+
+def pose_head(h: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xyz1: torch.Tensor, R: torch.Tensor, t: torch.Tensor, scale: float):
+    """h (B*J, C), w (3, C), bias (3,), xyz1 (B,J,3), R (B,3,3), t (B,3,1) -> (kp_hand (B,J,3), kp_cam (B,J,3)):
+    kp_hand = h w^T + bias + xyz1;  kp_cam = (kp_hand R^T) * scale + t  (include/pn2_ext.h: pn2x_pose_head)."""
+    B, J, _ = xyz1.shape
+    C = h.shape[1]
+    f32 = torch.float32
+    ptrs = (_native._ptr(h, "h", f32, B * J * C), _native._ptr(w, "w", f32, 3 * C), _native._ptr(bias, "bias", f32, 3),
+            _native._ptr(xyz1, "xyz1", f32, B * J * 3), _native._ptr(R, "R", f32, B * 9), _native._ptr(t, "t", f32, B * 3))
+    kp_hand = torch.empty((B, J, 3), dtype=f32, device=h.device)
+    kp_cam = torch.empty((B, J, 3), dtype=f32, device=h.device)
+    with torch.cuda.device(h.device):
+        _native._check(_lib.pn2x_pose_head(B, J, C, *ptrs, float(scale), kp_hand.data_ptr(), kp_cam.data_ptr(), _native._stream(h)),
+                       "pose_head")
+    return kp_hand, kp_cam
+
+
+def knn_indices(k: int, unknown: torch.Tensor, known: torch.Tensor) -> torch.Tensor:
+    """Indices (B,n,k) int32 of the k nearest `known` points of every `unknown` point, sorted by (distance, index) --
+    pointnet2_utils.knn without the sqrt / distance output the caller would discard."""
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    dist2 = torch.empty((B, n, k), dtype=torch.float32, device=unknown.device)
+    idx = torch.empty((B, n, k), dtype=torch.int32, device=unknown.device)
+    _native.knn_wrapper(B, n, m, k, unknown, known, dist2, idx)
+    return idx

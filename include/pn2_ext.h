@@ -111,6 +111,22 @@ int pn2x_bias_act_pm(long rows, int c, float *y, int ldy, const float *bias, lon
  */
 int pn2x_max_rows(int b, int r, int c, const float *x, float *out, void *stream);
 
+/*
+ * out = LN2( LN1( x + y + bias ) ) over the last dimension of row-major (rows, c) data, c <= 1024:
+ * torch.nn.functional.layer_norm semantics (biased variance, eps inside the square root), affine (g, b) each.
+ * y, bias and the second LayerNorm (g2, b2 both NULL) are optional.  One launch for the reference's residual add +
+ * LayerNorm runs in the attention-free transformer blocks (transformer.py:84-95 with attn=False) of the 21-token tail.
+ */
+int pn2x_add_layernorm(long rows, int c, const float *x, const float *y, const float *bias, const float *g1,
+                       const float *b1, float eps1, const float *g2, const float *b2, float eps2, float *out, void *stream);
+
+/*
+ * Head of HandTrackNet (hand_network.py:141-147): delta = h W^T + bias (W (3, c): the last Conv1d), kp_hand = delta +
+ * xyz1, kp_cam = (kp_hand R^T) * scale + t.  h (b*j, c) token-major; xyz1, kp_hand, kp_cam (b, j, 3); R (b,3,3); t (b,3,1).
+ */
+int pn2x_pose_head(int b, int j, int c, const float *h, const float *w, const float *bias, const float *xyz1,
+                   const float *R, const float *t, float scale, float *kp_hand, float *kp_cam, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

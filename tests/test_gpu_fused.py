@@ -210,3 +210,41 @@ def test_tuned_gemm_table_loads():
     assert gemm_tuning.enable() is True
     assert tunable.is_enabled() and not tunable.tuning_is_enabled()
     assert len(tunable.get_results()) > 50
+
+
+def test_tail_kernels_match_torch():
+    """add_layernorm / pose_head / max_rows / knn_indices (the fused element-wise runs of the 21-token tail) vs torch."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from hotrack_amd import ext, pointnet2_utils as ops
+    g = torch.Generator().manual_seed(5)
+    for rows, C in ((21, 384), (1344, 384), (5, 100), (64, 1024), (3, 64)):
+        x = torch.randn(rows, C, generator=g).cuda() * 3 + 1
+        y = torch.randn(rows, C, generator=g).cuda()
+        b = torch.randn(C, generator=g).cuda()
+        ln1, ln2 = nn.LayerNorm(C).cuda(), nn.LayerNorm(C, eps=1e-6).cuda()
+        for ln in (ln1, ln2):
+            ln.weight.data = torch.randn(C, generator=g).cuda()
+            ln.bias.data = torch.randn(C, generator=g).cuda()
+        with torch.no_grad():
+            torch.testing.assert_close(ext.add_layernorm(x, ln1), ln1(x), rtol=2e-5, atol=2e-5)
+            torch.testing.assert_close(ext.add_layernorm(x, ln1, ln2=ln2), ln2(ln1(x)), rtol=2e-5, atol=2e-5)
+            torch.testing.assert_close(ext.add_layernorm(x, ln1, y=y, bias=b, ln2=ln2), ln2(ln1(x + y + b)), rtol=2e-5, atol=2e-5)
+            torch.testing.assert_close(ext.add_layernorm(x, ln1, y=y), ln1(x + y), rtol=2e-5, atol=2e-5)
+    for B, J, C in ((1, 21, 256), (64, 21, 256), (3, 5, 70)):
+        h = torch.randn(B * J, C, generator=g).cuda()
+        w = torch.randn(3, C, generator=g).cuda() * 0.1
+        bias = torch.randn(3, generator=g).cuda()
+        xyz1 = torch.randn(B, J, 3, generator=g).cuda()
+        R = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0].cuda().contiguous()
+        t = torch.randn(B, 3, 1, generator=g).cuda()
+        kh, kc = ext.pose_head(h, w, bias, xyz1, R, t, 0.2)
+        ref_h = F.linear(h, w, bias).view(B, J, 3) + xyz1
+        torch.testing.assert_close(kh, ref_h, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(kc, torch.matmul(ref_h, R.transpose(1, 2)) * 0.2 + t.transpose(1, 2), rtol=1e-5, atol=1e-5)
+    for B, R_, C in ((1, 128, 512), (64, 128, 512), (3, 1, 7), (2, 37, 130), (2, 200, 64)):
+        x = torch.randn(B, R_, C, generator=g).cuda()
+        assert torch.equal(ext.max_rows(x), x.max(dim=1)[0])
+    xyz = torch.rand(4, 1024, 3, generator=g).cuda()
+    q = torch.rand(4, 21, 3, generator=g).cuda()
+    assert torch.equal(ext.knn_indices(64, q, xyz), ops.knn(64, q, xyz)[1])
