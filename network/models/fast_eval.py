@@ -63,7 +63,7 @@ class FastEval:
             return self.P
         from hotrack_amd import gemm_tuning
         from hotrack_amd.fused import fold_conv_bn as fold
-        gemm_tuning.enable()  # gfx950 solution table for the library GEMMs below (no-op if absent / disabled)
+        gemm_tuning.enable()  # load the gfx950 solution table for the library GEMMs (no-op if absent / disabled)
         net, bh = self.net, self.net.bhand
         P = {}
 
@@ -122,6 +122,11 @@ class FastEval:
 
     # ------------------------------------------------------------------------------------
     def forward(self, input, flag_dict):
+        from hotrack_amd import gemm_tuning
+        with gemm_tuning.scope():  # recorded GEMM solutions for this forward only
+            return self._forward(input, flag_dict)
+
+    def _forward(self, input, flag_dict):
         from hotrack_amd import ext
         from hotrack_amd import pointnet2_utils as ops
         net = self.net

@@ -208,8 +208,11 @@ def test_tuned_gemm_table_loads():
     import torch.cuda.tunable as tunable
     from hotrack_amd import gemm_tuning
     assert gemm_tuning.enable() is True
-    assert tunable.is_enabled() and not tunable.tuning_is_enabled()
-    assert len(tunable.get_results()) > 50
+    assert not tunable.is_enabled()                       # loaded, but only applied inside scope()
+    with gemm_tuning.scope():
+        assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+        assert len(tunable.get_results()) > 50
+    assert not tunable.is_enabled()
 
 
 def test_tail_kernels_match_torch():
