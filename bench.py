@@ -67,8 +67,8 @@ class KernelTimer:
     def summary(self, passes):
         by = {}
         for name, a, s, e in self.records:
-            if name == "fps_kernel":
-                key = ("fps_kernel", a[0], a[1], a[2])  # (b, n, m)
+            if name in ("fps_kernel", "fps_prefix_kernel"):
+                key = (name, a[0], a[1], a[2])  # (b, n, m)
             else:
                 key = ("sa_mlp_max_kernel", a[0], a[2], a[3], a[4], a[5], a[6])  # (b, s, k, c1, c2, c3)
             by.setdefault(key, []).append(s.elapsed_time(e) * 1e-3)
@@ -85,8 +85,14 @@ def roofline_of(key, sec, per_step):
                 "achieved": round(flops / sec / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step}
-    _, B, N, M = key
+    name, B, N, M = key
     kb = B * (12 * N + 4 * M)  # FPS bytes = B(12N + 4M)
+    if name == "fps_prefix_kernel":
+        return {"bound": "hbm", "kernel": "fps second level (B=%d,N=%d,M=%d)" % (B, N, M), "achieved": round(kb / sec / 1e9, 3),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb / sec / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                "bytes_per_launch": kb, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step,
+                "note": "FPS over level 1's samples = level 1's first M picks unless an arg-max tied (pn2_ext.h): per cloud "
+                        "the launch returns at once (no tie: all clouds of this synthetic batch) or runs the real pass"}
     return {"bound": "hbm", "kernel": "fps_kernel (B=%d,N=%d,M=%d)" % (B, N, M), "achieved": round(kb / sec / 1e9, 3),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb / sec / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
             "bytes_per_launch": kb, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step,

@@ -9,7 +9,9 @@ namespace pn2 {
 static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
 
-int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t st, int force_threads);
+int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t st, int force_threads,
+                 const int *skip_flags, int nflags, float *radii);
+int fps_tie_check(int b, int n, int m, int m1, const float *xyz, const int *idx, const float *radii, int *flags, hipStream_t st);
 int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                         int *idx, hipStream_t st);
 int three_nn_dispatch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
@@ -63,7 +65,34 @@ int pn2_furthest_point_sampling(int b, int n, int m, const float *xyz, float *te
     PN2_REQ(fits_int((long)n * 3), PN2_ERANGE);
     int force = 0;
     if (const char *e = getenv("PN2_FPS_THREADS")) force = atoi(e);  // tuning/experiments only
-    return fps_dispatch(b, n, m, xyz, temp, idx, (hipStream_t)stream, force);
+    return fps_dispatch(b, n, m, xyz, temp, idx, (hipStream_t)stream, force, nullptr, 0, nullptr);
+}
+
+// ---- two-level sampling shortcut (include/pn2_ext.h) ---------------------------------------------------------------
+int pn2x_furthest_point_sampling_radii(int b, int n, int m, const float *xyz, int *idx, float *radii, void *stream) {
+    PN2_REQ(b >= 0 && n >= 1 && m >= 0, PN2_EINVAL);
+    if (b == 0 || m == 0) return PN2_OK;
+    PN2_REQ(xyz && idx && radii, PN2_ENULL);
+    PN2_REQ(fits_int((long)n * 3), PN2_ERANGE);
+    return fps_dispatch(b, n, m, xyz, nullptr, idx, (hipStream_t)stream, 0, nullptr, 0, radii);
+}
+
+int pn2x_fps_prefix_ties(int b, int n, int m1, int m2, const float *xyz, const int *idx1, const float *radii, int *flags, void *stream) {
+    PN2_REQ(b >= 0 && n >= 1 && m1 >= 1 && m2 >= 1 && m2 <= m1, PN2_EINVAL);
+    if (b == 0) return PN2_OK;
+    PN2_REQ(xyz && idx1 && radii && flags, PN2_ENULL);
+    PN2_REQ(fits_int((long)n * 3) && b <= 65535, PN2_ERANGE);
+    return fps_tie_check(b, n, m2, m1, xyz, idx1, radii, flags, (hipStream_t)stream);
+}
+
+int pn2x_fps_prefix_flags(int n) { return n < 1 ? PN2_EINVAL : (n + 255) / 256; }
+
+int pn2x_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz, const int *flags, int nflags, int *idx, void *stream) {
+    PN2_REQ(b >= 0 && n >= 1 && m >= 0 && m <= n && nflags >= 1, PN2_EINVAL);
+    if (b == 0 || m == 0) return PN2_OK;
+    PN2_REQ(xyz && idx && flags, PN2_ENULL);
+    PN2_REQ(fits_int((long)n * 3), PN2_ERANGE);
+    return fps_dispatch(b, n, m, xyz, nullptr, idx, (hipStream_t)stream, 0, flags, nflags, nullptr);
 }
 
 int pn2_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,

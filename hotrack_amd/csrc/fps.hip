@@ -20,9 +20,13 @@ namespace pn2 {
 
 enum { kCentEntry = 0, kCentLds = 1, kCentGlobal = 2 };
 
-template <int T, int P, int CENT>
+// skip_flags (pn2x_furthest_point_sampling_prefix, pn2_ext.h): `nflags` ints per cloud; if given and all of a cloud's
+// are zero, the sample is known to be 0..m-1 and the workgroup writes that and returns.
+// RAD: also record radii (pn2x_furthest_point_sampling_radii); a template flag so the plain kernel's loop is untouched.
+template <int T, int P, int CENT, bool RAD>
 __global__ void __launch_bounds__(T)
-fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_all, int *__restrict__ idx_all) {
+fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_all, int *__restrict__ idx_all,
+           const int *__restrict__ skip_flags, int nflags, float *__restrict__ radii_all) {
     constexpr int W = T / kWave;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // entries: [parity][field][wave]   field: 0 dist, 1 k, 2 x, 3 y, 4 z
@@ -34,6 +38,14 @@ fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_al
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
+    if (skip_flags) {  // wave-uniform
+        int any = 0;
+        for (int f = 0; f < nflags; ++f) any |= skip_flags[(size_t)blockIdx.x * nflags + f];
+        if (!any) {
+            for (int i = tid; i < m; i += T) idx[i] = i;
+            return;
+        }
+    }
 
     float px[P], py[P], pz[P], pt[P];
     int pk[P];
@@ -86,6 +98,7 @@ fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_al
         const int wl = __builtin_ctzll(tie);  // first lane == lowest tie rank in this wave
 
         int kstar;
+        int gbits = wmax;  // bit pattern of the global maximum of this iteration
         if constexpr (W == 1) {
             kstar = __builtin_amdgcn_readlane(bestk, wl);
             if constexpr (CENT == kCentEntry) {
@@ -118,13 +131,18 @@ fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_al
             const uint64_t tie2 = __ballot(ev == gmax);
             const int wl2 = __builtin_ctzll(tie2);  // lanes 0..W-1 hold waves 0..W-1: lowest wave wins
             kstar = __builtin_amdgcn_readlane(ek, wl2);
+            gbits = gmax;
             if constexpr (CENT == kCentEntry) {
                 cx = i2f(__builtin_amdgcn_readlane(ex, wl2));
                 cy = i2f(__builtin_amdgcn_readlane(ey, wl2));
                 cz = i2f(__builtin_amdgcn_readlane(ez, wl2));
             }
         }
-        if (tid == 0) idx[it] = kstar;
+        if (tid == 0) {
+            idx[it] = kstar;
+            // the winning (maximum) running distance of this pick -- input of the post-hoc tie check
+            if constexpr (RAD) radii_all[(size_t)blockIdx.x * m + it] = i2f(gbits);
+        }
         if constexpr (CENT == kCentLds) {
             cx = lxyz[3 * kstar + 0];
             cy = lxyz[3 * kstar + 1];
@@ -182,25 +200,72 @@ fps_large_kernel(int n, int m, const float *__restrict__ xyz_all, float *__restr
     }
 }
 
-template <int T, int P>
-static int launch_fps(int b, int n, int m, int bs, int lg, int Q, const float *xyz, int *idx, hipStream_t st) {
+template <int T, int P, bool RAD>
+static int launch_fps(int b, int n, int m, int bs, int lg, int Q, const float *xyz, int *idx, hipStream_t st, const int *skip_flags,
+                      int nflags, float *radii) {
     const size_t ent_bytes = 2 * 5 * 16 * sizeof(float);
     if constexpr (P == 1) {
-        hipLaunchKernelGGL((fps_kernel<T, 1, kCentEntry>), dim3(b), dim3(T), ent_bytes, st, n, m, bs, lg, Q, xyz, idx);
+        hipLaunchKernelGGL((fps_kernel<T, 1, kCentEntry, RAD>), dim3(b), dim3(T), ent_bytes, st, n, m, bs, lg, Q, xyz, idx, skip_flags, nflags, radii);
     } else {
         const size_t need = ent_bytes + (size_t)n * 3 * sizeof(float);
         if (need <= 128 * 1024) {
-            auto kfn = fps_kernel<T, P, kCentLds>;
+            auto kfn = fps_kernel<T, P, kCentLds, RAD>;
             static size_t attr_bytes = 0;  // raise the dynamic-LDS cap once per size class, not per launch
             if (need > 64 * 1024 && need > attr_bytes) {
                 (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
                 attr_bytes = 128 * 1024;
             }
-            hipLaunchKernelGGL(kfn, dim3(b), dim3(T), need, st, n, m, bs, lg, Q, xyz, idx);
+            hipLaunchKernelGGL(kfn, dim3(b), dim3(T), need, st, n, m, bs, lg, Q, xyz, idx, skip_flags, nflags, radii);
         } else {
-            hipLaunchKernelGGL((fps_kernel<T, P, kCentGlobal>), dim3(b), dim3(T), ent_bytes, st, n, m, bs, lg, Q, xyz, idx);
+            hipLaunchKernelGGL((fps_kernel<T, P, kCentGlobal, RAD>), dim3(b), dim3(T), ent_bytes, st, n, m, bs, lg, Q, xyz, idx, skip_flags, nflags, radii);
         }
     }
+    return check_launch();
+}
+
+// ---- were the first m picks of a finished FPS run unique arg-maxima?  (pn2x_fps_prefix_ties, pn2_ext.h) ----------------
+// With the picks known there is no dependency chain left: every point replays its own running minimum against the
+// picks in order (the same sqdist / min chain as the sampling kernel, hence the same floats) and compares it with
+// the value the sampling kernel recorded for that pick (radii[i] = the maximum it selected at step i).  A point other
+// than pick i that reaches radii[i] at step i means that arg-max was tied.  One workgroup per 256 points.
+constexpr int kTieMaxM = 1024;
+__global__ void __launch_bounds__(256)
+fps_tie_check_kernel(int n, int m, int m1, const float *__restrict__ xyz_all, const int *__restrict__ idx_all,
+                     const float *__restrict__ radii_all, int *__restrict__ flags) {
+    __shared__ float4 pick[kTieMaxM];  // x, y, z of pick i, radius of pick i+1 (what a point is compared with after meeting pick i)
+    __shared__ int ck[kTieMaxM];
+    __shared__ int tie_any;
+    const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.y * n * 3;
+    const int *__restrict__ idx = idx_all + (size_t)blockIdx.y * m1;
+    const float *__restrict__ radii = radii_all + (size_t)blockIdx.y * m1;
+    const int tid = threadIdx.x;
+    if (tid == 0) tie_any = 0;
+    for (int i = tid; i < m; i += 256) {
+        const int k = idx[i];
+        ck[i] = k;
+        pick[i] = make_float4(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2], i + 1 < m ? radii[i + 1] : -1.0f);
+    }
+    __syncthreads();
+    const int k = blockIdx.x * 256 + tid;
+    bool tie = false;
+    if (k < n) {
+        const float px = xyz[3 * k], py = xyz[3 * k + 1], pz = xyz[3 * k + 2];
+        float d = 1e10f;
+#pragma unroll 8
+        for (int i = 0; i + 1 < m; ++i) {
+            const float4 c = pick[i];
+            d = fmin_raw(sqdist(px, py, pz, c.x, c.y, c.z), d);
+            if (d == c.w) tie |= (k != ck[i + 1]);  // rarely true: the pick itself, or a tie
+        }
+    }
+    if (__ballot(tie) != 0 && (tid & 63) == 0) tie_any = 1;
+    __syncthreads();
+    if (tid == 0) flags[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tie_any;
+}
+
+int fps_tie_check(int b, int n, int m, int m1, const float *xyz, const int *idx, const float *radii, int *flags, hipStream_t st) {
+    if (m > kTieMaxM) return PN2_ERANGE;
+    hipLaunchKernelGGL(fps_tie_check_kernel, dim3((n + 255) / 256, b), dim3(256), 0, st, n, m, m1, xyz, idx, radii, flags);
     return check_launch();
 }
 
@@ -210,7 +275,8 @@ static int next_pow2(int v) {
     return p;
 }
 
-int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t st, int force_threads) {
+int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t st, int force_threads,
+                 const int *skip_flags, int nflags, float *radii) {
     // reference block size: cuda_utils.h:10-14
     int bs = 1;
     while (bs * 2 <= n && bs * 2 <= 1024) bs *= 2;
@@ -219,6 +285,7 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
     const int Q = (n + bs - 1) / bs;
     const int slots = bs * Q;
     if (slots > 1024 * 16) {
+        if (skip_flags || radii) return PN2_ERANGE;  // the shortcut covers the register-resident kernels only
         if (!temp) return PN2_ESCRATCH;
         hipLaunchKernelGGL(fps_large_kernel, dim3(b), dim3(1024), 0, st, n, m, xyz, temp, idx);
         return check_launch();
@@ -234,7 +301,8 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
     }
     const int P = next_pow2((slots + T - 1) / T);
 #define PN2_FPS_CASE(TT, PP) \
-    if (T == TT && P == PP) return launch_fps<TT, PP>(b, n, m, bs, lg, Q, xyz, idx, st);
+    if (T == TT && P == PP) return radii ? launch_fps<TT, PP, true>(b, n, m, bs, lg, Q, xyz, idx, st, skip_flags, nflags, radii) \
+                                         : launch_fps<TT, PP, false>(b, n, m, bs, lg, Q, xyz, idx, st, skip_flags, nflags, radii);
 #define PN2_FPS_ROW(TT) PN2_FPS_CASE(TT, 1) PN2_FPS_CASE(TT, 2) PN2_FPS_CASE(TT, 4) PN2_FPS_CASE(TT, 8) PN2_FPS_CASE(TT, 16)
     PN2_FPS_ROW(64) PN2_FPS_ROW(128) PN2_FPS_ROW(256) PN2_FPS_ROW(512) PN2_FPS_ROW(1024)
 #undef PN2_FPS_ROW

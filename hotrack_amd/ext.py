@@ -252,3 +252,43 @@ def knn_indices(k: int, unknown: torch.Tensor, known: torch.Tensor) -> torch.Ten
     idx = torch.empty((B, n, k), dtype=torch.int32, device=unknown.device)
     _native.knn_wrapper(B, n, m, k, unknown, known, dist2, idx)
     return idx
+
+
+_lib.pn2x_furthest_point_sampling_radii.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp]
+_lib.pn2x_furthest_point_sampling_radii.restype = _ci
+_lib.pn2x_fps_prefix_ties.argtypes = [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_fps_prefix_ties.restype = _ci
+_lib.pn2x_fps_prefix_flags.argtypes = [_ci]
+_lib.pn2x_fps_prefix_flags.restype = _ci
+_lib.pn2x_furthest_point_sampling_prefix.argtypes = [_ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp]
+_lib.pn2x_furthest_point_sampling_prefix.restype = _ci
+
+
+def fps_two_level(xyz: torch.Tensor, m1: int, m2: int):
+    """The reference's two chained samplings  i1 = FPS(xyz, m1); l1 = xyz[i1]; i2 = FPS(l1, m2)  (backbones.py:98-104)
+    -> (i1 (B,m1), l1 (B,m1,3), i2 (B,m2)) int32/float32, bit-identical to running both.  The second pass is
+    skipped per cloud when level 1 had no tied arg-max among its first m2 picks (include/pn2_ext.h)."""
+    from . import pointnet2_utils as ops
+    B, N, _ = xyz.shape
+    if not 1 <= m2 <= m1:
+        raise ValueError("fps_two_level: need 1 <= m2 <= m1")
+    xyz = xyz.contiguous()
+    if m2 > 1024 or N > 16384:  # beyond the shortcut's kernels: two plain passes
+        i1 = ops.furthest_point_sample(xyz, m1)
+        l1 = gather_rows(xyz, i1)
+        return i1, l1, ops.furthest_point_sample(l1, m2)
+    px = _native._ptr(xyz, "xyz", torch.float32, B * N * 3)
+    nf = _lib.pn2x_fps_prefix_flags(N)
+    i1 = torch.empty((B, m1), dtype=torch.int32, device=xyz.device)
+    radii = torch.empty((B, m1), dtype=torch.float32, device=xyz.device)
+    flags = torch.empty((B, nf), dtype=torch.int32, device=xyz.device)
+    i2 = torch.empty((B, m2), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        st = _native._stream(xyz)
+        _native._check(_native._call(_lib.pn2x_furthest_point_sampling_radii, "fps_kernel", None, B, N, m1, px, i1.data_ptr(),
+                                     radii.data_ptr(), st), "fps_two_level/1")
+        l1 = gather_rows(xyz, i1)
+        _native._check(_lib.pn2x_fps_prefix_ties(B, N, m1, m2, px, i1.data_ptr(), radii.data_ptr(), flags.data_ptr(), st), "fps_two_level/ties")
+        _native._check(_native._call(_lib.pn2x_furthest_point_sampling_prefix, "fps_prefix_kernel", None, B, m1, m2, l1.data_ptr(),
+                                     flags.data_ptr(), nf, i2.data_ptr(), st), "fps_two_level/2")
+    return i1, l1, i2

@@ -93,6 +93,30 @@ int pn2x_three_interpolate_pm(int b, int c, int m, int n, const float *points, i
                               const float *weight, float *out, int ldo, void *stream);
 
 /*
+ * Two-level furthest point sampling without the second pass.  PointNet++ samples level 2 from level 1's samples
+ * (reference backbones.py:98-104: FPS 1024 -> 256, then FPS 256 -> 128 over those 256).  FPS is greedy, and every
+ * pick is the arg-max over ALL remaining points, so it is also the arg-max over the subset of picked points: as long
+ * as no arg-max among the first m2 picks of level 1 was a tie, level 2's sample is exactly level 1's first m2 picks,
+ * in order, i.e. idx2 = 0..m2-1 -- same distances, same min() chain, same floats.  With a tie the two passes may
+ * break it differently (their tie keys use different point numberings), so the second pass is then really run.
+ *   pn2x_furthest_point_sampling_radii : pn2_furthest_point_sampling that also records radii (b, m): radii[i] = the
+ *             running-minimum distance of pick i when it was selected (the maximum of step i); radii[0] is unused.
+ *   pn2x_fps_prefix_ties : given that run (xyz (b,n,3), picks idx1 (b,m1), radii (b,m1)), decide per cloud whether any
+ *             arg-max of picks 1..m2-1 was tied.  With the picks known this has no dependency chain: every point
+ *             replays its running minimum against the picks in order (same sqdist / min chain, same floats) and
+ *             compares it with radii[i]; fully parallel, one workgroup per 256 points.
+ *             flags: (b, pn2x_fps_prefix_flags(n)) ints, one per workgroup, non-zero = tie seen (conservative: a
+ *             duplicate of a pick counts).
+ *   pn2x_furthest_point_sampling_prefix : FPS over xyz (b, n, 3) -> idx (b, m), m <= n, really computed only for
+ *             clouds with a non-zero flag; the others get idx = 0..m-1 (the launch returns at once).
+ * They cover m2 <= 1024 and the register-resident sampling kernels (n <= 16384 points after padding).
+ */
+int pn2x_furthest_point_sampling_radii(int b, int n, int m, const float *xyz, int *idx, float *radii, void *stream);
+int pn2x_fps_prefix_ties(int b, int n, int m1, int m2, const float *xyz, const int *idx1, const float *radii, int *flags, void *stream);
+int pn2x_fps_prefix_flags(int n);
+int pn2x_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz, const int *flags, int nflags, int *idx, void *stream);
+
+/*
  * Row gather on point-major data: out[b, j, :] = src[b, idx[b,j], :]  (src (b,n,c), idx (b,m), out (b,m,c)).
  * The point-major twin of pn2_gather_points (used for the FPS-selected centroid coordinates).
  */

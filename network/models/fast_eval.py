@@ -38,6 +38,7 @@ class FastEval:
         self.P = None
         self._consts = {}
         self._idents = {}
+        self.two_level_fps = True  # level-2 sampling via the prefix property (ext.fps_two_level)
 
     def _palm_idx(self, device):
         key = ("palm", str(device))
@@ -159,7 +160,12 @@ class FastEval:
         # ---- sa1: 1024 -> 256 centroids, r = 0.1, K = 32, MLP [3 -> 32 -> 32 -> 64] ------------------
         p = P["sa1"]
         S1, K1 = bh.sa1.npoint, bh.sa1.nsample_list[0]
-        l1_xyz = ext.gather_rows(xyz2, ops.furthest_point_sample(xyz2, S1))
+        # both sampling levels at once: level 2 (FPS over level 1's samples) is level 1's prefix unless an arg-max tied
+        if self.two_level_fps:
+            _, l1_xyz, i_l2 = ext.fps_two_level(xyz2, S1, bh.sa2.npoint)
+        else:
+            l1_xyz = ext.gather_rows(xyz2, ops.furthest_point_sample(xyz2, S1))
+            i_l2 = ops.furthest_point_sample(l1_xyz, bh.sa2.npoint)
         idx1 = ops.ball_query(bh.sa1.radius_list[0], K1, xyz2, l1_xyz)
         c_l1 = p["l3"][0].shape[0]
         fp2_w = P["fp2"][0][0].shape[1]
@@ -170,7 +176,7 @@ class FastEval:
         # ---- sa2: 256 -> 128, r = 0.2, K = 32, MLP [64+3 -> 64 -> 64 -> 128] ---------------------------
         p = P["sa2"]
         S2, K2 = bh.sa2.npoint, bh.sa2.nsample_list[0]
-        l2_xyz = ext.gather_rows(l1_xyz, ops.furthest_point_sample(l1_xyz, S2))
+        l2_xyz = ext.gather_rows(l1_xyz, i_l2)
         idx2 = ops.ball_query(bh.sa2.radius_list[0], K2, l1_xyz, l2_xyz)
         a1f = F.linear(l1_feat.reshape(B * S1, c_l1), p["w1f"]).view(B, S1, -1)
         c_l2 = p["l3"][0].shape[0]

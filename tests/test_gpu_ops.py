@@ -215,3 +215,38 @@ def test_non_default_stream(ops, oracle):
         got = ops.furthest_point_sample(dev(xyz), 128)
     s.synchronize()
     np.testing.assert_array_equal(got.cpu().numpy(), oracle.furthest_point_sample(xyz, 128))
+
+
+def test_fps_two_level_shortcut():
+    """ext.fps_two_level == FPS(xyz, m1) followed by FPS(xyz[i1], m2), bit for bit, on tie-free clouds (second pass
+    skipped: idx2 = 0..m2-1 must then BE the answer) and on lattice / duplicated clouds (ties -> second pass runs)."""
+    from _cases import cloud
+    from hotrack_amd import ext, pointnet2_utils as ops
+    from oracle import pn2_oracle as O
+    skipped = ran = 0
+    for seed, (B, N, m1, m2, kind) in enumerate([(4, 1024, 256, 128, "uniform"), (4, 1024, 256, 128, "hand"), (3, 1000, 256, 128, "uniform"),
+                                                 (2, 1024, 256, 128, "lattice"), (2, 512, 128, 64, "dup"), (2, 343, 100, 100, "lattice"),
+                                                 (2, 2560, 512, 128, "uniform"), (1, 21, 8, 4, "uniform"), (2, 64, 64, 1, "uniform")]):
+        xyz = cloud(4000 + seed, B, N, kind)
+        d = torch.from_numpy(xyz).cuda()
+        i1, l1, i2 = ext.fps_two_level(d, m1, m2)
+        r1 = ops.furthest_point_sample(d, m1)
+        rl1 = ext.gather_rows(d, r1)
+        r2 = ops.furthest_point_sample(rl1, m2)
+        assert torch.equal(i1, r1) and torch.equal(l1, rl1) and torch.equal(i2, r2), (seed, kind)
+        # and against the oracle's two passes
+        o1 = O.furthest_point_sample(xyz, m1)
+        ol1 = np.take_along_axis(xyz, o1[..., None].astype(np.int64).repeat(3, -1), 1)
+        assert np.array_equal(i2.cpu().numpy(), O.furthest_point_sample(ol1, m2))
+        ident = torch.arange(m2, dtype=torch.int32, device="cuda").expand(B, m2)
+        if kind in ("uniform", "hand"):
+            assert torch.equal(i2, ident)      # the prefix property itself
+            skipped += 1
+        else:
+            ran += 1
+    assert skipped and ran
+    # a mixed batch: cloud 0 generic, cloud 1 a lattice -> per-cloud decision
+    xyz = np.concatenate([cloud(1, 1, 1024, "uniform"), cloud(2, 1, 1024, "lattice")])
+    d = torch.from_numpy(xyz).cuda()
+    i1, l1, i2 = ext.fps_two_level(d, 256, 128)
+    assert torch.equal(i2, ops.furthest_point_sample(ext.gather_rows(d, ops.furthest_point_sample(d, 256)), 128))
