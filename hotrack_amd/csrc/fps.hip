@@ -293,10 +293,12 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
     // One lane per point (T = slots) minimises VALU work per iteration, but the iteration is a latency
     // chain (DPP reduce -> LDS exchange -> barrier), and 4 waves per SIMD serialise it: measured on MI355X
     // (B=64): N=1024 T=1024 107 us, T=256 89 us; N=256 T=256 40 us, T=64 29 us.  So: 4 points per lane.
-    int T = next_pow2((slots + 3) / 4);
-    if (T < 64) T = 64;
-    if (T > 1024) T = 1024;
-    if (force_threads == 64 || force_threads == 256 || force_threads == 1024) {
+    // Measured per (slots) on MI355X, any batch <= 256 clouds (scripts/probes/fps_threads.py):
+    //   512 slots: T=64 39.5 us (one wave, no barrier at all), T=128 45.9;   1024: T=256 90.7, T=128 107, T=512 ~90;
+    //   8192: T=512 1353 us, T=1024 1413.
+    int T = slots <= 512 ? 64 : (slots <= 1024 ? 256 : 512);
+    if (slots > 512 * 16) T = 1024;
+    if (force_threads == 64 || force_threads == 128 || force_threads == 256 || force_threads == 512 || force_threads == 1024) {
         if (force_threads * 16 >= slots) T = force_threads;
     }
     const int P = next_pow2((slots + T - 1) / T);
