@@ -97,6 +97,19 @@ __device__ __forceinline__ int prefix_popc(uint64_t mask) {
 
 // Host-side launch helpers ---------------------------------------------------------------
 void set_last_hip_error(int e);
+// Compute units of the current device (256 on MI355X), cached per device: persistent-grid sizing.
+inline int num_compute_units() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -397,7 +397,7 @@ static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
     }
     // persistent workgroups: weights are loaded into registers once per workgroup
     const int wg_per_cu = (int)((160 * 1024) / lds) < MINW / 2 ? (int)((160 * 1024) / lds) : MINW / 2;
-    const int max_wg = 256 * (wg_per_cu < 1 ? 1 : wg_per_cu);
+    const int max_wg = num_compute_units() * (wg_per_cu < 1 ? 1 : wg_per_cu);
     // Balanced persistent grid: every workgroup runs the same number of tiles (ceil(tiles / rounds)), so the launch
     // takes `rounds` tile-times either way but leaves the CUs a ragged last round would idle to concurrent streams
     // (1344 tiles: 224 workgroups x 6 instead of 256 of which 64 run 6 and 192 run 5).
