@@ -34,6 +34,14 @@ def solve_rot_and_trans(x: torch.Tensor, y: torch.Tensor, cpu: bool = True):
     x = x.expand(y.shape[0], -1, -1).to(y.dtype)
     cx, cy = x.mean(dim=1, keepdim=True), y.mean(dim=1, keepdim=True)
     w = torch.bmm((x - cx).transpose(-1, -2), y - cy)
+    if y.is_cuda and y.dtype == torch.float32:
+        # value from the device kernel, gradient in closed form: no solver-library SVD in the training step
+        from hotrack_amd import ext
+        with torch.no_grad():
+            R0, _ = ext.kabsch(x.contiguous(), y.contiguous())
+        R = _KabschRotation.apply(w, R0)
+        t = cy - torch.bmm(cx, R.transpose(-1, -2))
+        return R, t.transpose(-1, -2)
     u, _, vh = torch.linalg.svd(w)
     v = vh.transpose(-1, -2)
     d = torch.det(torch.bmm(v, u.transpose(-1, -2)))
@@ -42,6 +50,58 @@ def solve_rot_and_trans(x: torch.Tensor, y: torch.Tensor, cpu: bool = True):
     R = torch.bmm(torch.bmm(v, fix), u.transpose(-1, -2))
     t = cy - torch.bmm(cx, R.transpose(-1, -2))
     return R, t.transpose(-1, -2)
+
+
+def _hat(u):
+    """(B,3) -> (B,3,3) skew matrices with hat(u) v = u x v."""
+    z = torch.zeros_like(u[:, 0])
+    return torch.stack([torch.stack([z, -u[:, 2], u[:, 1]], -1), torch.stack([u[:, 2], z, -u[:, 0]], -1),
+                        torch.stack([-u[:, 1], u[:, 0], z], -1)], -2)
+
+
+def _inv3(K):
+    """Closed-form inverse of (B,3,3) matrices (adjugate / determinant): element-wise ops only, so it can be captured
+    into a HIP graph (torch.linalg.inv / solve / svd call the solver library, which cannot)."""
+    a, b, c = K[:, 0, 0], K[:, 0, 1], K[:, 0, 2]
+    d, e, f = K[:, 1, 0], K[:, 1, 1], K[:, 1, 2]
+    g, h, i = K[:, 2, 0], K[:, 2, 1], K[:, 2, 2]
+    A, Bc, C = e * i - f * h, c * h - b * i, b * f - c * e
+    D, E, Fc = f * g - d * i, a * i - c * g, c * d - a * f
+    G, H, I = d * h - e * g, b * g - a * h, a * e - b * d
+    det = a * A + b * D + c * G
+    adj = torch.stack([torch.stack([A, Bc, C], -1), torch.stack([D, E, Fc], -1), torch.stack([G, H, I], -1)], -2)
+    return adj / det[:, None, None]
+
+
+class _KabschRotation(torch.autograd.Function):
+    """R(w) of the Kabsch fit as a differentiable function of the 3x3 cross-covariance w = (x-cx)^T (y-cy), with the
+    value supplied by the caller (device kernel) and the gradient in closed form.
+
+    R = V diag(1,1,d) U^T (w = U S V^T) makes  R w = Sym  symmetric, i.e. w = Q Sym with Q = R^T the polar factor of
+    w.  Differentiating  w = Q Sym :  Q^T dw - dw^T Q = X Sym + Sym X  with X = Q^T dQ skew; in axial vectors
+    x = K^-1 z,  K = tr(Sym) I - Sym,  z = axial(Q^T dw - dw^T Q).  For a loss gradient G = dL/dR this gives
+        dL/dw = 2 Q hat(u),   u = K^-1 axial((B - B^T)/2),   B = Q^T G^T = R G^T
+    -- the same derivative autograd takes through torch.linalg.svd (tests/test_network.py checks it in fp64), without
+    the solver library in either direction: no host round trip, capturable into a HIP graph.
+    """
+
+    @staticmethod
+    def forward(ctx, w, R):
+        ctx.save_for_backward(w, R)
+        return R.clone()
+
+    @staticmethod
+    def backward(ctx, G):
+        w, R = ctx.saved_tensors
+        sym = torch.bmm(R, w)
+        sym = 0.5 * (sym + sym.transpose(-1, -2))
+        tr = sym[:, 0, 0] + sym[:, 1, 1] + sym[:, 2, 2]
+        K = tr[:, None, None] * torch.eye(3, dtype=w.dtype, device=w.device) - sym
+        Bm = torch.bmm(R, G.transpose(-1, -2))
+        P = 0.5 * (Bm - Bm.transpose(-1, -2))
+        p = torch.stack([P[:, 2, 1], P[:, 0, 2], P[:, 1, 0]], -1)
+        u = torch.bmm(_inv3(K), p.unsqueeze(-1)).squeeze(-1)
+        return 2.0 * torch.bmm(R.transpose(-1, -2), _hat(u)), None
 
 
 def ransac_rt(x, y, n=0, cpu=True):

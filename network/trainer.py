@@ -67,9 +67,14 @@ class Trainer(nn.Module):
         elif not cfg["track"]:
             self.model = HandTrackNet(cfg)
             params = [p for p in self.model.parameters() if p.requires_grad]
+            # Whole-step HIP graph (forward + loss + backward + Adam in one replay): the training step is ~800 small
+            # launches and host-bound (about 14 ms of Python / autograd dispatch against 10.4 ms of kernels), so
+            # replaying it removes the host from the loop.  Single process only (DDP's bucketed all-reduce stays eager).
+            self.graph_step = bool(cfg.get("graph_step", os.environ.get("HOTRACK_GRAPH_STEP", "0") == "1"))
+            self._graph = self._graph_sig = self._static = self._static_loss = None
             if cfg["optimizer"] == "Adam":
                 self.optimizer = torch.optim.Adam(params, lr=cfg["learning_rate"], betas=(0.9, 0.999), eps=1e-8,
-                                                  weight_decay=cfg["weight_decay"])
+                                                  weight_decay=cfg["weight_decay"], capturable=self.graph_step)
             else:
                 self.optimizer = torch.optim.SGD(params, lr=cfg["learning_rate"], momentum=0.9)
             self.scheduler = self._make_scheduler()
@@ -123,6 +128,7 @@ class Trainer(nn.Module):
         for m in self.model.modules():
             if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
                 m.momentum = momentum
+        self._graph = None  # learning rate / BN momentum are baked into a captured step: re-capture per epoch
 
     def resume(self, dataset_len=None):
         ckpt = OrderedDict()
@@ -164,9 +170,9 @@ class Trainer(nn.Module):
     def init_flag_dict():
         return {"track_flag": False, "save_flag": False, "test_flag": False, "IKNet_flag": False}
 
-    def update(self, data):
-        self.model.train()
-        self.optimizer.zero_grad()
+    def _step(self, data, zero=True):
+        if zero:
+            self.optimizer.zero_grad()
         flags = self.init_flag_dict()
         if self.ddp is not None:
             loss_dict = self.ddp(data, flags)  # forward + compute_loss inside the DDP-wrapped module
@@ -176,9 +182,72 @@ class Trainer(nn.Module):
         loss_dict = self.summarize_losses(loss_dict)
         loss_dict["total_loss"].backward()  # DDP: bucketed all-reduce overlapped with backward
         self.optimizer.step()
+        return loss_dict
+
+    def update(self, data):
+        self.model.train()
+        loss_dict = None
+        if getattr(self, "graph_step", False) and self.ddp is None and torch.cuda.is_available():
+            try:
+                loss_dict = dict(self._graphed_step(data))
+            except RuntimeError as exc:  # an op of this configuration cannot be captured: stay eager from now on
+                self.log_string(f"graph_step disabled ({exc})")
+                self.graph_step, self._graph = False, None
+                torch.cuda.synchronize()
+        if loss_dict is None:
+            loss_dict = self._step(data)
         self.iteration += 1
         loss_dict["learning_rate"] = self.lr
         return loss_dict
+
+    # ---- whole-step HIP graph ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _leaves(d, prefix=()):
+        for k in sorted(d):
+            v = d[k]
+            if isinstance(v, dict):
+                yield from Trainer._leaves(v, prefix + (k,))
+            elif torch.is_tensor(v):
+                yield prefix + (k,), v
+
+    def _graphed_step(self, data):
+        sig = tuple((path, tuple(t.shape), t.dtype) for path, t in self._leaves(data))
+        if self._graph is None or sig != self._graph_sig:
+            self._capture(data, sig)
+        for (_, dst), (_, src) in zip(self._leaves(self._static), self._leaves(data)):
+            dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        return self._static_loss
+
+    def _capture(self, data, sig):
+        def clone(d):
+            return {k: (clone(v) if isinstance(v, dict) else (v.clone() if torch.is_tensor(v) else v)) for k, v in d.items()}
+
+        self._graph, self._static = None, clone(data)
+        # Warm-up on a side stream (MIOpen / BLAS pick their algorithms, autograd builds its buffers, Adam creates its
+        # state) -- then put every value back, IN PLACE, so the captured step starts from the state update() was called
+        # with and the optimizer state tensors the graph will update already exist (creating them inside the capture
+        # would replay their zero-fill every step).
+        model_snap = {k: v.clone() for k, v in self.model.state_dict().items()}
+        opt_snap = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.optimizer.state.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._step(self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for k, v in self.model.state_dict().items():
+                v.copy_(model_snap[k])
+            for p, st in self.optimizer.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(opt_snap[p][k]) if p in opt_snap else v.zero_()
+        self.optimizer.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_loss = self._step(self._static, zero=False)
+        self._graph, self._graph_sig = graph, sig
 
     def test(self, data, save_flag=False):
         flags = self.init_flag_dict()

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--graph", action="store_true", help="whole-step HIP graph (single GPU)")
     a = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -32,6 +33,7 @@ def main():
     args = add_args(argparse.ArgumentParser()).parse_args(["--config", "handtracknet_train_SimGrasp.yml"])
     args.num_points, args.batch_size = 1024, a.batch
     cfg = get_config(args, save=False)
+    cfg["graph_step"] = a.graph and world == 1
     torch.manual_seed(0)
     tr = Trainer(cfg)
     tr.step_epoch()
@@ -58,7 +60,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "HandTrackNet training frames/sec (N=1024)", "value": round(a.batch * world * a.steps / dt, 1),
                           "unit": "frames/s", "n_gpus": world, "ms_per_step": round(dt / a.steps * 1e3, 2), "per_gpu_batch": a.batch,
-                          "scaling": "weak", "loss": float(loss["total_loss"]), "dtype": "f32", "data": "synthetic"}))
+                          "scaling": "weak", "graph_step": bool(getattr(tr, "graph_step", False)), "loss": float(loss["total_loss"]), "dtype": "f32", "data": "synthetic"}))
     if world > 1:
         dist.destroy_process_group()
 

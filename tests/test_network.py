@@ -163,3 +163,34 @@ def test_gpu_forward_is_deterministic_and_batch_independent():
             assert torch.allclose(a[:1], c, atol=2e-4), float((a[:1] - c).abs().max())
     finally:
         pointnet_utils.set_fused_backend(None)
+
+
+def test_kabsch_rotation_gradient_matches_svd_autograd():
+    """hand_utils._KabschRotation (closed-form gradient of the Kabsch rotation w.r.t. the cross-covariance) against
+    autograd through torch.linalg.svd, fp64 on CPU, incl. a reflected (det < 0) configuration."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "network"))
+    from models import hand_utils as hu
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 6, 3, generator=g, dtype=torch.float64)
+    y = torch.randn(5, 6, 3, generator=g, dtype=torch.float64)
+    y[1] = x[1] @ torch.diag(torch.tensor([1.0, 1.0, -1.0], dtype=torch.float64)) + 0.01 * y[1]   # near-mirror image: d = -1 branch
+
+    def fit(w, closed_form):
+        u, _, vh = torch.linalg.svd(w)
+        v = vh.transpose(-1, -2)
+        d = torch.det(torch.bmm(v, u.transpose(-1, -2)))
+        fix = torch.eye(3, dtype=w.dtype).repeat(w.shape[0], 1, 1)
+        fix[:, 2, 2] = d
+        R = torch.bmm(torch.bmm(v, fix), u.transpose(-1, -2))
+        return hu._KabschRotation.apply(w, R.detach()) if closed_form else R
+
+    cx, cy = x.mean(1, keepdim=True), y.mean(1, keepdim=True)
+    grads = []
+    for closed_form in (False, True):
+        w = torch.bmm((x - cx).transpose(-1, -2), y - cy).requires_grad_(True)
+        R = fit(w, closed_form)
+        loss = (R * torch.arange(9, dtype=torch.float64).view(1, 3, 3)).sum() + (R[:, 0] * R[:, 1]).sum() + (R ** 3).sum()
+        loss.backward()
+        grads.append(w.grad.clone())
+    torch.testing.assert_close(grads[1], grads[0], rtol=1e-9, atol=1e-9)
