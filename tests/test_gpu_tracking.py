@@ -156,3 +156,25 @@ def test_graph_step_trains_like_eager(tmp_path, monkeypatch):
     assert float(se) == float(sg) == 5.0
     # parameters the reference never uses keep grad None (DDP contract) under capture too
     assert sum(p.grad is None for p in graph.model.parameters()) == sum(p.grad is None for p in eager.model.parameters()) > 0
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver and the judge read (short run, no CPU leg)."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "frames/s" and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["per_gpu_batch"] * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
