@@ -237,9 +237,14 @@ sa_mlp_max_kernel(const SaArgs A) {
     // The two roles run SEPARATE loops (same trip count, two s_barriers per tile each), so the register
     // allocator does not have to keep the COMPUTE role's resident weights alive through the LOAD role's code.
     if (!compute) {
-        // the LOAD waves issue few instructions but each is latency-critical: let them win issue arbitration
-        // against the co-resident MFMA stream (measured: gather 12k -> ~5k cycles per half tile)
-        __builtin_amdgcn_s_setprio(3);
+        // Wave priority of the LOAD role.  Before its loop was software-pipelined it needed s_setprio(3) to get its
+        // (then latency-critical) loads issued between the MFMAs; now its loads run one to two half-tiles ahead and
+        // the matrix-core role is the critical path, so default priority is better (sweep, profiles/r01_misc_measurements.md:
+        // prio 0 / 1 / 3 -> K=64 launch 71.2 / 72.5 / 72.6 us, sa1 37.8 / 39.6 / 39.7 us).
+#ifndef SA_LOADER_PRIO
+#define SA_LOADER_PRIO 0
+#endif
+        __builtin_amdgcn_s_setprio(SA_LOADER_PRIO);
         // pipeline fill: rows of the first half and indices of the second half of the first tile this loop gathers
         HalfIdx I0, I1;
         HalfRows D0, D1;
@@ -267,6 +272,9 @@ sa_mlp_max_kernel(const SaArgs A) {
         }
         return;
     }
+#ifdef SA_COMPUTE_PRIO
+    __builtin_amdgcn_s_setprio(SA_COMPUTE_PRIO);
+#endif
     int it = 0;
     for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, ++it) {
         stamp(it, 0);
