@@ -434,6 +434,9 @@ static int launch_sa(int b, const SaArgs &a, hipStream_t st) {
     return PN2_ERANGE;
 }
 
+#ifndef SA_NB1
+#define SA_NB1 2  /* H1 ring depth; 3 measured no better (profiles/r01_misc_measurements.md) */
+#endif
 static long long *g_sa_trace = nullptr;
 }  // namespace pn2
 
@@ -459,9 +462,9 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
     a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out; a.out_b = out_b; a.out_s = out_s; a.out_c = out_c;
     a.num_tiles = 0; a.tiles_per_cloud = 0; a.trace = g_sa_trace;
     hipStream_t st = (hipStream_t)stream;
-    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2, 4, 4, 2>(b, a, st);
-    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4, 2, 4, 2>(b, a, st);
-    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4, 2, 2, 2>(b, a, st);
+    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2, 4, 4, SA_NB1>(b, a, st);
+    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4, 2, 4, SA_NB1>(b, a, st);
+    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4, 2, 2, SA_NB1>(b, a, st);
     return PN2_ERANGE;
 }
 
