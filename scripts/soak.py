@@ -1,0 +1,78 @@
+"""Soak test (not part of pytest): minutes of randomised launches looking for rare failures -- races in the SA kernel's
+two-role pipeline, the optimiser's last-workgroup protocol, the two-level FPS shortcut.  usage: python scripts/soak.py [seconds]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from _sdf_cases import make_volume, object_points, random_pose  # noqa: E402
+from hotrack_amd import ext, sdf, pointnet2_utils as ops  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+t_end = time.time() + budget
+rng = np.random.default_rng(12345)
+g = torch.Generator().manual_seed(999)
+n_sa = n_opt = n_fps = 0
+vol = torch.from_numpy(make_volume(81, 0.005, "capsule", np.float16)).cuda()
+cvol = sdf.CornerVolume(vol)
+while time.time() < t_end:
+    # ---- fused SA kernel vs an unfused torch evaluation of the same thing, random shapes / operand sets ----
+    C1, C2, C3 = [(32, 32, 64), (64, 64, 128), (128, 128, 192)][rng.integers(3)]
+    K = int(rng.choice([16, 32, 64]))
+    B, N, S = int(rng.integers(1, 70)), int(rng.integers(8, 1200)), int(rng.integers(1, 300))
+    mode = int(rng.integers(3))
+    idx = torch.randint(0, N, (B, S, K), generator=g, dtype=torch.int32).cuda()
+    xyz, cxyz = torch.rand(B, N, 3, generator=g).cuda(), torch.rand(B, S, 3, generator=g).cuda()
+    wx, b1 = torch.randn(C1, 3, generator=g).cuda(), torch.randn(C1, generator=g).cuda()
+    a1f = torch.randn(B, N, C1, generator=g).cuda() if mode >= 1 else None
+    cadd = torch.randn(B, S, C1, generator=g).cuda() if mode == 2 else None
+    w2, b2 = (torch.randn(C2, C1, generator=g) * 0.1).cuda(), torch.randn(C2, generator=g).cuda()
+    w3, b3 = (torch.randn(C3, C2, generator=g) * 0.1).cuda(), torch.randn(C3, generator=g).cuda()
+    got = ext.sa_mlp_max(idx, w2, b2, w3, b3, a1f=a1f, xyz=xyz, cxyz=cxyz, wx=wx, b1=b1, cadd=cadd, point_major=True)
+    li = idx.long()
+    bi = torch.arange(B, device="cuda")[:, None, None]
+    h1 = (xyz[bi, li] - cxyz[:, :, None]) @ wx.t() + b1
+    if a1f is not None:
+        h1 = h1 + a1f[bi, li]
+    if cadd is not None:
+        h1 = h1 + cadd[:, :, None]
+    ref = torch.relu(torch.relu(torch.relu(h1) @ w2.t() + b2) @ w3.t() + b3).max(dim=2)[0]
+    err = float((got - ref).abs().max())
+    assert err <= 2e-4 * max(1.0, float(ref.abs().max())), ("sa_mlp_max", (B, N, S, K, C1, mode), err)
+    again = ext.sa_mlp_max(idx, w2, b2, w3, b3, a1f=a1f, xyz=xyz, cxyz=cxyz, wx=wx, b1=b1, cadd=cadd, point_major=True)
+    assert torch.equal(got, again), "sa_mlp_max not deterministic"
+    n_sa += 1
+    # ---- optimiser loop: bitwise repeatable (fixed reduction order, ticket protocol) ----
+    if n_sa % 4 == 0:
+        P, Np = int(rng.choice([64, 257, 2048])), int(rng.integers(16, 1500))
+        pc = object_points(int(rng.integers(1 << 30)), Np, "capsule")
+        R0, t0 = random_pose(int(rng.integers(1 << 30)))
+        cam = torch.from_numpy((pc @ R0.T + t0).astype(np.float32)).cuda()
+        pre = torch.randn(P, 6, generator=g).cuda()
+        pre[0] = 0
+        a = sdf.obj_optimize(cam, torch.from_numpy(R0).cuda(), torch.from_numpy(t0).cuda(), pre, cvol, 0.005)
+        b = sdf.obj_optimize(cam, torch.from_numpy(R0).cuda(), torch.from_numpy(t0).cuda(), pre, cvol, 0.005)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "obj_optimize not repeatable"
+        assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+        n_opt += 1
+    # ---- two-level FPS on clouds with planted duplicates / lattice patches ----
+    if n_sa % 2 == 0:
+        Bf, Nf = int(rng.integers(1, 9)), int(rng.choice([256, 700, 1024, 2048]))
+        x = torch.rand(Bf, Nf, 3, generator=g)
+        if rng.random() < 0.5:
+            x[:, : Nf // 3] = torch.round(x[:, : Nf // 3] * 6) / 6       # lattice patch -> exact ties
+        if rng.random() < 0.3:
+            x[:, Nf // 2:] = x[:, : Nf - Nf // 2]                          # duplicates
+        x = x.cuda()
+        m1 = int(rng.integers(2, min(Nf, 512)))
+        m2 = int(rng.integers(1, m1 + 1))
+        i1, l1, i2 = ext.fps_two_level(x, m1, m2)
+        r1 = ops.furthest_point_sample(x, m1)
+        assert torch.equal(i1, r1) and torch.equal(i2, ops.furthest_point_sample(ext.gather_rows(x, r1), m2)), ("fps_two_level", Bf, Nf, m1, m2)
+        n_fps += 1
+torch.cuda.synchronize()
+print(f"soak ok: {n_sa} SA launches x2, {n_opt} optimiser pairs, {n_fps} two-level FPS cases in {budget:.0f} s")
