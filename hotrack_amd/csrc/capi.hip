@@ -85,7 +85,7 @@ int pn2x_fps_prefix_ties(int b, int n, int m1, int m2, const float *xyz, const i
     return fps_tie_check(b, n, m2, m1, xyz, idx1, radii, flags, (hipStream_t)stream);
 }
 
-int pn2x_fps_prefix_flags(int n) { return n < 1 ? PN2_EINVAL : (n + 255) / 256; }
+int pn2x_fps_prefix_flags(int n) { return n < 1 ? PN2_EINVAL : (n + 63) / 64; }  // one per tie-check workgroup (64 points)
 
 int pn2x_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz, const int *flags, int nflags, int *idx, void *stream) {
     PN2_REQ(b >= 0 && n >= 1 && m >= 0 && m <= n && nflags >= 1, PN2_EINVAL);

@@ -60,6 +60,18 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Full wave64 fp32 sum, same DPP ladder (6 v_add_f32_dpp, no LDS crossbar); wave-uniform result.  The summation order
+// is fixed (butterfly inside each row of 16, then rows 0+1, 2+3, then halves), so results are run-to-run identical.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    PN2_DPP_STEP("v_add_f32_dpp", v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    PN2_DPP_STEP("v_add_f32_dpp", v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    PN2_DPP_STEP("v_add_f32_dpp", v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+    PN2_DPP_STEP("v_add_f32_dpp", v, "row_mirror row_mask:0xf bank_mask:0xf");
+    PN2_DPP_STEP("v_add_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    PN2_DPP_STEP("v_add_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // fminf without the v_max canonicalisation hipcc inserts in IEEE mode (operands are never sNaN here).
 __device__ __forceinline__ float fmin_raw(float a, float b) {
     float r;

@@ -9,11 +9,7 @@
 
 namespace pn2 {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_f32(v); }  // DPP ladder, no ds_bpermute round trips
 
 // One wave per row; C <= 64 * EPL.  torch.nn.functional.layer_norm semantics: biased variance, eps inside the sqrt.
 template <int EPL>

@@ -104,7 +104,8 @@ int pn2x_three_interpolate_pm(int b, int c, int m, int n, const float *points, i
  *   pn2x_fps_prefix_ties : given that run (xyz (b,n,3), picks idx1 (b,m1), radii (b,m1)), decide per cloud whether any
  *             arg-max of picks 1..m2-1 was tied.  With the picks known this has no dependency chain: every point
  *             replays its running minimum against the picks in order (same sqdist / min chain, same floats) and
- *             compares it with radii[i]; fully parallel, one workgroup per 256 points.
+ *             compares it with radii[i]; fully parallel (the prefix-min is also split over four threads per point), one workgroup
+ *             per 64 points.
  *             flags: (b, pn2x_fps_prefix_flags(n)) ints, one per workgroup, non-zero = tie seen (conservative: a
  *             duplicate of a pick counts).
  *   pn2x_furthest_point_sampling_prefix : FPS over xyz (b, n, 3) -> idx (b, m), m <= n, really computed only for
