@@ -114,6 +114,13 @@ class FastEval:
             c[i] = torch.cat([self.P["wq"][i], self.P["wq"][2 + i]], dim=0).contiguous()
         return c[i]
 
+    def _perm_idx(self, perm, B):
+        """(B, J*re) int32 row indices of rearrange_module's token gather (perm (J, re)), cached per batch size."""
+        key = ("perm", B, str(perm.device))
+        if key not in self._idents:
+            self._idents[key] = perm.reshape(1, -1).to(torch.int32).expand(B, -1).contiguous()
+        return self._idents[key]
+
     def _ident(self, B, J, K, dev):
         """(B, J, K) int32 identity neighbour index for slot-major gathered rows (row j*K + k of each cloud)."""
         key = (B, J, K, str(dev))
@@ -245,7 +252,7 @@ class FastEval:
             ext.sa_mlp_max(idx, *p["l2"], *p["l3"], a1f=a[:, :, :c1q], xyz=nb_xyz, cxyz=xyz1,
                            wx=p["wx"], b1=p["b1"], out=f11[:, :, i * c_q:(i + 1) * c_q])
         Wr, br, perm = P["r1"]
-        f12 = F.linear(f11[:, perm].reshape(B * J, -1), Wr, br)  # (B*J, C)
+        f12 = F.linear(ext.gather_rows(f11, self._perm_idx(perm, B)).view(B * J, -1), Wr, br)  # (B*J, C)
         cadd = F.linear(f12, P["wc2"]).view(B, J, -1)
         f13 = torch.empty((B, J, 2 * c_q), **f32)
         for i, (idx, a, nb_xyz) in enumerate(plan):
@@ -253,7 +260,7 @@ class FastEval:
             ext.sa_mlp_max(idx, *p["l2"], *p["l3"], a1f=a[:, :, c1q:2 * c1q], xyz=nb_xyz, cxyz=xyz1,
                            wx=p["wx"], b1=p["b1"], cadd=cadd[:, :, i * c1q:(i + 1) * c1q], out=f13[:, :, i * c_q:(i + 1) * c_q])
         Wr, br, perm = P["r2"]
-        f14 = F.linear(f13[:, perm].reshape(B * J, -1), Wr, br)
+        f14 = F.linear(ext.gather_rows(f13, self._perm_idx(perm, B)).view(B * J, -1), Wr, br)
 
         # ---- "TransT" with attn=False: only LayerNorms and FFNs are live; the element-wise runs between the GEMMs
         # (residual add, bias, one or two LayerNorms) are one launch each --------------------------------------
