@@ -20,14 +20,19 @@ constexpr int kBqTile = 4096;  // points per LDS tile: 48 KiB -> 3 workgroups / 
 template <int CPW>  // centroids per wave
 __global__ void __launch_bounds__(kBqThreads)
 ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz_all,
-                  const float *__restrict__ xyz_all, int *__restrict__ idx_all) {
+                  const float *__restrict__ xyz_all, int *__restrict__ idx_all, const int *__restrict__ picks_all,
+                  float *__restrict__ new_xyz_out_all) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile_cap = n < kBqTile ? n : kBqTile;
     float *sx = smem, *sy = smem + tile_cap, *sz = smem + 2 * tile_cap;
 
     const int b = blockIdx.y;
     const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
-    const float *__restrict__ new_xyz = new_xyz_all + (size_t)b * m * 3;
+    // centroids either given by coordinates (the reference operator) or as indices into this cloud (`picks`, the
+    // output of FPS -- pn2x_ball_query_picks), in which case their coordinates are also written out: the gather
+    // launch that follows FPS in the reference (pointnet_utils.py:379) is folded into the query
+    const float *__restrict__ new_xyz = picks_all ? nullptr : new_xyz_all + (size_t)b * m * 3;
+    const int *__restrict__ picks = picks_all ? picks_all + (size_t)b * m : nullptr;
     int *__restrict__ idx = idx_all + (size_t)b * m * nsample;
 
     const int tid = threadIdx.x;
@@ -41,9 +46,14 @@ ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restr
     for (int c = 0; c < CPW; ++c) {
         const int s = c_base + c * kBqWaves + w;
         const bool ok = s < m;
-        cx[c] = ok ? new_xyz[3 * s + 0] : 0.f;
-        cy[c] = ok ? new_xyz[3 * s + 1] : 0.f;
-        cz[c] = ok ? new_xyz[3 * s + 2] : 0.f;
+        const float *__restrict__ src = !ok ? nullptr : (picks ? xyz + 3 * (size_t)picks[s] : new_xyz + 3 * (size_t)s);
+        cx[c] = ok ? src[0] : 0.f;
+        cy[c] = ok ? src[1] : 0.f;
+        cz[c] = ok ? src[2] : 0.f;
+        if (ok && picks && lane == 0) {
+            float *o = new_xyz_out_all + ((size_t)b * m + s) * 3;
+            o[0] = cx[c]; o[1] = cy[c]; o[2] = cz[c];
+        }
         cnt[c] = ok ? 0 : nsample;  // out-of-range centroids are "done"
         first[c] = 0;
     }
@@ -94,7 +104,7 @@ ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restr
 }
 
 int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                        const float *xyz, int *idx, hipStream_t st) {
+                        const float *xyz, int *idx, hipStream_t st, const int *picks, float *new_xyz_out) {
     if (b == 0 || m == 0) return PN2_OK;
     const float radius2 = radius * radius;  // fp32 product, ball_query_gpu.cu:23
     const int tile_cap = n < kBqTile ? n : kBqTile;
@@ -107,11 +117,11 @@ int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const fl
     const int per_block = kBqWaves * cpw;
     dim3 grid((m + per_block - 1) / per_block, b);
     if (cpw == 4)
-        hipLaunchKernelGGL(ball_query_kernel<4>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx);
+        hipLaunchKernelGGL(ball_query_kernel<4>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out);
     else if (cpw == 2)
-        hipLaunchKernelGGL(ball_query_kernel<2>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx);
+        hipLaunchKernelGGL(ball_query_kernel<2>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out);
     else
-        hipLaunchKernelGGL(ball_query_kernel<1>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx);
+        hipLaunchKernelGGL(ball_query_kernel<1>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out);
     return check_launch();
 }
 

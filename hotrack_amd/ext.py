@@ -264,10 +264,31 @@ _lib.pn2x_furthest_point_sampling_prefix.argtypes = [_ci, _ci, _ci, _vp, _vp, _c
 _lib.pn2x_furthest_point_sampling_prefix.restype = _ci
 
 
-def fps_two_level(xyz: torch.Tensor, m1: int, m2: int):
+_lib.pn2x_ball_query_picks.argtypes = [_ci, _ci, _ci, ctypes.c_float, _ci, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_ball_query_picks.restype = _ci
+
+
+def ball_query_picks(radius: float, nsample: int, xyz: torch.Tensor, picks: torch.Tensor):
+    """Ball query around the centroids xyz[picks] (picks (B,S) int32 from FPS) -> (idx (B,S,nsample) int32,
+    new_xyz (B,S,3) = the centroids' coordinates): pointnet2_utils.ball_query + the gather before it, one launch."""
+    B, N, _ = xyz.shape
+    S = picks.shape[1]
+    px = _native._ptr(xyz, "xyz", torch.float32, B * N * 3)
+    pp = _native._ptr(picks, "picks", torch.int32, B * S)
+    idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
+    new_xyz = torch.empty((B, S, 3), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _native._check(_lib.pn2x_ball_query_picks(B, N, S, float(radius), nsample, px, pp, new_xyz.data_ptr(), idx.data_ptr(),
+                                                  _native._stream(xyz)), "ball_query_picks")
+    return idx, new_xyz
+
+
+def fps_two_level(xyz: torch.Tensor, m1: int, m2: int, query=None):
     """The reference's two chained samplings  i1 = FPS(xyz, m1); l1 = xyz[i1]; i2 = FPS(l1, m2)  (backbones.py:98-104)
     -> (i1 (B,m1), l1 (B,m1,3), i2 (B,m2)) int32/float32, bit-identical to running both.  The second pass is
-    skipped per cloud when level 1 had no tied arg-max among its first m2 picks (include/pn2_ext.h)."""
+    skipped per cloud when level 1 had no tied arg-max among its first m2 picks (include/pn2_ext.h).
+    query=(radius, nsample): level 1's ball query is done by the launch that produces l1 (ball_query_picks) and its
+    index tensor (B,m1,nsample) is returned as a fourth value."""
     from . import pointnet2_utils as ops
     B, N, _ = xyz.shape
     if not 1 <= m2 <= m1:
@@ -276,7 +297,8 @@ def fps_two_level(xyz: torch.Tensor, m1: int, m2: int):
     if m2 > 1024 or N > 16384:  # beyond the shortcut's kernels: two plain passes
         i1 = ops.furthest_point_sample(xyz, m1)
         l1 = gather_rows(xyz, i1)
-        return i1, l1, ops.furthest_point_sample(l1, m2)
+        i2 = ops.furthest_point_sample(l1, m2)
+        return (i1, l1, i2) if query is None else (i1, l1, i2, ops.ball_query(query[0], query[1], xyz, l1))
     px = _native._ptr(xyz, "xyz", torch.float32, B * N * 3)
     nf = _lib.pn2x_fps_prefix_flags(N)
     i1 = torch.empty((B, m1), dtype=torch.int32, device=xyz.device)
@@ -287,8 +309,11 @@ def fps_two_level(xyz: torch.Tensor, m1: int, m2: int):
         st = _native._stream(xyz)
         _native._check(_native._call(_lib.pn2x_furthest_point_sampling_radii, "fps_kernel", None, B, N, m1, px, i1.data_ptr(),
                                      radii.data_ptr(), st), "fps_two_level/1")
-        l1 = gather_rows(xyz, i1)
+        if query is None:
+            l1 = gather_rows(xyz, i1)
+        else:
+            idx1, l1 = ball_query_picks(query[0], query[1], xyz, i1)
         _native._check(_lib.pn2x_fps_prefix_ties(B, N, m1, m2, px, i1.data_ptr(), radii.data_ptr(), flags.data_ptr(), st), "fps_two_level/ties")
         _native._check(_native._call(_lib.pn2x_furthest_point_sampling_prefix, "fps_prefix_kernel", None, B, m1, m2, l1.data_ptr(),
                                      flags.data_ptr(), nf, i2.data_ptr(), st), "fps_two_level/2")
-    return i1, l1, i2
+    return (i1, l1, i2) if query is None else (i1, l1, i2, idx1)

@@ -118,6 +118,14 @@ int pn2x_fps_prefix_flags(int n);
 int pn2x_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz, const int *flags, int nflags, int *idx, void *stream);
 
 /*
+ * pn2_ball_query whose centroids are given as indices into the cloud itself (picks (b, m) int32, values in [0, n):
+ * the output of FPS), which is how PointNet++ always calls it (pointnet_utils.py:379-382: sample, gather, query).
+ * Also writes the centroids' coordinates new_xyz (b, m, 3) = xyz[picks], so the gather launch disappears.
+ */
+int pn2x_ball_query_picks(int b, int n, int m, float radius, int nsample, const float *xyz, const int *picks, float *new_xyz,
+                          int *idx, void *stream);
+
+/*
  * Row gather on point-major data: out[b, j, :] = src[b, idx[b,j], :]  (src (b,n,c), idx (b,m), out (b,m,c)).
  * The point-major twin of pn2_gather_points (used for the FPS-selected centroid coordinates).
  */

@@ -169,11 +169,13 @@ class FastEval:
         S1, K1 = bh.sa1.npoint, bh.sa1.nsample_list[0]
         # both sampling levels at once: level 2 (FPS over level 1's samples) is level 1's prefix unless an arg-max tied
         if self.two_level_fps:
-            _, l1_xyz, i_l2 = ext.fps_two_level(xyz2, S1, bh.sa2.npoint)
+            # sampling level 1 -> ball query level 1 (which also emits the centroids' coordinates) -> tie check ->
+            # sampling level 2 (a no-op launch unless an arg-max tied): no gather launches
+            _, l1_xyz, i_l2, idx1 = ext.fps_two_level(xyz2, S1, bh.sa2.npoint, query=(bh.sa1.radius_list[0], K1))
         else:
             l1_xyz = ext.gather_rows(xyz2, ops.furthest_point_sample(xyz2, S1))
             i_l2 = ops.furthest_point_sample(l1_xyz, bh.sa2.npoint)
-        idx1 = ops.ball_query(bh.sa1.radius_list[0], K1, xyz2, l1_xyz)
+            idx1 = ops.ball_query(bh.sa1.radius_list[0], K1, xyz2, l1_xyz)
         c_l1 = p["l3"][0].shape[0]
         fp2_w = P["fp2"][0][0].shape[1]
         fp2_in = torch.empty((B, S1, fp2_w), **f32)  # [l1_feat | interp(l2 -> l1)]
@@ -183,8 +185,7 @@ class FastEval:
         # ---- sa2: 256 -> 128, r = 0.2, K = 32, MLP [64+3 -> 64 -> 64 -> 128] ---------------------------
         p = P["sa2"]
         S2, K2 = bh.sa2.npoint, bh.sa2.nsample_list[0]
-        l2_xyz = ext.gather_rows(l1_xyz, i_l2)
-        idx2 = ops.ball_query(bh.sa2.radius_list[0], K2, l1_xyz, l2_xyz)
+        idx2, l2_xyz = ext.ball_query_picks(bh.sa2.radius_list[0], K2, l1_xyz, i_l2)
         a1f = F.linear(l1_feat.reshape(B * S1, c_l1), p["w1f"]).view(B, S1, -1)
         c_l2 = p["l3"][0].shape[0]
         l2_feat = torch.empty((B, S2, c_l2), **f32)

@@ -250,3 +250,19 @@ def test_fps_two_level_shortcut():
     d = torch.from_numpy(xyz).cuda()
     i1, l1, i2 = ext.fps_two_level(d, 256, 128)
     assert torch.equal(i2, ops.furthest_point_sample(ext.gather_rows(d, ops.furthest_point_sample(d, 256)), 128))
+
+
+def test_ball_query_picks_matches_gather_then_query():
+    from _cases import cloud
+    from hotrack_amd import ext, pointnet2_utils as ops
+    for seed, (B, N, S, r, K, kind) in enumerate([(4, 1024, 256, 0.1, 32, "hand"), (3, 256, 128, 0.2, 32, "hand"), (2, 5000, 300, 0.05, 64, "uniform"),
+                                                  (2, 300, 7, 0.3, 1, "lattice"), (1, 21, 21, 0.5, 16, "uniform")]):
+        d = torch.from_numpy(cloud(8000 + seed, B, N, kind)).cuda()
+        picks = ops.furthest_point_sample(d, S)
+        idx, new_xyz = ext.ball_query_picks(r, K, d, picks)
+        ref_xyz = ext.gather_rows(d, picks)
+        assert torch.equal(new_xyz, ref_xyz)
+        assert torch.equal(idx, ops.ball_query(r, K, d, ref_xyz))
+    d = torch.from_numpy(cloud(1, 2, 1024, "uniform")).cuda()
+    i1, l1, i2, idx1 = ext.fps_two_level(d, 256, 128, query=(0.1, 32))
+    assert torch.equal(idx1, ops.ball_query(0.1, 32, d, l1)) and torch.equal(l1, ext.gather_rows(d, i1))
