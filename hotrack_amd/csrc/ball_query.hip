@@ -21,7 +21,7 @@ template <int CPW>  // centroids per wave
 __global__ void __launch_bounds__(kBqThreads)
 ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz_all,
                   const float *__restrict__ xyz_all, int *__restrict__ idx_all, const int *__restrict__ picks_all,
-                  float *__restrict__ new_xyz_out_all) {
+                  float *__restrict__ new_xyz_out_all, float *__restrict__ new_xyz_copy, int copy_ld) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile_cap = n < kBqTile ? n : kBqTile;
     float *sx = smem, *sy = smem + tile_cap, *sz = smem + 2 * tile_cap;
@@ -53,6 +53,10 @@ ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restr
         if (ok && picks && lane == 0) {
             float *o = new_xyz_out_all + ((size_t)b * m + s) * 3;
             o[0] = cx[c]; o[1] = cy[c]; o[2] = cz[c];
+            if (new_xyz_copy) {  // second copy into three columns of a consumer's wider row buffer
+                float *o2 = new_xyz_copy + ((size_t)b * m + s) * copy_ld;
+                o2[0] = cx[c]; o2[1] = cy[c]; o2[2] = cz[c];
+            }
         }
         cnt[c] = ok ? 0 : nsample;  // out-of-range centroids are "done"
         first[c] = 0;
@@ -104,7 +108,8 @@ ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restr
 }
 
 int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                        const float *xyz, int *idx, hipStream_t st, const int *picks, float *new_xyz_out) {
+                        const float *xyz, int *idx, hipStream_t st, const int *picks, float *new_xyz_out, float *new_xyz_copy,
+                        int copy_ld) {
     if (b == 0 || m == 0) return PN2_OK;
     const float radius2 = radius * radius;  // fp32 product, ball_query_gpu.cu:23
     const int tile_cap = n < kBqTile ? n : kBqTile;
@@ -117,11 +122,11 @@ int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const fl
     const int per_block = kBqWaves * cpw;
     dim3 grid((m + per_block - 1) / per_block, b);
     if (cpw == 4)
-        hipLaunchKernelGGL(ball_query_kernel<4>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out);
+        hipLaunchKernelGGL(ball_query_kernel<4>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out, new_xyz_copy, copy_ld);
     else if (cpw == 2)
-        hipLaunchKernelGGL(ball_query_kernel<2>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out);
+        hipLaunchKernelGGL(ball_query_kernel<2>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out, new_xyz_copy, copy_ld);
     else
-        hipLaunchKernelGGL(ball_query_kernel<1>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out);
+        hipLaunchKernelGGL(ball_query_kernel<1>, grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out, new_xyz_copy, copy_ld);
     return check_launch();
 }
 

@@ -13,7 +13,7 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
                  const int *skip_flags, int nflags, float *radii);
 int fps_tie_check(int b, int n, int m, int m1, const float *xyz, const int *idx, const float *radii, int *flags, hipStream_t st);
 int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
-                        int *idx, hipStream_t st, const int *picks, float *new_xyz_out);
+                        int *idx, hipStream_t st, const int *picks, float *new_xyz_out, float *new_xyz_copy, int copy_ld);
 int three_nn_dispatch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
                       hipStream_t st, bool weights);
 int interp_pm_dispatch(int b, int c, int m, int n, const float *points, int ldp, const int *idx, const float *weight,
@@ -103,18 +103,27 @@ int pn2_ball_query(int b, int n, int m, float radius, int nsample, const float *
     PN2_REQ(new_xyz && xyz && idx, PN2_ENULL);
     PN2_REQ(b <= 65535, PN2_ERANGE);
     PN2_REQ(fits_int((long)n * 3) && fits_int((long)m * nsample), PN2_ERANGE);
-    return ball_query_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream, nullptr, nullptr);
+    return ball_query_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream, nullptr, nullptr, nullptr, 0);
 }
+
+int pn2x_ball_query_picks2(int b, int n, int m, float radius, int nsample, const float *xyz, const int *picks, float *new_xyz,
+                           int *idx, float *new_xyz_copy, int copy_ld, void *stream);
 
 int pn2x_ball_query_picks(int b, int n, int m, float radius, int nsample, const float *xyz, const int *picks, float *new_xyz,
                           int *idx, void *stream) {
+    return pn2x_ball_query_picks2(b, n, m, radius, nsample, xyz, picks, new_xyz, idx, nullptr, 0, stream);
+}
+
+int pn2x_ball_query_picks2(int b, int n, int m, float radius, int nsample, const float *xyz, const int *picks, float *new_xyz,
+                           int *idx, float *new_xyz_copy, int copy_ld, void *stream) {
+    PN2_REQ(!new_xyz_copy || copy_ld >= 3, PN2_EINVAL);
     PN2_REQ(b >= 0 && n >= 1 && m >= 0 && nsample >= 1, PN2_EINVAL);
     PN2_REQ(radius == radius, PN2_EINVAL);
     if (b == 0 || m == 0) return PN2_OK;
     PN2_REQ(xyz && picks && new_xyz && idx, PN2_ENULL);
     PN2_REQ(b <= 65535, PN2_ERANGE);
     PN2_REQ(fits_int((long)n * 3) && fits_int((long)m * nsample), PN2_ERANGE);
-    return ball_query_dispatch(b, n, m, radius, nsample, nullptr, xyz, idx, (hipStream_t)stream, picks, new_xyz);
+    return ball_query_dispatch(b, n, m, radius, nsample, nullptr, xyz, idx, (hipStream_t)stream, picks, new_xyz, new_xyz_copy, copy_ld);
 }
 
 int pn2_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,

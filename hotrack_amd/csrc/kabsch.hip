@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256)
 hand_frame_kernel(int xb, int num, int n, int j, const float *__restrict__ tmpl_all, const float *__restrict__ kp_all,
                   const int *__restrict__ palm_idx, const float *__restrict__ pts_all, float scale,
                   float *__restrict__ R_all, float *__restrict__ t_all, float *__restrict__ xyz2_all,
-                  float *__restrict__ xyz1_all) {
+                  float *__restrict__ xyz1_all, float *__restrict__ xyz2_copy, int copy_ld) {
     __shared__ float sR[9], st[3];
     __shared__ float sy[16 * 3];
     const int b = blockIdx.x;
@@ -147,9 +147,14 @@ hand_frame_kernel(int xb, int num, int n, int j, const float *__restrict__ tmpl_
         float *o = i < n ? o2 + 3 * i : o1 + 3 * (i - n);
         const float d0 = p[0] - t0, d1 = p[1] - t1, d2 = p[2] - t2;
         // (R^T d)_c = sum_a R[a][c] d_a, accumulated in index order like the reference's matmul
-        o[0] = (d0 * r00 + d1 * r10 + d2 * r20) / scale;
-        o[1] = (d0 * r01 + d1 * r11 + d2 * r21) / scale;
-        o[2] = (d0 * r02 + d1 * r12 + d2 * r22) / scale;
+        const float v0 = (d0 * r00 + d1 * r10 + d2 * r20) / scale;
+        const float v1 = (d0 * r01 + d1 * r11 + d2 * r21) / scale;
+        const float v2 = (d0 * r02 + d1 * r12 + d2 * r22) / scale;
+        o[0] = v0; o[1] = v1; o[2] = v2;
+        if (xyz2_copy && i < n) {  // second copy straight into a consumer's row buffer (three columns of a wider row)
+            float *c = xyz2_copy + ((size_t)b * n + i) * copy_ld;
+            c[0] = v0; c[1] = v1; c[2] = v2;
+        }
     }
 }
 
@@ -163,13 +168,24 @@ extern "C" int pn2x_kabsch(int b, int xb, int num, const float *x, const float *
     return pn2::check_launch();
 }
 
+extern "C" int pn2x_hand_frame2(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
+                                const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
+                                float *xyz1, float *xyz2_copy, int copy_ld, void *stream);
+
 extern "C" int pn2x_hand_frame(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
                                const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
                                float *xyz1, void *stream) {
+    return pn2x_hand_frame2(b, xb, num, n, j, palm_template, kp, palm_idx, points, scale, R, t, xyz2, xyz1, nullptr, 0, stream);
+}
+
+extern "C" int pn2x_hand_frame2(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
+                                const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
+                                float *xyz1, float *xyz2_copy, int copy_ld, void *stream) {
+    if (xyz2_copy && copy_ld < 3) return PN2_EINVAL;
     if (b < 0 || num < 1 || num > 16 || n < 0 || j < 1 || !(xb == b || xb == 1) || !(scale > 0.f)) return PN2_EINVAL;
     if (b == 0) return PN2_OK;
     if (!palm_template || !kp || !palm_idx || !points || !R || !t || !xyz2 || !xyz1) return PN2_ENULL;
     hipLaunchKernelGGL(pn2::hand_frame_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, xb, num, n, j, palm_template, kp,
-                       palm_idx, points, scale, R, t, xyz2, xyz1);
+                       palm_idx, points, scale, R, t, xyz2, xyz1, xyz2_copy, copy_ld);
     return pn2::check_launch();
 }

@@ -173,11 +173,23 @@ def max_rows(x: torch.Tensor) -> torch.Tensor:
 
 _lib.pn2x_hand_frame.argtypes = [_ci] * 5 + [_vp] * 4 + [ctypes.c_float] + [_vp] * 5
 _lib.pn2x_hand_frame.restype = _ci
+_lib.pn2x_hand_frame2.argtypes = [_ci] * 5 + [_vp] * 4 + [ctypes.c_float] + [_vp] * 5 + [_ci, _vp]
+_lib.pn2x_hand_frame2.restype = _ci
 
 
-def hand_frame(palm_template: torch.Tensor, kp: torch.Tensor, palm_idx: torch.Tensor, points: torch.Tensor, scale: float):
+def _xyz_cols(t: torch.Tensor, name: str, B: int, R: int):
+    """A (B, R, 3) column block of a wider fp32 row buffer -> (data_ptr, row stride)."""
+    if not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (B, R, 3) or t.stride(2) != 1 or \
+            (B > 1 and t.stride(0) != R * t.stride(1)):
+        raise ValueError(f"{name}: expected a (B,{R},3) float32 column block with uniform row stride, got {tuple(t.shape)} {t.stride()}")
+    return t.data_ptr(), t.stride(1)
+
+
+def hand_frame(palm_template: torch.Tensor, kp: torch.Tensor, palm_idx: torch.Tensor, points: torch.Tensor, scale: float,
+               xyz2_copy: torch.Tensor = None):
     """Kabsch(palm_template -> kp[:, palm_idx]) + canonicalisation in one launch.
-    Returns R (B,3,3), t (B,3,1), xyz2 (B,N,3), xyz1 (B,J,3)."""
+    Returns R (B,3,3), t (B,3,1), xyz2 (B,N,3), xyz1 (B,J,3).  xyz2_copy: a (B,N,3) column block of a consumer's row
+    buffer that receives a second copy of xyz2."""
     if palm_template.dim() == 2:
         palm_template = palm_template.unsqueeze(0)
     palm_template, kp, points = palm_template.float().contiguous(), kp.float().contiguous(), points.float().contiguous()
@@ -189,11 +201,12 @@ def hand_frame(palm_template: torch.Tensor, kp: torch.Tensor, palm_idx: torch.Te
     t = torch.empty((B, 3, 1), dtype=f32, device=points.device)
     xyz2 = torch.empty((B, N, 3), dtype=f32, device=points.device)
     xyz1 = torch.empty((B, J, 3), dtype=f32, device=points.device)
+    pc, ldc = (None, 0) if xyz2_copy is None else _xyz_cols(xyz2_copy, "xyz2_copy", B, N)
     with torch.cuda.device(points.device):
-        _native._check(_lib.pn2x_hand_frame(B, xb, num, N, J, _native._ptr(palm_template, "palm_template", f32, xb * num * 3),
-                                            _native._ptr(kp, "kp", f32, B * J * 3), _native._ptr(palm_idx, "palm_idx", torch.int32, num),
-                                            _native._ptr(points, "points", f32, B * N * 3), float(scale), R.data_ptr(), t.data_ptr(),
-                                            xyz2.data_ptr(), xyz1.data_ptr(), _native._stream(points)), "hand_frame")
+        _native._check(_lib.pn2x_hand_frame2(B, xb, num, N, J, _native._ptr(palm_template, "palm_template", f32, xb * num * 3),
+                                             _native._ptr(kp, "kp", f32, B * J * 3), _native._ptr(palm_idx, "palm_idx", torch.int32, num),
+                                             _native._ptr(points, "points", f32, B * N * 3), float(scale), R.data_ptr(), t.data_ptr(),
+                                             xyz2.data_ptr(), xyz1.data_ptr(), pc, ldc, _native._stream(points)), "hand_frame")
     return R, t, xyz2, xyz1
 
 
@@ -264,22 +277,24 @@ _lib.pn2x_furthest_point_sampling_prefix.argtypes = [_ci, _ci, _ci, _vp, _vp, _c
 _lib.pn2x_furthest_point_sampling_prefix.restype = _ci
 
 
-_lib.pn2x_ball_query_picks.argtypes = [_ci, _ci, _ci, ctypes.c_float, _ci, _vp, _vp, _vp, _vp, _vp]
-_lib.pn2x_ball_query_picks.restype = _ci
+_lib.pn2x_ball_query_picks2.argtypes = [_ci, _ci, _ci, ctypes.c_float, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp]
+_lib.pn2x_ball_query_picks2.restype = _ci
 
 
-def ball_query_picks(radius: float, nsample: int, xyz: torch.Tensor, picks: torch.Tensor):
+def ball_query_picks(radius: float, nsample: int, xyz: torch.Tensor, picks: torch.Tensor, xyz_copy: torch.Tensor = None):
     """Ball query around the centroids xyz[picks] (picks (B,S) int32 from FPS) -> (idx (B,S,nsample) int32,
-    new_xyz (B,S,3) = the centroids' coordinates): pointnet2_utils.ball_query + the gather before it, one launch."""
+    new_xyz (B,S,3) = the centroids' coordinates): pointnet2_utils.ball_query + the gather before it, one launch.
+    xyz_copy: a (B,S,3) column block of a consumer's row buffer that receives a second copy of new_xyz."""
     B, N, _ = xyz.shape
     S = picks.shape[1]
     px = _native._ptr(xyz, "xyz", torch.float32, B * N * 3)
     pp = _native._ptr(picks, "picks", torch.int32, B * S)
     idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
     new_xyz = torch.empty((B, S, 3), dtype=torch.float32, device=xyz.device)
+    pc, ldc = (None, 0) if xyz_copy is None else _xyz_cols(xyz_copy, "xyz_copy", B, S)
     with torch.cuda.device(xyz.device):
-        _native._check(_lib.pn2x_ball_query_picks(B, N, S, float(radius), nsample, px, pp, new_xyz.data_ptr(), idx.data_ptr(),
-                                                  _native._stream(xyz)), "ball_query_picks")
+        _native._check(_lib.pn2x_ball_query_picks2(B, N, S, float(radius), nsample, px, pp, new_xyz.data_ptr(), idx.data_ptr(),
+                                                   pc, ldc, _native._stream(xyz)), "ball_query_picks")
     return idx, new_xyz
 
 

@@ -36,6 +36,10 @@ int pn2x_kabsch(int b, int xb, int num, const float *x, const float *y, float *R
 int pn2x_hand_frame(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
                     const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
                     float *xyz1, void *stream);
+/* ... and a second copy of xyz2 into three columns of a wider row buffer (row stride copy_ld floats), or NULL. */
+int pn2x_hand_frame2(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
+                     const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
+                     float *xyz1, float *xyz2_copy, int copy_ld, void *stream);
 
 /*
  * Fused grouped MLP + max of one set-abstraction scale, eval mode (BatchNorm folded into the
@@ -124,6 +128,10 @@ int pn2x_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz, c
  */
 int pn2x_ball_query_picks(int b, int n, int m, float radius, int nsample, const float *xyz, const int *picks, float *new_xyz,
                           int *idx, void *stream);
+/* ... and a second copy of the coordinates into three columns of a wider row buffer (row stride copy_ld floats; the
+ * consumer's [feat | xyz] GEMM input, so the reference's torch.cat of pointnet_utils.py:493 is not needed), or NULL. */
+int pn2x_ball_query_picks2(int b, int n, int m, float radius, int nsample, const float *xyz, const int *picks, float *new_xyz,
+                           int *idx, float *new_xyz_copy, int copy_ld, void *stream);
 
 /*
  * Row gather on point-major data: out[b, j, :] = src[b, idx[b,j], :]  (src (b,n,c), idx (b,m), out (b,m,c)).

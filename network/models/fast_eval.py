@@ -76,7 +76,10 @@ class FastEval:
         (W1, b1), l2, l3 = msg(bh.sa2, 0)
         D = W1.shape[1] - 3
         P["sa2"] = dict(w1f=W1[:, :D].contiguous(), wx=W1[:, D:].contiguous(), b1=b1, l2=l2, l3=l3)
-        P["sa3"] = [fold(c, n) for c, n in zip(bh.sa3.mlp_convs, bh.sa3.mlp_bns)]  # in = [xyz | feat]
+        sa3 = [fold(c, n) for c, n in zip(bh.sa3.mlp_convs, bh.sa3.mlp_bns)]  # reference input = [xyz | feat]
+        W = sa3[0][0]
+        sa3[0] = (torch.cat([W[:, 3:], W[:, :3]], dim=1).contiguous(), sa3[0][1])  # -> [feat | xyz] (aligned block first)
+        P["sa3"] = sa3
         fp3 = [fold(c, n) for c, n in zip(bh.fp3.mlp_convs, bh.fp3.mlp_bns)]
         c_l2 = bh.sa2.out_channel
         P["fp3"] = dict(wa=fp3[0][0][:, :c_l2].contiguous(), wb=fp3[0][0][:, c_l2:].contiguous(), b=fp3[0][1], rest=fp3[1:])
@@ -158,7 +161,11 @@ class FastEval:
             raise NotImplementedError("fast path covers the 21-keypoint hand")
         palm_idx = self._palm_idx(pts.device)
         # Kabsch (palm template -> jittered palm keypoints) + canonicalisation of cloud and keypoints: one launch
-        R, t, xyz2, xyz1 = ext.hand_frame(palm.contiguous(), kp.contiguous(), palm_idx, pts.contiguous(), 0.2)
+        # fp1's input rows [interp(l1 -> l0) | xyz | pad] exist from the start: the hand-frame kernel drops its xyz copy there
+        c_i = P["fp2"][-1][0].shape[0]
+        fp1_in = torch.empty((B, N, c_i + 4), **f32)
+        R, t, xyz2, xyz1 = ext.hand_frame(palm.contiguous(), kp.contiguous(), palm_idx, pts.contiguous(), 0.2,
+                                          xyz2_copy=fp1_in[:, :, c_i:c_i + 3])
         scale = self._scale(pts.device)
         canon = {"scale": scale, "rotation": R, "translation": t}
         tt = t.transpose(1, 2)
@@ -185,14 +192,15 @@ class FastEval:
         # ---- sa2: 256 -> 128, r = 0.2, K = 32, MLP [64+3 -> 64 -> 64 -> 128] ---------------------------
         p = P["sa2"]
         S2, K2 = bh.sa2.npoint, bh.sa2.nsample_list[0]
-        idx2, l2_xyz = ext.ball_query_picks(bh.sa2.radius_list[0], K2, l1_xyz, i_l2)
-        a1f = F.linear(l1_feat.reshape(B * S1, c_l1), p["w1f"]).view(B, S1, -1)
         c_l2 = p["l3"][0].shape[0]
-        l2_feat = torch.empty((B, S2, c_l2), **f32)
+        sa3_in = torch.empty((B, S2, c_l2 + 4), **f32)  # [l2_feat | l2_xyz | pad]: sa3's group-all input, no torch.cat
+        idx2, l2_xyz = ext.ball_query_picks(bh.sa2.radius_list[0], K2, l1_xyz, i_l2, xyz_copy=sa3_in[:, :, c_l2:c_l2 + 3])
+        a1f = F.linear(l1_feat.reshape(B * S1, c_l1), p["w1f"]).view(B, S1, -1)
+        l2_feat = sa3_in[:, :, :c_l2]
         ext.sa_mlp_max(idx2, *p["l2"], *p["l3"], a1f=a1f, xyz=l1_xyz, cxyz=l2_xyz, wx=p["wx"], b1=p["b1"], out=l2_feat)
 
-        # ---- sa3: group-all [xyz | feat] -> MLP -> max over the 128 points ------------------------------
-        x = torch.cat([l2_xyz, l2_feat], dim=2).view(B * S2, -1)
+        # ---- sa3: group-all [feat | xyz] (weights permuted to match) -> MLP -> max over the 128 points -----------
+        x = sa3_in.view(B * S2, c_l2 + 4)[:, :c_l2 + 3]
         for W, b in P["sa3"]:
             x = _lin_relu(x, W, b)
         l3 = ext.max_rows(x.view(B, S2, -1))  # (B,512)
@@ -200,7 +208,7 @@ class FastEval:
         # ---- fp3: S == 1 -> the global feature is broadcast; first layer split so it is applied once per cloud
         p = P["fp3"]
         g = F.linear(l3, p["wb"], p["b"])  # (B,256) per-cloud half, bias included
-        h = F.linear(l2_feat.view(B * S2, c_l2), p["wa"]).view(B, S2, -1)
+        h = F.linear(sa3_in.view(B * S2, c_l2 + 4)[:, :c_l2], p["wa"]).view(B, S2, -1)
         ext.bias_act_pm_(h, g, rows_per_bias=S2, relu=True)
         x = h.view(B * S2, -1)
         for W, b in p["rest"]:
@@ -216,11 +224,9 @@ class FastEval:
         l1_out = x.view(B, S1, -1)
 
         # ---- fp1: interpolate l1 -> l0, [interp | xyz] (weights permuted to match) -> MLP; conv1 ----------
-        c_i = l1_out.shape[2]
-        fp1_in = torch.empty((B, N, c_i + 4), **f32)
+        assert c_i == l1_out.shape[2]
         w, i3 = ext.three_nn_weights(xyz2, l1_xyz)
         ext.three_interpolate_pm(l1_out, i3, w, fp1_in[:, :, :c_i])
-        fp1_in[:, :, c_i:c_i + 3] = xyz2
         x = fp1_in.view(B * N, c_i + 4)[:, :c_i + 3]
         for W, b in P["fp1"]:
             x = _lin_relu(x, W, b)
