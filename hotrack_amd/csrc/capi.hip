@@ -19,7 +19,7 @@ int three_nn_dispatch(int b, int n, int m, const float *unknown, const float *kn
 int interp_pm_dispatch(int b, int c, int m, int n, const float *points, int ldp, const int *idx, const float *weight,
                        float *out, int ldo, hipStream_t st);
 int knn_dispatch(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2, int *idx,
-                 hipStream_t st);
+                 hipStream_t st, int k2, int *idx2);
 int group_fwd_dispatch(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,
                        float *out, hipStream_t st);
 int group_bwd_dispatch(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
@@ -162,7 +162,16 @@ int pn2_knn(int b, int n, int m, int k, const float *unknown, const float *known
     if (b == 0 || n == 0) return PN2_OK;
     PN2_REQ(unknown && dist2 && idx && (known || m == 0), PN2_ENULL);
     PN2_REQ(b <= 65535 && fits_int((long)n * k) && fits_int((long)m * 3), PN2_ERANGE);
-    return knn_dispatch(b, n, m, k, unknown, known, dist2, idx, (hipStream_t)stream);
+    return knn_dispatch(b, n, m, k, unknown, known, dist2, idx, (hipStream_t)stream, 0, nullptr);
+}
+
+int pn2x_knn_indices(int b, int n, int m, int k, int k2, const float *unknown, const float *known, int *idx, int *idx2, void *stream) {
+    PN2_REQ(b >= 0 && n >= 0 && m >= 1 && k >= 1 && k2 >= 0 && k2 <= k, PN2_EINVAL);
+    PN2_REQ(k <= PN2_KNN_MAX_K, PN2_ERANGE);
+    if (b == 0 || n == 0) return PN2_OK;
+    PN2_REQ(unknown && known && idx && (idx2 || k2 == 0), PN2_ENULL);
+    PN2_REQ(b <= 65535 && fits_int((long)n * k) && fits_int((long)m * 3), PN2_ERANGE);
+    return knn_dispatch(b, n, m, k, unknown, known, nullptr, idx, (hipStream_t)stream, k2, k2 > 0 ? idx2 : nullptr);
 }
 
 int pn2_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,

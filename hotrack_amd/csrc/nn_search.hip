@@ -198,7 +198,7 @@ __device__ __forceinline__ void sort_keys(unsigned long long (&key)[P]) {
 template <int P>
 __global__ void __launch_bounds__(256)
 knn_wave_kernel(int n, int m, int k, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
-                float *__restrict__ dist2_all, int *__restrict__ idx_all) {
+                float *__restrict__ dist2_all, int *__restrict__ idx_all, int k2, int *__restrict__ idx2_all) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -220,16 +220,20 @@ knn_wave_kernel(int n, int m, int k, const float *__restrict__ unknown_all, cons
     }
     sort_keys<P>(key);
 
-    float *__restrict__ od = dist2_all + ((size_t)b * n + q) * k;
+    // dist2_all may be NULL (indices only); idx2_all, if given, receives the first k2 <= k indices as a second,
+    // contiguous (b, n, k2) list -- the k-NN list is sorted, so a smaller neighbourhood is its prefix
+    float *__restrict__ od = dist2_all ? dist2_all + ((size_t)b * n + q) * k : nullptr;
     int *__restrict__ oi = idx_all + ((size_t)b * n + q) * k;
+    int *__restrict__ oi2 = idx2_all ? idx2_all + ((size_t)b * n + q) * k2 : nullptr;
     for (int r = 0; r < k; ++r) {
         const unsigned hd = (unsigned)(key[0] >> 32);
         const unsigned mn = wave_min_u32(hd);
         const uint64_t tie = __ballot(hd == mn);
         const int wl = __builtin_ctzll(tie);  // lanes own ascending index ranges: lowest lane = lowest index
         if (lane == wl) {
-            od[r] = i2f((int)mn);
+            if (od) od[r] = i2f((int)mn);
             oi[r] = (int)(unsigned)key[0];
+            if (oi2 && r < k2) oi2[r] = (int)(unsigned)key[0];
 #pragma unroll
             for (int j = 0; j + 1 < P; ++j) key[j] = key[j + 1];
             key[P - 1] = kInfKey;
@@ -265,12 +269,13 @@ knn_thread_kernel(int n, int m, int k, const float *__restrict__ unknown_all, co
 }
 
 int knn_dispatch(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2,
-                 int *idx, hipStream_t st) {
+                 int *idx, hipStream_t st, int k2, int *idx2) {
     if (b == 0 || n == 0) return PN2_OK;
+    if ((!dist2 || idx2) && m > 64 * 32) return PN2_ERANGE;  // the index-only / prefix variants cover the wave kernel
     dim3 grid((n + 3) / 4, b);
 #define PN2_KNN_CASE(PP)                                                                                    \
     if (m <= 64 * PP) {                                                                                     \
-        hipLaunchKernelGGL(knn_wave_kernel<PP>, grid, dim3(256), 0, st, n, m, k, unknown, known, dist2, idx); \
+        hipLaunchKernelGGL(knn_wave_kernel<PP>, grid, dim3(256), 0, st, n, m, k, unknown, known, dist2, idx, k2, idx2); \
         return check_launch();                                                                              \
     }
     PN2_KNN_CASE(1) PN2_KNN_CASE(2) PN2_KNN_CASE(4) PN2_KNN_CASE(8) PN2_KNN_CASE(16) PN2_KNN_CASE(32)

@@ -256,15 +256,27 @@ def pose_head(h: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xyz1: torch.
     return kp_hand, kp_cam
 
 
-def knn_indices(k: int, unknown: torch.Tensor, known: torch.Tensor) -> torch.Tensor:
+_lib.pn2x_knn_indices.argtypes = [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_knn_indices.restype = _ci
+
+
+def knn_indices(k: int, unknown: torch.Tensor, known: torch.Tensor, k2: int = 0):
     """Indices (B,n,k) int32 of the k nearest `known` points of every `unknown` point, sorted by (distance, index) --
-    pointnet2_utils.knn without the sqrt / distance output the caller would discard."""
+    pointnet2_utils.knn without the sqrt / distance output the caller would discard.  k2 > 0: also the first k2 of
+    every list as a second contiguous (B,n,k2) tensor (returns a pair)."""
     B, n, _ = unknown.shape
     m = known.shape[1]
-    dist2 = torch.empty((B, n, k), dtype=torch.float32, device=unknown.device)
+    if m > 2048:  # beyond the wave kernel: the operator API
+        from . import pointnet2_utils as ops
+        idx = ops.knn(k, unknown, known)[1]
+        return (idx, idx[:, :, :k2].contiguous()) if k2 else idx
+    pu, pk = _native._ptr(unknown, "unknown", torch.float32, B * n * 3), _native._ptr(known, "known", torch.float32, B * m * 3)
     idx = torch.empty((B, n, k), dtype=torch.int32, device=unknown.device)
-    _native.knn_wrapper(B, n, m, k, unknown, known, dist2, idx)
-    return idx
+    idx2 = torch.empty((B, n, k2), dtype=torch.int32, device=unknown.device) if k2 else None
+    with torch.cuda.device(unknown.device):
+        _native._check(_lib.pn2x_knn_indices(B, n, m, k, k2, pu, pk, idx.data_ptr(), None if idx2 is None else idx2.data_ptr(),
+                                             _native._stream(unknown)), "knn_indices")
+    return (idx, idx2) if k2 else idx
 
 
 _lib.pn2x_furthest_point_sampling_radii.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp]

@@ -122,6 +122,13 @@ int pn2x_fps_prefix_flags(int n);
 int pn2x_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz, const int *flags, int nflags, int *idx, void *stream);
 
 /*
+ * pn2_knn without the distance output, plus (k2 > 0) the first k2 indices of every list as a second contiguous
+ * (b, n, k2) tensor: the k-NN list is sorted by (distance, index), so a smaller neighbourhood is its prefix -- the
+ * reference searches twice (GivenCenterPoints scales 16 and 64, pointnet_utils.py:560-565).  m <= 2048.
+ */
+int pn2x_knn_indices(int b, int n, int m, int k, int k2, const float *unknown, const float *known, int *idx, int *idx2, void *stream);
+
+/*
  * pn2_ball_query whose centroids are given as indices into the cloud itself (picks (b, m) int32, values in [0, n):
  * the output of FPS), which is how PointNet++ always calls it (pointnet_utils.py:379-382: sample, gather, query).
  * Also writes the centroids' coordinates new_xyz (b, m, 3) = xyz[picks], so the gather launch disappears.

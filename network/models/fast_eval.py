@@ -237,7 +237,8 @@ class FastEval:
         q = P["q"]
         # kNN lists are sorted by (distance, index): the K=16 list is the prefix of the K=64 list -> one search
         Ks = [q[("q1", i)]["K"] for i in range(2)]
-        gi = ext.knn_indices(max(Ks), xyz1, xyz2)
+        kmin, kmax = min(Ks), max(Ks)
+        gi, gi_small = ext.knn_indices(kmax, xyz1, xyz2, k2=kmin) if kmin < kmax else (ext.knn_indices(kmax, xyz1, xyz2), None)
         c_q = q[("q1", 0)]["l3"][0].shape[0]
         c1q = q[("q1", 0)]["l2"][0].shape[1]
         src3 = src2.view(B, N, C)
@@ -247,11 +248,11 @@ class FastEval:
             W = self._wcat(i)  # (2*c1q, C): layer-1 feature weights of q1 | q2 at this scale
             # few slots and a batch large enough that the GEMM, not the launch count, is what costs (measured: pays from B ~ 32)
             if J * K * 2 <= N and B * N >= 32768:  # gather the J*K feature rows, then the GEMM (slot-major rows, identity index)
-                flat = gi[:, :, :K].reshape(B, J * K)
+                flat = (gi_small if K == kmin and gi_small is not None else gi[:, :, :K].contiguous()).view(B, J * K)
                 a = F.linear(ext.gather_rows(src3, flat).view(B * J * K, C), W).view(B, J * K, -1)
                 plan.append((self._ident(B, J, K, dev), a, ext.gather_rows(xyz2, flat)))
             else:
-                idx = gi if K == gi.shape[2] else gi[:, :, :K].contiguous()
+                idx = gi if K == kmax else (gi_small if K == kmin and gi_small is not None else gi[:, :, :K].contiguous())
                 plan.append((idx, F.linear(src2, W).view(B, N, -1), xyz2))
         f11 = torch.empty((B, J, 2 * c_q), **f32)
         for i, (idx, a, nb_xyz) in enumerate(plan):

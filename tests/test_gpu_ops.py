@@ -266,3 +266,14 @@ def test_ball_query_picks_matches_gather_then_query():
     d = torch.from_numpy(cloud(1, 2, 1024, "uniform")).cuda()
     i1, l1, i2, idx1 = ext.fps_two_level(d, 256, 128, query=(0.1, 32))
     assert torch.equal(idx1, ops.ball_query(0.1, 32, d, l1)) and torch.equal(l1, ext.gather_rows(d, i1))
+
+
+def test_knn_indices_prefix_output():
+    from hotrack_amd import ext, pointnet2_utils as ops
+    g = torch.Generator().manual_seed(21)
+    for B, n, m, k, k2 in ((4, 21, 1024, 64, 16), (2, 21, 512, 64, 16), (3, 5, 100, 7, 7), (1, 1, 64, 64, 1), (2, 30, 2048, 200, 4)):
+        q, x = torch.rand(B, n, 3, generator=g).cuda(), torch.rand(B, m, 3, generator=g).cuda()
+        ref = ops.knn(k, q, x)[1]
+        idx, small = ext.knn_indices(k, q, x, k2=k2)
+        assert torch.equal(idx, ref) and torch.equal(small, ref[:, :, :k2].contiguous())
+        assert torch.equal(ext.knn_indices(k, q, x), ref)
