@@ -18,4 +18,6 @@ with torch.no_grad():
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         model(d, dict(FLAGS)); torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=40, max_shapes_column_width=60))
+from torch.autograd import DeviceType
+print("device kernels in one forward:", sum(1 for e in prof.events() if e.device_type == DeviceType.CUDA))
+#print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=40, max_shapes_column_width=60))
