@@ -251,3 +251,33 @@ def test_tail_kernels_match_torch():
     xyz = torch.rand(4, 1024, 3, generator=g).cuda()
     q = torch.rand(4, 21, 3, generator=g).cuda()
     assert torch.equal(ext.knn_indices(64, q, xyz), ops.knn(64, q, xyz)[1])
+
+
+@pytest.mark.parametrize("B,N,dup", [(33, 1024, False), (3, 512, False), (2, 2048, False), (2, 1024, True)])
+def test_fast_path_other_shapes_match_module_path(B, N, dup):
+    """Fast path vs module path beyond the default shape: the gathered-row layer-1 branch (B*N >= 32768), other point
+    counts, and clouds with duplicated points (tied FPS arg-maxima -> the second sampling level really runs)."""
+    from hotrack_amd import fused, pointnet2_utils
+    from models import pointnet_utils
+    from models.hand_network import HandTrackNet
+    pointnet_utils.set_operator_backend(pointnet2_utils)
+    torch.manual_seed(0)
+    model = HandTrackNet(make_cfg("cuda"))
+    deterministic_init(model)
+    model = model.cuda().eval()
+    d = synthetic_frames(300 + B + N, B, N)
+    if dup:
+        d["hand_points"][:, N // 2:] = d["hand_points"][:, : N - N // 2]
+    d = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in d.items()}
+    flags = {"track_flag": False, "test_flag": True, "save_flag": False, "IKNet_flag": False}
+    with torch.no_grad():
+        pointnet_utils.set_fused_backend(None)
+        ref = model(d, dict(flags))
+        try:
+            pointnet_utils.set_fused_backend(fused)
+            fast = model(d, dict(flags))
+            assert model._fast is not None
+        finally:
+            pointnet_utils.set_fused_backend(None)
+    for k in ("pred_kp", "pred_kp_handframe", "points_handframe"):
+        assert torch.allclose(fast[k], ref[k], atol=2e-4), (k, float((fast[k] - ref[k]).abs().max()))
