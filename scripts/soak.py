@@ -1,5 +1,5 @@
 """Soak test (not part of pytest): minutes of randomised launches looking for rare failures -- races in the SA kernel's
-two-role pipeline, the optimiser's last-workgroup protocol, the two-level FPS shortcut.  usage: python scripts/soak.py [seconds]"""
+two-role pipeline, the optimiser's last-workgroup protocol, the two-level FPS shortcut.  usage: python scripts/soak.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -14,8 +14,9 @@ from hotrack_amd import ext, sdf, pointnet2_utils as ops  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + budget
-rng = np.random.default_rng(12345)
-g = torch.Generator().manual_seed(999)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+g = torch.Generator().manual_seed(seed + 1)
 n_sa = n_opt = n_fps = 0
 vol = torch.from_numpy(make_volume(81, 0.005, "capsule", np.float16)).cuda()
 cvol = sdf.CornerVolume(vol)
