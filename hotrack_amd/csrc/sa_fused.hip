@@ -20,6 +20,10 @@
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
+#ifndef SA_PAD
+#define SA_PAD 4  /* LDS row padding in floats (row stride C + SA_PAD); must keep rows 16-byte aligned */
+#endif
+
 namespace pn2 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -74,7 +78,7 @@ sa_mlp_max_kernel(const SaArgs A) {
     const int num_tiles = A.num_tiles, tiles_per_cloud = A.tiles_per_cloud;
     constexpr int WP = 4 / WC;
     constexpr int TM = WP * 64;
-    constexpr int LD1 = C1 + 4, LD2 = C2 + 4;
+    constexpr int LD1 = C1 + SA_PAD, LD2 = C2 + SA_PAD;
     constexpr int NT2 = C2 / (16 * WC), NT3 = C3 / (16 * WC);
     static_assert(C2 % (16 * WC) == 0 && C3 % (16 * WC) == 0 && C1 % 16 == 0, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -396,7 +400,7 @@ static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
     a.num_tiles = (int)num_tiles_l;
     a.lgK = 0;
     while ((1 << a.lgK) < a.K) ++a.lgK;
-    const size_t lds = (size_t)TM * (NB1 * (C1 + 4) + C2 + 4) * sizeof(float);
+    const size_t lds = (size_t)TM * (NB1 * (C1 + SA_PAD) + C2 + SA_PAD) * sizeof(float);
     auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW, NB1, K, MODE>;
     static bool attr_set = false;  // once per instantiation; never during a later stream capture
     if (lds > 64 * 1024 && !attr_set) {
