@@ -13,6 +13,14 @@ constexpr int kWave = 64;
 // Squared distance in the one fixed contraction order used by oracle and kernels alike:
 // fma(dz,dz, fma(dx,dx, dy*dy)).  (reference expression: sampling_gpu.cu:133,
 // ball_query_gpu.cu:33, interpolate_gpu.cu:40,108 compiled with nvcc --fmad=true.)
+// Two squared distances at once with the packed fp32 VALU ops of gfx90a+ (v_pk_add / v_pk_mul / v_pk_fma_f32: each
+// lane-wise IEEE operation is the same as the scalar one, so results are bit-identical to sqdist()).
+typedef float pn2_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pn2_f32x2 sqdist2(pn2_f32x2 ax, pn2_f32x2 ay, pn2_f32x2 az, float bx, float by, float bz) {
+    const pn2_f32x2 dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+}
+
 __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
