@@ -2,9 +2,7 @@
 Runs only where /root/reference exists (the build container); skipped on the GPU box."""
 import os
 import sys
-import types
 
-import numpy as np
 import pytest
 import torch
 

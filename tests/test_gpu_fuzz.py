@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _cases import cloud, take_points
+from _cases import cloud
 
 pytestmark = pytest.mark.gpu
 
