@@ -228,11 +228,9 @@ static int launch_fps(int b, int n, int m, int bs, int lg, int Q, const float *x
         const size_t need = ent_bytes + (size_t)n * 3 * sizeof(float);
         if (need <= 128 * 1024) {
             auto kfn = fps_kernel<T, P, kCentLds, RAD>;
-            static size_t attr_bytes = 0;  // raise the dynamic-LDS cap once per size class, not per launch
-            if (need > 64 * 1024 && need > attr_bytes) {
+            static PerDeviceOnce raised;  // raise the dynamic-LDS cap once per instantiation and device, not per launch
+            if (need > 64 * 1024 && raised.first_use())
                 (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                attr_bytes = 128 * 1024;
-            }
             hipLaunchKernelGGL(kfn, dim3(b), dim3(T), need, st, n, m, bs, lg, Q, xyz, idx, skip_flags, nflags, radii);
         } else {
             hipLaunchKernelGGL((fps_kernel<T, P, kCentGlobal, RAD>), dim3(b), dim3(T), ent_bytes, st, n, m, bs, lg, Q, xyz, idx, skip_flags, nflags, radii);

@@ -130,6 +130,20 @@ inline int num_compute_units() {
     return cached[dev];
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: a per-instantiation `static`
+// of this type remembers which devices have had it raised (a process may drive several GPUs).
+struct PerDeviceOnce {
+    bool done[64] = {};
+    // true exactly once per device (and always for device ids outside the table: the call is idempotent)
+    bool first_use() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

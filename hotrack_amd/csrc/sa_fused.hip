@@ -402,11 +402,9 @@ static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
     while ((1 << a.lgK) < a.K) ++a.lgK;
     const size_t lds = (size_t)TM * (NB1 * (C1 + SA_PAD) + C2 + SA_PAD) * sizeof(float);
     auto kfn = sa_mlp_max_kernel<C1, C2, C3, WC, RTC, MINW, NB1, K, MODE>;
-    static bool attr_set = false;  // once per instantiation; never during a later stream capture
-    if (lds > 64 * 1024 && !attr_set) {
+    static PerDeviceOnce raised;  // once per instantiation and device; never during a later stream capture
+    if (lds > 64 * 1024 && raised.first_use())
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     // persistent workgroups: weights are loaded into registers once per workgroup
     const int wg_per_cu = (int)((160 * 1024) / lds) < MINW / 2 ? (int)((160 * 1024) / lds) : MINW / 2;
     const int max_wg = num_compute_units() * (wg_per_cu < 1 ? 1 : wg_per_cu);

@@ -32,6 +32,8 @@ def _lin_relu(x2d: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tens
 
 
 class FastEval:
+    MAX_POINTS = 2048  # the index-only kNN (one search for both neighbourhood sizes) covers clouds up to 64 x 32 points
+
     def __init__(self, net):
         self.net = net
         self._key = None
@@ -54,7 +56,40 @@ class FastEval:
 
     # ------------------------------------------------------------------------------------
     def _versions(self):
-        return tuple(p._version for p in self.net.parameters()) + tuple(b._version for b in self.net.buffers())
+        """Cache key of the folded weights: in-place edits bump `_version`; replacing a Parameter object, `.to(device)` /
+        `.float()` (which assign `param.data`) change `data_ptr()` / the device instead."""
+        return tuple((t._version, t.data_ptr(), t.device) for t in list(self.net.parameters()) + list(self.net.buffers()))
+
+    @staticmethod
+    def supported(net) -> bool:
+        """True when this path covers the network's configuration: single-scale sa1/sa2, two-scale kNN q1/q2, three-layer
+        grouped MLPs whose (K, widths) the fused set-abstraction kernel implements, 'kp' hand frame.  Anything else (e.g.
+        --network/backbone_out_dim overrides, multi-scale pointnet YAMLs) runs the module path, which falls back to the
+        unfused HIP operators per scale."""
+        from hotrack_amd import ext
+        bh = net.bhand
+        if net.handframe != "kp" or not net.elide_dead_attention:
+            return False
+
+        def scales_ok(mod, n_scales):
+            if len(mod.conv_blocks) != n_scales or len(mod.nsample_list) != n_scales:
+                return False
+            for convs, K in zip(mod.conv_blocks, mod.nsample_list):
+                if len(convs) != 3 or not ext.sa_mlp_max_supported(int(K), *(int(c.weight.shape[0]) for c in convs)):
+                    return False
+            return True
+
+        if not (scales_ok(bh.sa1, 1) and scales_ok(bh.sa2, 1) and scales_ok(net.q1, 2) and scales_ok(net.q2, 2)):
+            return False
+        if getattr(bh.sa1, "knn", False) or getattr(bh.sa2, "knn", False) or not (net.q1.knn and net.q2.knn):
+            return False
+        if bh.in_dim != 0 or not bh.sa3.group_all:
+            return False
+        # q1 / q2 share one kNN search and the layer-1 GEMM: same neighbourhood sizes and widths in both modules
+        if list(net.q1.nsample_list) != list(net.q2.nsample_list):
+            return False
+        w = [tuple(int(c.weight.shape[0]) for c in convs) for mod in (net.q1, net.q2) for convs in mod.conv_blocks]
+        return len(set(w)) == 1
 
     def prepare(self, force: bool = False):
         """Fold BatchNorm into the convolutions and pre-arrange the weights (cached; refreshed when any

@@ -100,8 +100,11 @@ class HandTrackNet(nn.Module):
                 and torch.device(self.device).type == "cuda"):
             if self._fast is None:
                 from .fast_eval import FastEval
-                self._fast = FastEval(self)
-            return self._fast.forward(input, flag_dict)  # point-major inference path, same results
+                self._fast = FastEval(self) if FastEval.supported(self) else False
+            # configurations / sizes the point-major path does not cover use the module path below (same results)
+            if (self._fast is not False and input["jittered_hand_kp"].shape[1] == 21
+                    and input["hand_points"].shape[1] <= self._fast.MAX_POINTS):
+                return self._fast.forward(input, flag_dict)
         dev = self.device
         if flag_dict["track_flag"]:
             palm_template = input["pred_palm_template"]

@@ -23,6 +23,24 @@ class HandTrackModel(nn.Module):
         self.use_graph = True  # GPU + fused backend: one captured HIP graph per (N, keypoints) shape, replayed per frame
         self._graphs = {}
 
+    # A captured graph bakes in the pointers of the BN-folded weights FastEval built at capture time: anything that can
+    # change the weights (checkpoint load, fine-tuning, .to()/.float()) drops the captured graphs.
+    def train(self, mode: bool = True):
+        self._graphs.clear()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._graphs.clear()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._graphs.clear()
+        return super().load_state_dict(*a, **k)
+
+    def invalidate_graphs(self):
+        """Call after editing parameters in place outside train() / load_state_dict() / .to()."""
+        self._graphs.clear()
+
     # ------------------------------------------------------------------------------------
     def _graph_step(self, points, kp_init, palm_template, flag_dict):
         """One tracking step as a replay of a captured HIP graph (static input / output buffers): a frame is

@@ -220,8 +220,10 @@ class Trainer(nn.Module):
         return self._static_loss
 
     def _capture(self, data, sig):
-        def clone(d):
-            return {k: (clone(v) if isinstance(v, dict) else (v.clone() if torch.is_tensor(v) else v)) for k, v in d.items()}
+        def clone(d):  # static DEVICE buffers: a DataLoader batch arrives on the host, and the captured region must not contain
+            # host-to-device copies (pageable-memory copies inside a capture either fail or bake host pointers in)
+            return {k: (clone(v) if isinstance(v, dict) else (v.to(self.device, copy=True) if torch.is_tensor(v) else v))
+                    for k, v in d.items()}
 
         self._graph, self._static = None, clone(data)
         # Warm-up on a side stream (MIOpen / BLAS pick their algorithms, autograd builds its buffers, Adam creates its
