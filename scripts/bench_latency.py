@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "network"), os.path.join(ROOT, "tests")]
 import torch  # noqa: E402
 
-from _netinit import deterministic_init, make_cfg, synthetic_frames  # noqa: E402
+from netinit import deterministic_init, make_cfg, synthetic_frames  # noqa: E402
 from hotrack_amd import fused, pointnet2_utils  # noqa: E402
 from models import pointnet_utils  # noqa: E402
 from models.hand_network import HandTrackNet  # noqa: E402

@@ -2,7 +2,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "network"), os.path.join(ROOT, "tests")]
 import torch
-from _netinit import deterministic_init, make_cfg, synthetic_frames
+from netinit import deterministic_init, make_cfg, synthetic_frames
 from hotrack_amd import fused, pointnet2_utils
 from models import pointnet_utils
 from models.hand_network import HandTrackNet
