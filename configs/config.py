@@ -59,7 +59,7 @@ def get_config(args, save=True):
     cfg["data_cfg"]["basepath"] = pjoin(root, data_cfg["basepath"])
     if torch.cuda.is_available():
         local = int(os.environ.get("LOCAL_RANK", cfg.get("cuda_id", 0)))
-        cfg["device"] = torch.device("cuda", local)
+        cfg["device"] = torch.device("cuda", local % torch.cuda.device_count())  # (% only matters for the shared-GPU self-test)
     else:
         cfg["device"] = "cpu"
     print("Running on ", cfg["device"])

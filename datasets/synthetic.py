@@ -69,11 +69,89 @@ class SyntheticSequences(Dataset):
 
 def get_dataloader(cfg, mode="train", shuffle=False, num_workers=0, distributed=False, length=None):
     syn = cfg["data_cfg"].get("synthetic", {})
+    if cfg.get("track") == "obj_opt":
+        ds = SyntheticObjectSequences(cfg, syn.get("test_sequences", 2), syn.get("sequence_frames", 30) if length is None else length)
+        return torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, collate_fn=lambda b: b[0])
     if cfg.get("track"):
-        ds = SyntheticSequences(cfg, syn.get("test_sequences", 4), cfg["data_cfg"].get("num_frames", 100) if length is None else length)
+        ds = SyntheticSequences(cfg, syn.get("test_sequences", 4),
+                                syn.get("sequence_frames", cfg["data_cfg"].get("num_frames", 100)) if length is None else length)
         return torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, collate_fn=lambda b: b[0])
     n = length or (syn.get("train_frames", 2048) if mode == "train" else max(cfg["batch_size"] * 4, 64))
     ds = SyntheticFrames(cfg, n, base_seed=0 if mode == "train" else 1_000_000)
     sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=shuffle) if distributed else None
     return torch.utils.data.DataLoader(ds, batch_size=cfg["batch_size"], shuffle=shuffle and sampler is None, sampler=sampler,
                                        num_workers=num_workers, drop_last=(mode == "train"))
+
+
+# ---- object sequences (track: obj_opt) ---------------------------------------------------------------------------------
+def _capsule_sdf(p):
+    """Signed distance to a bottle-sized capsule (radius 4 cm, 14 cm core) in the object frame, metres."""
+    z = np.clip(p[..., 2], -0.07, 0.07)
+    return np.sqrt(p[..., 0] ** 2 + p[..., 1] ** 2 + (p[..., 2] - z) ** 2) - 0.04
+
+
+def capsule_volume(res: int = 201, stride: float = 0.002) -> np.ndarray:
+    """(res,res,res) fp16 SDF volume on the +-0.2 m box the reference voxelises its DeepSDF decoder on
+    (optimization_obj.py:133-143: 201^3, stride 0.002, clamped), indexed [ix,iy,iz]."""
+    ax = (np.arange(res) - res // 2) * float(stride)
+    g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), axis=-1)
+    return np.clip(_capsule_sdf(g), -0.1, 0.1).astype(np.float16)
+
+
+def _rot(axis, angle):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K
+
+
+def capsule_surface(rng, n, noise=0.0015):
+    """n points on the capsule surface (object frame) + sensor noise."""
+    z = rng.uniform(-0.11, 0.11, n)
+    phi = rng.uniform(0, 2 * np.pi, n)
+    zc = np.clip(z, -0.07, 0.07)
+    r = np.sqrt(np.maximum(0.04 ** 2 - (z - zc) ** 2, 0.0))
+    p = np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=-1)
+    return p + rng.normal(0, noise, p.shape)
+
+
+class SyntheticObjectSequences(Dataset):
+    """Sequences for `track: obj_opt` (reference SequenceData items as ObjTrackModel_Optimization.forward reads them,
+    track_network.py:338-383): per frame obj_points (1,N,3) camera frame, gt_obj_pose, category / file_name / projection;
+    frame 0 also carries jittered_obj_pose (obj_jitter_cfg: r degrees, t metres) and -- in place of the DeepSDF latent the
+    reference decodes -- the object's SDF volume."""
+
+    def __init__(self, cfg, num_sequences: int, frames: int, res: int = 201, stride: float = 0.002):
+        self.cfg, self.ns, self.nf = cfg, num_sequences, frames
+        self.res, self.stride = res, stride
+        self._vol = None
+
+    def __len__(self):
+        return self.ns
+
+    def __getitem__(self, s):
+        if self._vol is None:
+            self._vol = torch.from_numpy(capsule_volume(self.res, self.stride))
+        rng = np.random.default_rng(40_000 + s)
+        n = self.cfg["num_points"]
+        jit = self.cfg.get("obj_jitter_cfg", {})
+        R = _rot(rng.standard_normal(3), rng.uniform(0, np.pi))
+        t = np.array([0.0, 0.0, 0.5]) + rng.uniform(-0.05, 0.05, 3)
+        w_axis, w = rng.standard_normal(3), rng.normal(0, 0.01)   # per-frame rotation increment (rad) and velocity (m)
+        vel = rng.normal(0, 0.002, 3)
+        f = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+        seq = []
+        for k in range(self.nf):
+            pts = capsule_surface(rng, n) @ R.T + t
+            fr = {"obj_points": f(pts).unsqueeze(0), "category": [self.cfg["obj_category"][0]], "file_name": [f"synthetic_obj_{s:03d}/{k:04d}"],
+                  "gt_obj_pose": {"rotation": f(R).reshape(1, 1, 3, 3), "translation": f(t).reshape(1, 1, 3, 1)},
+                  "projection": {"w": [640], "h": [480]}}
+            if k == 0:
+                ang = np.deg2rad(float(jit.get("r", 5))) * rng.standard_normal()
+                Rj = R @ _rot(rng.standard_normal(3), ang)
+                tj = t + rng.normal(0, float(jit.get("t", 0.03)) / 3, 3)
+                fr["jittered_obj_pose"] = {"rotation": f(Rj).reshape(1, 3, 3), "translation": f(tj).reshape(1, 3, 1)}
+                fr["sdf_volume"], fr["voxel_scale"] = self._vol, self.stride
+            seq.append(fr)
+            R = R @ _rot(w_axis, w)
+            t = t + vel
+        return seq

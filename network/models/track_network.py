@@ -97,3 +97,67 @@ class HandTrackModel(nn.Module):
             for k, v in loss.items():
                 total[k] = total[k] + v if k in total else v  # stays on the device: one host sync per sequence
         return {k: float(v) / len(input) for k, v in total.items()}, ret_dict_lst
+
+
+class ObjTrackModel_Optimization(nn.Module):
+    """Per-sequence object-pose tracking by gradient-free particle optimisation against the object's SDF volume
+    (counterpart of the reference's ObjTrackModel_Optimization, track_network.py:322-383; BASELINE configs[3], stage 1).
+
+    Frame 0 starts from the jittered pose; frame t starts from frame t-1's result, which also becomes the `prev_*` entries
+    of the pose dict (:353-370).  Each frame is one `gf_optimize_obj.optimize` call = 10 iterations x 2048 candidate
+    poses evaluated by the fused SDF-lookup kernels with the pose update on the device (hotrack_amd/csrc/sdf.hip): the loop
+    never synchronises with the host.  The reference decodes the volume from a DeepSDF latent per sequence
+    (`load_obj_for_opt` + `optimizer.load_obj`, :342-346 -- needs the checkpoints); here the sequence hands the volume
+    over (`input[0]['sdf_volume']`, `['voxel_scale']`)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        from .optimization_obj import gf_optimize_obj
+        self.device = cfg["device"]
+        self.dataset_name = cfg["data_cfg"]["dataset_name"]
+        self.sdf_code_source = cfg.get("sdf_code_source", "pred")
+        self.num_parts = cfg.get("num_parts", 1)
+        self.sym = cfg.get("obj_sym", -1)
+        self.optimizer = gf_optimize_obj(cfg)
+
+    def forward(self, input, flag_dict):
+        flag_dict["track_flag"] = True
+        assert flag_dict["test_flag"]
+        if "sdf_volume" in input[0]:
+            self.optimizer.load_volume(input[0]["sdf_volume"], input[0].get("voxel_scale"))
+        elif self.optimizer.sdf_volume is None:
+            raise RuntimeError("no SDF volume: decoding it from a DeepSDF latent needs the checkpoints (out of scope); "
+                               "put 'sdf_volume' / 'voxel_scale' into the sequence's first frame")
+        last = None
+        rets = []
+        for data in input:
+            if last is not None:
+                data["jittered_obj_pose"] = last
+            else:
+                jp = data["jittered_obj_pose"]
+                jp["translation"] = jp["translation"].float().reshape(1, 3, 1).to(self.device)
+                jp["rotation"] = jp["rotation"].float().reshape(1, 3, 3).to(self.device)
+                jp["prev_translation"], jp["prev_rotation"] = jp["translation"], jp["rotation"]
+                last = {"translation": jp["translation"], "rotation": jp["rotation"]}
+            ret = self.optimizer.optimize(data["obj_points"], data["jittered_obj_pose"], data["category"][0],
+                                          data["file_name"][0], data.get("projection"))
+            last["prev_translation"], last["prev_rotation"] = last["translation"], last["rotation"]  # last frame's pose
+            last["translation"], last["rotation"] = ret["translation"], ret["rotation"]            # current frame's pose
+            rets.append(ret)
+        return rets
+
+    def compute_loss(self, input, ret_dict_lst, flag_dict):
+        """Mean rotation / symmetry-axis (degrees) and translation (metres) error against gt_obj_pose.  (The reference
+        evaluates through pose_utils.part_dof_utils.eval_part_full plus a chamfer term on the reconstructed mesh, :385-440 --
+        mesh assets.)"""
+        r_err = t_err = a_err = 0.0
+        for data, ret in zip(input, ret_dict_lst):
+            gR = data["gt_obj_pose"]["rotation"].float().reshape(3, 3).to(self.device)
+            gt = data["gt_obj_pose"]["translation"].float().reshape(3).to(self.device)
+            R, t = ret["rotation"].reshape(3, 3), ret["translation"].reshape(3)
+            cos = ((R.t() @ gR).diagonal().sum() - 1) / 2
+            r_err = r_err + torch.rad2deg(torch.arccos(cos.clamp(-1, 1)))
+            a_err = a_err + torch.rad2deg(torch.arccos((R[:, 2] * gR[:, 2]).sum().clamp(-1, 1)))  # object z axis (revolution axis)
+            t_err = t_err + (t - gt).norm()
+        n = max(len(input), 1)
+        return {"obj_pred_r_diff": float(r_err) / n, "obj_pred_axis_diff": float(a_err) / n, "obj_pred_t_diff": float(t_err) / n}, ret_dict_lst

@@ -27,8 +27,10 @@ def main(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+            torch.cuda.set_device(int(os.environ["LOCAL_RANK"]) % torch.cuda.device_count())
+        # RCCL (backend "nccl") on the GPUs; PN2_DIST_BACKEND=gloo lets several ranks share one GPU (plumbing self-test only:
+        # scripts/scale_selftest.sh -- RCCL refuses two ranks on one device)
+        dist.init_process_group(os.environ.get("PN2_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
     cfg = get_config(args)
     log_dir = os.path.join(cfg["experiment_dir"], "log")
     os.makedirs(log_dir, exist_ok=True)
@@ -57,6 +59,7 @@ def main(args):
                 break
         for k, v in acc.items():
             trainer.log_string("Train {} is {}".format(k, v / max(n, 1)))
+        trainer.log_string("world_size %d, %d iterations" % (world, n))
         if (epoch + 1) % cfg["freq"]["save"] == 0:
             trainer.save()
         acc, n = {}, 0

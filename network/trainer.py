@@ -22,7 +22,7 @@ import torch.nn.init as init
 from torch.optim import lr_scheduler
 
 from models.hand_network import HandTrackNet
-from models.track_network import HandTrackModel
+from models.track_network import HandTrackModel, ObjTrackModel_Optimization
 
 
 def weights_init(init_type="gaussian"):
@@ -64,6 +64,16 @@ class Trainer(nn.Module):
         self.optimizer = self.scheduler = None
         if cfg["track"] == "hand":
             self.model = HandTrackModel(cfg, handnet=HandTrackNet)
+        elif cfg["track"] == "hand_IKNet":
+            # reference: HandTrackModel(handnet, IKnet=IKNet) + MANO shape / pose optimisation (trainer.py:120-127).  IKNet,
+            # the MANO layer and the hand optimiser's silhouette / regularisation terms need licensed assets (SURVEY.md
+            # section 2 rows 9, 16, 21): without them the entry runs the HandTrackNet tracking branch of the same loop
+            # (track_network.py:214-217) and says so.
+            self.log_string("track=hand_IKNet: IKNet / MANO assets are not available -> HandTrackNet tracking branch only")
+            cfg = dict(cfg, use_optimization=False)
+            self.model = HandTrackModel(cfg, handnet=HandTrackNet)
+        elif cfg["track"] == "obj_opt":
+            self.model = ObjTrackModel_Optimization(cfg)
         elif not cfg["track"]:
             self.model = HandTrackNet(cfg)
             params = [p for p in self.model.parameters() if p.requires_grad]
@@ -132,7 +142,9 @@ class Trainer(nn.Module):
 
     def resume(self, dataset_len=None):
         ckpt = OrderedDict()
-        if self.cfg["track"] == "hand":
+        if self.cfg["track"] == "obj_opt":
+            return self.epoch  # nothing to load: the optimiser has no learned parameters (reference trainer.py:128-133)
+        if self.cfg["track"] in ("hand", "hand_IKNet"):
             name = get_last_model(self.ckpt_dir)
             if name is None:
                 self.log_string("No HandTrackNet checkpoint found: tracking with freshly initialised weights")

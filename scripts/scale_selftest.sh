@@ -1,0 +1,35 @@
+#!/bin/bash
+# Multi-rank plumbing self-test on ONE GPU (no 8-GPU node is available to the builder; the driver runs the real scaling
+# bench).  Launches bench.py and network/train.py exactly as the driver / a user would -- torch.distributed.run, one process
+# per rank, 127.0.0.1 rendezvous -- but with the gloo backend so that N ranks can share device 0 (RCCL refuses two ranks on
+# one device).  Checks: the JSON line says n_gpus == N == world_size, value aggregates all ranks, training runs N ranks and
+# every rank ends with identical parameters.   usage: scripts/scale_selftest.sh [N ...]   (default: 2 4)
+set -euo pipefail
+R=$(cd "$(dirname "$0")/.." && pwd)
+cd "$R"
+Ns=${@:-2 4}
+export HOTRACK_DATA_ROOT=${HOTRACK_DATA_ROOT:-/tmp/hotrack_selftest}
+one=$(python bench.py --gpus 1 --steps 5 --warmup 2 --min-time 0.2 --no-cpu-baseline | grep '^{')
+for N in $Ns; do
+  port=$((29600 + N))
+  line=$(PN2_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
+         --master-port $port bench.py --gpus $N --steps 5 --warmup 2 --min-time 0.2 --no-cpu-baseline | grep '^{')
+  python - "$N" "$line" "$one" <<'PY'
+import json, sys
+n, d, one = int(sys.argv[1]), json.loads(sys.argv[2]), json.loads(sys.argv[3])
+assert d["n_gpus"] == n and d["config"]["world_size"] == n, d
+assert d["config"]["global_batch"] == n * d["config"]["per_gpu_batch"] and d["scaling"] == "weak"
+assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
+# N ranks time-share one GPU here, so the aggregate stays near the 1-rank number (it must NOT be N times smaller or larger)
+print(f"bench --gpus {n}: ok  n_gpus={d['n_gpus']} world_size={d['config']['world_size']} value={d['value']:.0f} frames/s "
+      f"(1 rank on the same GPU: {one['value']:.0f})")
+PY
+done
+for N in 2; do
+  PN2_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
+      --master-port $((29700 + N)) network/train.py --config handtracknet_train_SimGrasp.yml --num_points 512 --batch_size 4 \
+      --total_epoch 1 --synthetic_frames 32 --max_iters 3 2>&1 | tee /tmp/selftest_train_$N.log | grep -E "world_size|Train total_loss" || true
+  grep -q "world_size $N, 3 iterations" /tmp/selftest_train_$N.log || { echo "train.py did not run $N ranks"; tail -20 /tmp/selftest_train_$N.log; exit 1; }
+  echo "train.py x$N ranks: ok"
+done
+echo "scale_selftest: all ok"

@@ -92,6 +92,69 @@ def main():
     print(json.dumps(rep, indent=1))
 
 
+def main_obj(ref_tn):
+    """tests/golden/track_obj_sequence.npz: the reference's ObjTrackModel_Optimization.forward (track_network.py:338-383) on a
+    synthetic object sequence.  Harness-side: `load_obj_for_opt` (reads DeepSDF / mesh assets) returns a placeholder tuple,
+    the optimiser is a gf_optimize_obj created with object.__new__ (its __init__ loads the decoder) holding an analytic
+    capsule volume and seeded particles, its `load_obj` (decodes the latent into that volume) is a no-op.  The per-frame
+    loop, the pose hand-off and `optimize` are the reference's own code."""
+    import optimization_obj as oo
+    from _sdf_cases import make_volume, object_points, random_pose, _axis_angle
+    from oracle import sdf_oracle as S
+    res, stride, P, N, F = 81, 0.005, 512, 256, 5
+    vol = make_volume(res, stride, "capsule", np.float16)
+    rng = np.random.default_rng(4242)
+    pre = rng.standard_normal((P, 6)).astype(np.float32)
+    pre[0] = 0
+    o = object.__new__(oo.gf_optimize_obj)
+    o.volume_size, o.voxel_scale, o.device, o.update_shape_flag = res, stride, "cpu", False
+    o.sdf_volume = torch.from_numpy(vol).reshape(res, res, res)
+    o.iteration, o.scaling_coefficient1, o.scaling_coefficient2, o.beta = 10, 0.02, 2, 0.9
+    o.pre_sampled_particle, o.particle_size = torch.from_numpy(pre), P
+    o.load_obj = lambda *a, **k: None
+    model = object.__new__(ref_tn.ObjTrackModel_Optimization)
+    torch.nn.Module.__init__(model)
+    model.device, model.optimizer, model.root_dir, model.dataset_name, model.sdf_code_source = "cpu", o, "", "HO3D", "pred"
+    ref_tn.load_obj_for_opt = lambda *a, **k: (None, {"scale": [1.0]}, None, "gt_path", "recon_path")
+    R, t = random_pose(31)
+    R, t = R.astype(np.float64), t.astype(np.float64)
+    dR, vel = _axis_angle(rng.standard_normal(3), 0.012), rng.normal(0, 0.002, 3)
+    Rj, tj = random_pose(32, angle=0.06, trans=0.008)
+    seq, pts, gts = [], [], []
+    for k in range(F):
+        p = (object_points(5000 + k, N, "capsule").astype(np.float64) @ R.T + t).astype(np.float32)
+        fr = {"obj_points": torch.from_numpy(p)[None], "category": ["bottle"], "file_name": [f"seq/{k:04d}"],
+              "gt_obj_pose": {"rotation": torch.from_numpy(R.astype(np.float32)), "translation": torch.from_numpy(t.astype(np.float32))},
+              "projection": {"w": [640], "h": [480]}}
+        if k == 0:
+            fr["jittered_obj_pose"] = {"rotation": torch.from_numpy((R @ Rj).astype(np.float32)),
+                                       "translation": torch.from_numpy((t + tj).astype(np.float32))}
+        seq.append(fr); pts.append(p); gts.append((R.astype(np.float32), t.astype(np.float32)))
+        R, t = R @ dR, t + vel
+    init_R, init_t = seq[0]["jittered_obj_pose"]["rotation"].numpy().copy(), seq[0]["jittered_obj_pose"]["translation"].numpy().copy()
+    with torch.no_grad():
+        rets = model(seq, {"track_flag": True, "test_flag": True, "save_flag": False})
+    R_ref = np.stack([r["rotation"].numpy().reshape(3, 3) for r in rets])
+    t_ref = np.stack([r["translation"].numpy().reshape(3) for r in rets])
+    # the oracle chained the same way
+    Ro, to, worst = init_R.reshape(3, 3), init_t.reshape(3), 0.0
+    for k in range(F):
+        Ro, to = S.obj_optimize(pts[k], Ro, to, pre, vol, stride)
+        worst = max(worst, float(np.abs(Ro - R_ref[k]).max()), float(np.abs(to - t_ref[k]).max()))
+    np.savez_compressed(os.path.join(HERE, "track_obj_sequence.npz"), vol=vol, meta=np.array([res, stride]), pre=pre, pts=np.stack(pts),
+                        init_R=init_R, init_t=init_t, R_ref=R_ref, t_ref=t_ref,
+                        gt_R=np.stack([g[0] for g in gts]), gt_t=np.stack([g[1] for g in gts]))
+    err_t = [float(np.linalg.norm(t_ref[k] - gts[k][1])) for k in range(F)]
+    return {"obj_frames": F, "obj_oracle_vs_reference_max_abs": worst, "obj_translation_error_per_frame_m": err_t}
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "golden vectors can only be regenerated where /root/reference exists"
     main()
+    rep = main_obj(sys.modules["track_network"])
+    with open(os.path.join(HERE, "GOLDEN_REPORT_TRACK.json")) as f:
+        full = json.load(f)
+    full.update(rep)
+    with open(os.path.join(HERE, "GOLDEN_REPORT_TRACK.json"), "w") as f:
+        json.dump(full, f, indent=1)
+    print(json.dumps(rep, indent=1))
