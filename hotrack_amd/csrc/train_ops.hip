@@ -1,0 +1,382 @@
+// train_ops.hip -- training-mode building blocks on POINT-MAJOR activations (rows x channels, fp32) for gfx950.
+//
+// The reference trains the grouped MLPs as Conv2d(1x1) + BatchNorm2d + ReLU over channel-major (B, C, S, K) tensors
+// (network/models/pointnet_utils.py:399-403, :460-462, :504-506, :577-581) -- per layer a convolution-library call with
+// layout transposes, a BatchNorm kernel, a ReLU kernel, and as many again in backward.  Here a 1x1 convolution is what it
+// is, a GEMM over all R = B*S*K positions (library GEMM, point-major rows), and everything between two GEMMs is ONE pair
+// of streaming kernels per direction:
+//
+//   forward    bn_stats        per-channel sum / sum of squares over the R rows (fp32 partials, fp64 atomics)
+//              bn_relu_apply   H = relu(gamma * (Y - mean) * invstd + beta); the first workgroup also writes the saved
+//                              mean / invstd, the running-statistics update and num_batches_tracked
+//   backward   bn_relu_bwd_reduce   sum(g), sum(g * xhat)  with  g = dH * [H > 0]
+//              bn_relu_bwd_apply    dY = gamma * invstd * (g - sum(g)/R - xhat * sum(g*xhat)/R); dgamma, dbeta
+//
+// plus the transposes of the point-major row gathers the forward uses (pn2x_gather_rows, pn2x_three_interpolate_pm):
+//   scatter_add_rows      dIn[b, idx[b,j], :] += dOut[b, j, :]                   (group_points_grad on rows)
+//   interp_pm_bwd         dPts[b, idx[b,j,t], :] += w[b,j,t] * dOut[b, j, :]      (three_interpolate_grad on rows)
+// All HBM-bound: 16-byte accesses along the contiguous channel axis, one pass over each operand.
+#include "pn2_common.h"
+#include "../../include/pn2_ext.h"
+
+namespace pn2 {
+
+constexpr int kTT = 256;
+
+struct BnCh {  // per-thread constants of its 4 channels
+    float mean[4], invstd[4], g[4], b[4];
+};
+
+__device__ __forceinline__ void bn_consts(BnCh &k, int C, int c0, long rows, const double *__restrict__ sums, float eps,
+                                          const float *__restrict__ gamma, const float *__restrict__ beta, double *var_out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double m = sums[c0 + i] / (double)rows;
+        double v = sums[C + c0 + i] / (double)rows - m * m;
+        v = v > 0.0 ? v : 0.0;
+        k.mean[i] = (float)m;
+        k.invstd[i] = (float)(1.0 / sqrt(v + (double)eps));
+        k.g[i] = gamma[c0 + i];
+        k.b[i] = beta[c0 + i];
+        if (var_out) var_out[i] = v;
+    }
+}
+
+__device__ __forceinline__ float bn_act(float y, const BnCh &k, int i) {
+    return ((y - k.mean[i]) * k.invstd[i]) * k.g[i] + k.b[i];  // torch's evaluation order
+}
+
+// block-level reduction of per-thread float4 pairs over the threads that share a channel quad, then fp64 atomics
+__device__ __forceinline__ void block_reduce_to_sums(float4 a, float4 b, int Q, int rpp, int C, double *__restrict__ sums) {
+    __shared__ float4 red[2][kTT];
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < Q) {
+        double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+        for (int r = 0; r < rpp; ++r) {
+            const float4 u = red[0][r * Q + threadIdx.x], v = red[1][r * Q + threadIdx.x];
+            s[0] += u.x; s[1] += u.y; s[2] += u.z; s[3] += u.w;
+            t[0] += v.x; t[1] += v.y; t[2] += v.z; t[3] += v.w;
+        }
+        const int c0 = threadIdx.x * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(sums + c0 + i, s[i]);
+            atomicAdd(sums + C + c0 + i, t[i]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kTT)
+bn_stats_kernel(long rows, int C, const float *__restrict__ Y, int ld, int rows_per_block, double *__restrict__ sums) {
+    const int Q = C >> 2, rpp = kTT / Q;
+    const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float4 s = make_float4(0, 0, 0, 0), t = s;
+    if (rr < rpp) {
+        for (long r = r0 + rr; r < r1; r += rpp) {
+            const float4 v = *reinterpret_cast<const float4 *>(Y + r * ld + 4 * q);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            t.x += v.x * v.x; t.y += v.y * v.y; t.z += v.z * v.z; t.w += v.w * v.w;
+        }
+    }
+    block_reduce_to_sums(s, t, Q, rpp, C, sums);
+}
+
+__global__ void __launch_bounds__(kTT)
+bn_relu_apply_kernel(long rows, int C, const float *__restrict__ Y, int ldy, const double *__restrict__ sums,
+                     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ conv_bias,
+                     float eps, float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
+                     long long *__restrict__ nbt, float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                     float *__restrict__ H, int ldh, int rows_per_block, int relu) {
+    const int Q = C >> 2, rpp = kTT / Q;
+    const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
+    if (rr >= rpp) return;
+    BnCh k;
+    double var[4];
+    bn_consts(k, C, 4 * q, rows, sums, eps, gamma, beta, var);
+    if (blockIdx.x == 0 && rr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q + i;
+            save_mean[c] = k.mean[i];
+            save_invstd[c] = k.invstd[i];
+            if (running_mean) {  // torch: running = (1 - m) * running + m * batch; the variance unbiased (n / (n - 1))
+                const float bm = k.mean[i] + (conv_bias ? conv_bias[c] : 0.f);  // Y excludes the conv bias (it cancels in BN)
+                const float bv = (float)(rows > 1 ? var[i] * ((double)rows / (double)(rows - 1)) : var[i]);
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * bm;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * bv;
+            }
+        }
+        if (q == 0 && nbt) *nbt += 1;
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long r = r0 + rr; r < r1; r += rpp) {
+        const float4 v = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
+        float4 h;
+        h.x = bn_act(v.x, k, 0); h.y = bn_act(v.y, k, 1); h.z = bn_act(v.z, k, 2); h.w = bn_act(v.w, k, 3);
+        if (relu) { h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f); }
+        *reinterpret_cast<float4 *>(H + r * ldh + 4 * q) = h;
+    }
+}
+
+struct BnSaved {
+    float mean[4], invstd[4], g[4], b[4];
+};
+
+__device__ __forceinline__ void load_saved(BnCh &k, int c0, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                           const float *__restrict__ gamma, const float *__restrict__ beta) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        k.mean[i] = mean[c0 + i]; k.invstd[i] = invstd[c0 + i]; k.g[i] = gamma[c0 + i]; k.b[i] = beta[c0 + i];
+    }
+}
+
+__global__ void __launch_bounds__(kTT)
+bn_relu_bwd_reduce_kernel(long rows, int C, const float *__restrict__ dH, int ldd, const float *__restrict__ Y, int ldy,
+                          const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
+                          const float *__restrict__ beta, int rows_per_block, int relu, double *__restrict__ sums) {
+    const int Q = C >> 2, rpp = kTT / Q;
+    const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float4 s = make_float4(0, 0, 0, 0), t = s;
+    if (rr < rpp) {
+        BnCh k;
+        load_saved(k, 4 * q, mean, invstd, gamma, beta);
+        for (long r = r0 + rr; r < r1; r += rpp) {
+            const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
+            float4 g = *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q);
+            if (relu) {
+                if (!(bn_act(y.x, k, 0) > 0.f)) g.x = 0.f;
+                if (!(bn_act(y.y, k, 1) > 0.f)) g.y = 0.f;
+                if (!(bn_act(y.z, k, 2) > 0.f)) g.z = 0.f;
+                if (!(bn_act(y.w, k, 3) > 0.f)) g.w = 0.f;
+            }
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            t.x += g.x * ((y.x - k.mean[0]) * k.invstd[0]);
+            t.y += g.y * ((y.y - k.mean[1]) * k.invstd[1]);
+            t.z += g.z * ((y.z - k.mean[2]) * k.invstd[2]);
+            t.w += g.w * ((y.w - k.mean[3]) * k.invstd[3]);
+        }
+    }
+    block_reduce_to_sums(s, t, Q, rpp, C, sums);
+}
+
+__global__ void __launch_bounds__(kTT)
+bn_relu_bwd_apply_kernel(long rows, int C, const float *__restrict__ dH, int ldd, const float *__restrict__ Y, int ldy,
+                         const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
+                         const float *__restrict__ beta, const double *__restrict__ sums, int rows_per_block, int relu,
+                         float *__restrict__ dY, int ldo, float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dbias) {
+    const int Q = C >> 2, rpp = kTT / Q;
+    const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
+    if (rr >= rpp) return;
+    BnCh k;
+    load_saved(k, 4 * q, mean, invstd, gamma, beta);
+    float sg[4], sgx[4], scale[4];
+    const float inv_r = (float)(1.0 / (double)rows);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sg[i] = (float)sums[4 * q + i];
+        sgx[i] = (float)sums[C + 4 * q + i];
+        scale[i] = k.g[i] * k.invstd[i];
+    }
+    if (blockIdx.x == 0 && rr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dgamma[4 * q + i] = sgx[i];
+            dbeta[4 * q + i] = sg[i];
+            if (dbias) dbias[4 * q + i] = 0.f;  // gradient of a bias in front of BatchNorm: sum_r dy = 0 identically
+        }
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long r = r0 + rr; r < r1; r += rpp) {
+        const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
+        float4 g = *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q);
+        const float yy[4] = {y.x, y.y, y.z, y.w};
+        float gg[4] = {g.x, g.y, g.z, g.w}, o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (relu && !(bn_act(yy[i], k, i) > 0.f)) gg[i] = 0.f;
+            const float xhat = (yy[i] - k.mean[i]) * k.invstd[i];
+            o[i] = scale[i] * (gg[i] - sg[i] * inv_r - xhat * (sgx[i] * inv_r));
+        }
+        *reinterpret_cast<float4 *>(dY + r * ldo + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- transposes of the row gathers ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kTT)
+scatter_add_rows_kernel(int n, int m, int Q, const float *__restrict__ dOut, int ldo, const int *__restrict__ idx,
+                        float *__restrict__ dIn, int ldi) {
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * kTT + threadIdx.x;
+    if (e >= (long)m * Q) return;
+    const int j = (int)(e / Q), q = (int)(e % Q);
+    const int row = idx[(size_t)b * m + j];
+    const float4 v = *reinterpret_cast<const float4 *>(dOut + ((size_t)b * m + j) * ldo + 4 * q);
+    float *dst = dIn + ((size_t)b * n + row) * ldi + 4 * q;
+    unsafeAtomicAdd(dst + 0, v.x);
+    unsafeAtomicAdd(dst + 1, v.y);
+    unsafeAtomicAdd(dst + 2, v.z);
+    unsafeAtomicAdd(dst + 3, v.w);
+}
+
+__global__ void __launch_bounds__(kTT)
+interp_pm_bwd_kernel(int m, int n, int Q, const float *__restrict__ dOut, int ldo, const int *__restrict__ idx,
+                     const float *__restrict__ weight, float *__restrict__ dPts, int ldp) {
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * kTT + threadIdx.x;
+    if (e >= (long)n * Q) return;
+    const int j = (int)(e / Q), q = (int)(e % Q);
+    const float4 v = *reinterpret_cast<const float4 *>(dOut + ((size_t)b * n + j) * ldo + 4 * q);
+    const int *id = idx + ((size_t)b * n + j) * 3;
+    const float *w = weight + ((size_t)b * n + j) * 3;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        float *dst = dPts + ((size_t)b * m + id[t]) * ldp + 4 * q;
+        const float wt = w[t];
+        unsafeAtomicAdd(dst + 0, wt * v.x);
+        unsafeAtomicAdd(dst + 1, wt * v.y);
+        unsafeAtomicAdd(dst + 2, wt * v.z);
+        unsafeAtomicAdd(dst + 3, wt * v.w);
+    }
+}
+
+// ---- layer 1 of a set-abstraction scale, pre-activation, never materialising the grouped input ---------------------------
+// y1[b, (s,k), :] = a1f[b, idx[b,s,k], :] + wx . (xyz[b, idx] - cxyz[b,s]) + cadd[b,s,:]     (each term optional)
+// (the same linear split as the eval kernel, pn2_ext.h pn2x_sa_mlp_max; bias omitted: BatchNorm follows).  Also writes the
+// relative coordinates rel (b, s*k, 3) the backward needs for d(wx).
+__global__ void __launch_bounds__(kTT)
+sa_layer1_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int a1f_ld, const float *__restrict__ xyz,
+                 const float *__restrict__ cxyz, const float *__restrict__ wx, const float *__restrict__ cadd, int cadd_ld,
+                 const int *__restrict__ idx, float *__restrict__ out, float *__restrict__ rel_out) {
+    const int b = blockIdx.y;
+    const long e = (long)blockIdx.x * kTT + threadIdx.x;
+    const int sk = S * K;
+    if (e >= (long)sk * Q) return;
+    const int r = (int)(e / Q), q = (int)(e % Q);
+    const int s = r / K;
+    const int j = idx[(size_t)b * sk + r];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a1f) acc = *reinterpret_cast<const float4 *>(a1f + ((size_t)b * n + j) * a1f_ld + 4 * q);
+    if (xyz) {
+        const float *p = xyz + ((size_t)b * n + j) * 3, *c = cxyz + ((size_t)b * S + s) * 3;
+        const float rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
+        const float *w = wx + (size_t)q * 12;
+        acc.x += w[0] * rx + w[1] * ry + w[2] * rz;
+        acc.y += w[3] * rx + w[4] * ry + w[5] * rz;
+        acc.z += w[6] * rx + w[7] * ry + w[8] * rz;
+        acc.w += w[9] * rx + w[10] * ry + w[11] * rz;
+        if (rel_out && q == 0) {
+            float *o = rel_out + ((size_t)b * sk + r) * 3;
+            o[0] = rx; o[1] = ry; o[2] = rz;
+        }
+    }
+    if (cadd) {
+        const float4 v = *reinterpret_cast<const float4 *>(cadd + ((size_t)b * S + s) * cadd_ld + 4 * q);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(out + ((size_t)b * sk + r) * (4 * Q) + 4 * q) = acc;
+}
+
+static int rows_per_block_for(long rows, int C) {
+    const int rpp = kTT / (C >> 2);
+    long rpb = (rows + 2047) / 2048;  // ~2048 workgroups on a large problem
+    if (rpb < 4L * rpp) rpb = 4L * rpp;
+    return (int)rpb;
+}
+
+static bool bad_c(int C) { return C < 4 || C % 4 != 0 || C > 1024; }
+
+}  // namespace pn2
+
+extern "C" int pn2x_bn_stats(long rows, int c, const float *y, int ldy, double *sums, void *stream) {
+    using namespace pn2;
+    if (rows < 1 || bad_c(c) || ldy < c || ldy % 4) return PN2_EINVAL;
+    if (!y || !sums) return PN2_ENULL;
+    if (((uintptr_t)y) % 16) return PN2_EINVAL;
+    const int rpb = rows_per_block_for(rows, c);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kTT), 0, (hipStream_t)stream, rows, c, y, ldy, rpb, sums);
+    return check_launch();
+}
+
+extern "C" int pn2x_bn_relu_apply(long rows, int c, const float *y, int ldy, const double *sums, const float *gamma,
+                                  const float *beta, const float *conv_bias, float eps, float momentum, float *running_mean,
+                                  float *running_var, long long *num_batches_tracked, float *save_mean, float *save_invstd,
+                                  float *h, int ldh, int relu, void *stream) {
+    using namespace pn2;
+    if (rows < 1 || bad_c(c) || ldy < c || ldy % 4 || ldh < c || ldh % 4) return PN2_EINVAL;
+    if (!y || !sums || !gamma || !beta || !save_mean || !save_invstd || !h) return PN2_ENULL;
+    if (((uintptr_t)y | (uintptr_t)h) % 16) return PN2_EINVAL;
+    const int rpb = rows_per_block_for(rows, c);
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kTT), 0, (hipStream_t)stream, rows, c, y, ldy,
+                       sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean,
+                       save_invstd, h, ldh, rpb, relu);
+    return check_launch();
+}
+
+extern "C" int pn2x_bn_relu_bwd(long rows, int c, const float *dh, int ldd, const float *y, int ldy, const float *mean,
+                                const float *invstd, const float *gamma, const float *beta, int relu, double *sums, float *dy,
+                                int ldo, float *dgamma, float *dbeta, float *dbias, void *stream) {
+    using namespace pn2;
+    if (rows < 1 || bad_c(c) || ldy < c || ldy % 4 || ldd < c || ldd % 4 || ldo < c || ldo % 4) return PN2_EINVAL;
+    if (!dh || !y || !mean || !invstd || !gamma || !beta || !sums || !dy || !dgamma || !dbeta) return PN2_ENULL;
+    if (((uintptr_t)y | (uintptr_t)dh | (uintptr_t)dy) % 16) return PN2_EINVAL;
+    const int rpb = rows_per_block_for(rows, c);
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, grid, dim3(kTT), 0, (hipStream_t)stream, rows, c, dh, ldd, y, ldy, mean, invstd, gamma,
+                       beta, rpb, relu, sums);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, grid, dim3(kTT), 0, (hipStream_t)stream, rows, c, dh, ldd, y, ldy, mean, invstd, gamma,
+                       beta, sums, rpb, relu, dy, ldo, dgamma, dbeta, dbias);
+    return check_launch();
+}
+
+extern "C" int pn2x_scatter_add_rows(int b, int n, int m, int c, const float *dout, int ldo, const int *idx, float *din, int ldi,
+                                     void *stream) {
+    using namespace pn2;
+    if (b < 0 || n < 1 || m < 0 || c < 0 || c % 4 || ldo < c || ldo % 4 || ldi < c || ldi % 4) return PN2_EINVAL;
+    if (b == 0 || m == 0 || c == 0) return PN2_OK;
+    if (!dout || !idx || !din) return PN2_ENULL;
+    if (((uintptr_t)dout | (uintptr_t)din) % 16) return PN2_EINVAL;
+    const int Q = c / 4;
+    const long total = (long)m * Q;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + kTT - 1) / kTT), b), dim3(kTT), 0, (hipStream_t)stream, n, m, Q,
+                       dout, ldo, idx, din, ldi);
+    return check_launch();
+}
+
+extern "C" int pn2x_three_interpolate_pm_grad(int b, int c, int m, int n, const float *dout, int ldo, const int *idx,
+                                              const float *weight, float *dpoints, int ldp, void *stream) {
+    using namespace pn2;
+    if (b < 0 || m < 1 || n < 0 || c < 0 || c % 4 || ldo < c || ldo % 4 || ldp < c || ldp % 4) return PN2_EINVAL;
+    if (b == 0 || n == 0 || c == 0) return PN2_OK;
+    if (!dout || !idx || !weight || !dpoints) return PN2_ENULL;
+    if (((uintptr_t)dout | (uintptr_t)dpoints) % 16) return PN2_EINVAL;
+    const int Q = c / 4;
+    const long total = (long)n * Q;
+    hipLaunchKernelGGL(interp_pm_bwd_kernel, dim3((unsigned)((total + kTT - 1) / kTT), b), dim3(kTT), 0, (hipStream_t)stream, m, n, Q, dout,
+                       ldo, idx, weight, dpoints, ldp);
+    return check_launch();
+}
+
+extern "C" int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
+                              const float *wx, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
+                              void *stream) {
+    using namespace pn2;
+    if (b < 0 || n < 1 || s < 0 || k < 1 || c1 < 4 || c1 % 4) return PN2_EINVAL;
+    if (b == 0 || s == 0) return PN2_OK;
+    if (!idx || !out || (!a1f && !xyz)) return PN2_ENULL;
+    if (xyz && (!cxyz || !wx)) return PN2_ENULL;
+    if ((a1f && (a1f_ld < c1 || a1f_ld % 4)) || (cadd && (cadd_ld < c1 || cadd_ld % 4))) return PN2_EINVAL;
+    if (((uintptr_t)a1f | (uintptr_t)cadd | (uintptr_t)out) % 16) return PN2_EINVAL;
+    const int Q = c1 / 4;
+    const long total = (long)s * k * Q;
+    hipLaunchKernelGGL(sa_layer1_kernel, dim3((unsigned)((total + kTT - 1) / kTT), b), dim3(kTT), 0, (hipStream_t)stream, n, s, k, Q, a1f,
+                       a1f_ld, xyz, cxyz, wx, cadd, cadd_ld, idx, out, rel_out);
+    return check_launch();
+}

@@ -1,0 +1,204 @@
+"""Training-mode operators on point-major activations (include/pn2_ext.h, csrc/train_ops.hip) as autograd Functions.
+
+  bn_relu(y, conv, bn, ws)          train-mode BatchNorm (+ ReLU) of the pre-activations y (R, C): batch statistics, running
+                                    statistics update, saved mean / invstd; backward = one reduce + one apply kernel
+  sa_layer1(...)                    layer-1 pre-activations of a set-abstraction scale from the linear split
+                                    a1f[idx] + wx.(xyz[idx] - centre) + cadd, without materialising the grouped input;
+                                    backward = scatter-add of rows (+ one small GEMM for d(wx), one sum for d(cadd))
+  interpolate_rows(points, idx, w)  three-NN interpolation on rows; backward = weighted scatter-add of rows
+
+GPU tensors only (no CPU path).  `Workspace` hands out zeroed fp64 accumulator slices: ONE fill launch per training step
+instead of one per BatchNorm call and direction.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import pointnet2_hip as _native
+
+_lib = _native._lib
+_vp, _ci, _cl, _cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_lib.pn2x_bn_stats.argtypes = [_cl, _ci, _vp, _ci, _vp, _vp]
+_lib.pn2x_bn_relu_apply.argtypes = [_cl, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp]
+_lib.pn2x_bn_relu_bwd.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
+_lib.pn2x_scatter_add_rows.argtypes = [_ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _ci, _vp]
+_lib.pn2x_three_interpolate_pm_grad.argtypes = [_ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp]
+_lib.pn2x_sa_layer1.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
+for _n in ("pn2x_bn_stats", "pn2x_bn_relu_apply", "pn2x_bn_relu_bwd", "pn2x_scatter_add_rows", "pn2x_three_interpolate_pm_grad",
+           "pn2x_sa_layer1"):
+    getattr(_lib, _n).restype = _ci
+
+_f32 = torch.float32
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    if not t.is_cuda or t.dtype != _f32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+        raise ValueError(f"{name}: expected a 2-D float32 GPU tensor with contiguous rows (stride multiple of 4, 16-byte aligned), "
+                         f"got shape {tuple(t.shape)} strides {t.stride()} on {t.device}")
+    return t.data_ptr(), t.stride(0)
+
+
+class Workspace:
+    """Zeroed fp64 accumulators for the BatchNorm reductions of one training step: reset() = one fill launch, take(n)
+    hands out consecutive slices.  The capacity grows on demand outside graph capture."""
+
+    def __init__(self, device, capacity: int = 1 << 16):
+        self.buf = torch.zeros(capacity, dtype=torch.float64, device=device)
+        self.used = 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.used = 0
+
+    def take(self, n: int) -> torch.Tensor:
+        if self.used + n > self.buf.numel():
+            raise RuntimeError("train_ops.Workspace exhausted: construct it with a larger capacity")
+        out = self.buf[self.used:self.used + n]
+        self.used += n
+        return out
+
+
+class _BnRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, conv_bias, running_mean, running_var, nbt, eps, momentum, relu, ws_f, ws_b):
+        py, ldy = _rows2d(y, "y")
+        R, C = y.shape
+        h = torch.empty((R, C), dtype=_f32, device=y.device)
+        saved = torch.empty((2, C), dtype=_f32, device=y.device)
+        st = _native._stream(y)
+        with torch.cuda.device(y.device):
+            _native._check(_lib.pn2x_bn_stats(R, C, py, ldy, ws_f.data_ptr(), st), "bn_stats")
+            _native._check(_lib.pn2x_bn_relu_apply(R, C, py, ldy, ws_f.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(conv_bias),
+                                                   float(eps), float(momentum), _p(running_mean), _p(running_var), _p(nbt),
+                                                   saved[0].data_ptr(), saved[1].data_ptr(), h.data_ptr(), C, 1 if relu else 0, st),
+                           "bn_relu_apply")
+        ctx.save_for_backward(y, gamma, beta, saved)
+        ctx.ws_b, ctx.relu, ctx.has_bias = ws_b, relu, conv_bias is not None
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        y, gamma, beta, saved = ctx.saved_tensors
+        dh = dh.contiguous()
+        R, C = y.shape
+        dy = torch.empty((R, C), dtype=_f32, device=y.device)
+        dpar = torch.empty((3, C), dtype=_f32, device=y.device)
+        with torch.cuda.device(y.device):
+            _native._check(_lib.pn2x_bn_relu_bwd(R, C, dh.data_ptr(), C, y.data_ptr(), y.stride(0), saved[0].data_ptr(), saved[1].data_ptr(),
+                                                 gamma.data_ptr(), beta.data_ptr(), 1 if ctx.relu else 0, ctx.ws_b.data_ptr(), dy.data_ptr(), C,
+                                                 dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(), _native._stream(y)), "bn_relu_bwd")
+        return dy, dpar[0], dpar[1], (dpar[2] if ctx.has_bias else None), None, None, None, None, None, None, None, None
+
+
+def bn_relu(y: torch.Tensor, bn: torch.nn.Module, ws: Workspace, conv_bias: torch.Tensor = None, relu: bool = True) -> torch.Tensor:
+    """relu(BatchNorm_train(y + conv_bias)) for y (R, C) point-major; `bn` supplies weight / bias / running statistics /
+    momentum / eps (torch.nn.BatchNorm1d|2d semantics incl. the running-statistics update).  conv_bias only shifts the
+    batch mean, so y is taken WITHOUT it; its gradient is identically zero and is returned as zeros."""
+    C = y.shape[1]
+    track = bn.track_running_stats and bn.running_mean is not None
+    return _BnRelu.apply(y, bn.weight, bn.bias, conv_bias, bn.running_mean if track else None, bn.running_var if track else None,
+                         bn.num_batches_tracked if track else None, bn.eps, bn.momentum if bn.momentum is not None else 0.1, relu,
+                         ws.take(2 * C), ws.take(2 * C))
+
+
+def scatter_add_rows(dout: torch.Tensor, idx: torch.Tensor, din: torch.Tensor) -> torch.Tensor:
+    """din[b, idx[b,j], :] += dout[b, j, :]; dout (B,M,C) contiguous, idx (B,M) int32, din (B,N,>=C) rows (may be a column block)."""
+    B, M, C = dout.shape
+    N = din.shape[1]
+    with torch.cuda.device(dout.device):
+        _native._check(_lib.pn2x_scatter_add_rows(B, N, M, C, _native._ptr(dout, "dout", _f32, B * M * C), C,
+                                                  _native._ptr(idx, "idx", torch.int32, B * M), din.data_ptr(), din.stride(1),
+                                                  _native._stream(dout)), "scatter_add_rows")
+    return din
+
+
+class _SaLayer1(torch.autograd.Function):
+    """One module call = all its scales: a1f (B,N,sum C1) | None, cadd (B,S,sum C1) | None, then per scale (idx_i, wx_i)."""
+
+    @staticmethod
+    def forward(ctx, a1f, cadd, xyz, cxyz, n_scales, *rest):
+        idxs, wxs = rest[:n_scales], rest[n_scales:]
+        B, N, _ = xyz.shape
+        S = cxyz.shape[1]
+        outs, rels = [], []
+        col = 0
+        st = _native._stream(xyz)
+        for idx, wx in zip(idxs, wxs):
+            K, C1 = idx.shape[2], wx.shape[0]
+            out = torch.empty((B, S * K, C1), dtype=_f32, device=xyz.device)
+            rel = torch.empty((B, S * K, 3), dtype=_f32, device=xyz.device)
+            wxc = wx.contiguous()
+            with torch.cuda.device(xyz.device):
+                _native._check(_lib.pn2x_sa_layer1(
+                    B, N, S, K, C1, None if a1f is None else a1f.data_ptr() + 4 * col, 0 if a1f is None else a1f.stride(1),
+                    xyz.data_ptr(), cxyz.data_ptr(), wxc.data_ptr(), None if cadd is None else cadd.data_ptr() + 4 * col,
+                    0 if cadd is None else cadd.stride(1), _native._ptr(idx, "idx", torch.int32, B * S * K), out.data_ptr(),
+                    rel.data_ptr(), st), "sa_layer1")
+            outs.append(out)
+            rels.append(rel)
+            col += C1
+        ctx.save_for_backward(*idxs, *rels)
+        ctx.meta = (n_scales, None if a1f is None else tuple(a1f.shape), None if cadd is None else tuple(cadd.shape), S)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        n, a1f_shape, cadd_shape, S = ctx.meta
+        idxs, rels = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dev = douts[0].device
+        d_a1f = torch.zeros(a1f_shape, dtype=_f32, device=dev) if a1f_shape is not None else None
+        d_cadd = torch.empty(cadd_shape, dtype=_f32, device=dev) if cadd_shape is not None else None
+        d_wx = []
+        col = 0
+        for dy, idx, rel in zip(douts, idxs, rels):
+            dy = dy.contiguous()
+            B, SK, C1 = dy.shape
+            if d_a1f is not None:
+                scatter_add_rows(dy, idx.view(B, SK), d_a1f[:, :, col:col + C1])
+            if d_cadd is not None:
+                torch.sum(dy.view(B, S, SK // S, C1), dim=2, out=d_cadd[:, :, col:col + C1])
+            d_wx.append(torch.mm(dy.view(B * SK, C1).t(), rel.view(B * SK, 3)))
+            col += C1
+        return (d_a1f, d_cadd, None, None, None, *([None] * n), *d_wx)
+
+
+def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs):
+    """Layer-1 pre-activations of every scale of one SA module: list of (B, S*K_i, C1_i).
+    a1f (B,N,sum C1) per-point feature terms [scale 0 | scale 1 ...] or None; cadd (B,S,sum C1) per-centroid terms or None;
+    xyz (B,N,3), cxyz (B,S,3) (no gradient); idxs[i] (B,S,K_i) int32; wxs[i] (C1_i, 3)."""
+    return list(_SaLayer1.apply(a1f, cadd, xyz, cxyz, len(idxs), *idxs, *wxs))
+
+
+class _InterpRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx, weight):
+        from . import ext
+        B, M, C = points.shape
+        n = idx.shape[1]
+        out = torch.empty((B, n, C), dtype=_f32, device=points.device)
+        ext.three_interpolate_pm(points, idx, weight, out)
+        ctx.save_for_backward(idx, weight)
+        ctx.m = M
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, weight = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, n, C = dout.shape
+        dp = torch.zeros((B, ctx.m, C), dtype=_f32, device=dout.device)
+        with torch.cuda.device(dout.device):
+            _native._check(_lib.pn2x_three_interpolate_pm_grad(B, C, ctx.m, n, dout.data_ptr(), C, idx.data_ptr(), weight.data_ptr(),
+                                                               dp.data_ptr(), C, _native._stream(dout)), "three_interpolate_pm_grad")
+        return dp, None, None
+
+
+def interpolate_rows(points: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """points (B,M,C) contiguous, idx / weight (B,n,3) -> (B,n,C); gradient to points only (reference pointnet2_utils.py:190)."""
+    return _InterpRows.apply(points.contiguous(), idx, weight)

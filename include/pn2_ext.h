@@ -175,6 +175,57 @@ int pn2x_add_layernorm(long rows, int c, const float *x, const float *y, const f
 int pn2x_pose_head(int b, int j, int c, const float *h, const float *w, const float *bias, const float *xyz1,
                    const float *R, const float *t, float scale, float *kp_hand, float *kp_cam, void *stream);
 
+/*
+ * ---- training-mode building blocks on point-major activations (hotrack_amd/csrc/train_ops.hip) --------------------------
+ * The reference trains every grouped MLP as Conv2d(1x1) + BatchNorm2d + ReLU on channel-major (B, C, S, K) tensors
+ * (pointnet_utils.py:399-403, :460-462, :504-506, :577-581).  A 1x1 convolution is a GEMM over all R = B*S*K positions
+ * (library GEMM on point-major rows); what sits between two GEMMs is one pair of streaming kernels per direction.
+ * Rows are `c` floats wide (c % 4 == 0, c <= 1024) with a row stride `ld*` (multiple of 4), 16-byte aligned.
+ *
+ * pn2x_bn_stats: sums[0:c] += sum_r y[r,:], sums[c:2c] += sum_r y[r,:]^2  (fp64 accumulators, zeroed by the caller).
+ */
+int pn2x_bn_stats(long rows, int c, const float *y, int ldy, double *sums, void *stream);
+/*
+ * pn2x_bn_relu_apply: batch statistics from `sums` (biased variance, eps inside the sqrt -- torch.nn.BatchNorm semantics),
+ * h = relu?(gamma * (y - mean) * invstd + beta); writes save_mean / save_invstd (c floats each, for the backward) and,
+ * when running_mean != NULL, the running-statistics update running = (1 - momentum) running + momentum batch (variance
+ * unbiased) and num_batches_tracked += 1.  conv_bias (or NULL) is the bias of the preceding convolution: it cancels in
+ * the normalisation, so y is computed without it and it is only added to the running mean.
+ */
+int pn2x_bn_relu_apply(long rows, int c, const float *y, int ldy, const double *sums, const float *gamma, const float *beta,
+                       const float *conv_bias, float eps, float momentum, float *running_mean, float *running_var,
+                       long long *num_batches_tracked, float *save_mean, float *save_invstd, float *h, int ldh, int relu,
+                       void *stream);
+/*
+ * pn2x_bn_relu_bwd: with g = dh * [h > 0] (h recomputed from y), xhat = (y - mean) * invstd:
+ *   dbeta = sum_r g, dgamma = sum_r g * xhat, dy = gamma * invstd * (g - dbeta / R - xhat * dgamma / R).
+ * sums: 2c fp64 accumulators zeroed by the caller (two launches: reduce, apply).  dbias (or NULL): gradient of the bias of
+ * the convolution in front of the BatchNorm -- sum_r dy, identically zero -- written as zeros.
+ */
+int pn2x_bn_relu_bwd(long rows, int c, const float *dh, int ldd, const float *y, int ldy, const float *mean,
+                     const float *invstd, const float *gamma, const float *beta, int relu, double *sums, float *dy, int ldo,
+                     float *dgamma, float *dbeta, float *dbias, void *stream);
+/*
+ * Layer 1 of a set-abstraction scale in TRAINING mode, pre-activation, without materialising the grouped input
+ * [feat_j | xyz_j - c_s | centre_feat_s] (reference pointnet_utils.py:389-399, :566-577): the same linear split as
+ * pn2x_sa_mlp_max (a1f / wx / cadd, each optional, see above), bias omitted because BatchNorm follows.
+ *   out (b, s*k, c1) point-major; rel_out (b, s*k, 3) or NULL receives xyz_j - c_s (the backward's d(wx) operand).
+ */
+int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
+                   const float *wx, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out, void *stream);
+/*
+ * Transpose of pn2x_gather_rows (group_points_grad on point-major rows, reference group_points_gpu.cu:8-25):
+ *   din[b, idx[b,j], :] += dout[b, j, :]      dout (b, m, ldo), idx (b, m) int32, din (b, n, ldi) accumulated into.
+ */
+int pn2x_scatter_add_rows(int b, int n, int m, int c, const float *dout, int ldo, const int *idx, float *din, int ldi,
+                          void *stream);
+/*
+ * Transpose of pn2x_three_interpolate_pm (three_interpolate_grad on rows, reference interpolate_gpu.cu:192-214):
+ *   dpoints[b, idx[b,j,t], :] += weight[b,j,t] * dout[b, j, :]   dout (b, n, ldo), dpoints (b, m, ldp) accumulated into.
+ */
+int pn2x_three_interpolate_pm_grad(int b, int c, int m, int n, const float *dout, int ldo, const int *idx,
+                                   const float *weight, float *dpoints, int ldp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,142 @@
+"""Point-major TRAINING forward of HandTrackNet's PointNet++ part (backbone + the two keypoint query modules) for MI355X.
+
+Same parameters, same mathematics as the module path (`PointNet2Msg_fast`, `PointNetSetAbstractionMsg_GivenCenterPoints`,
+`rearrange_module`; reference backbones.py:114-133, pointnet_utils.py:368-409, :424-464, :484-512, :536-590, blocks.py:226-239)
+-- train-mode BatchNorm with batch statistics and running-statistics updates included -- but laid out for the GPU:
+
+  * activations are point-major (rows = B*S*K positions, channels contiguous): a 1x1 convolution is ONE library GEMM over all
+    rows (no convolution-library call, no NCHW<->NHWC transposes), and BatchNorm + ReLU between two GEMMs is one stats kernel +
+    one apply kernel forward, one reduce + one apply kernel backward (hotrack_amd.train_ops);
+  * the grouped inputs [feat_j | xyz_j - c_s | centre feat] are never materialised: layer 1 is linear, so its per-point half
+    is a GEMM over the N points and the rest is assembled by pn2x_sa_layer1 (gather + relative coordinates + centre term);
+    the backward is a row scatter-add;
+  * q1 / q2 share one kNN search (the K=16 list is the prefix of the K=64 list).
+
+The module path (pointnet_utils.py in this directory) remains the general fallback; tests compare the two
+(tests/test_gpu_train.py) and both against the reference's golden training step.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def _w2d(conv):
+    return conv.weight.view(conv.weight.shape[0], -1)
+
+
+class FastTrain:
+    def __init__(self, net):
+        self.net = net
+        self.ws = None
+
+    @staticmethod
+    def supported(net) -> bool:
+        bh = net.bhand
+        mods = (bh.sa1, bh.sa2, net.q1, net.q2)
+        if bh.in_dim != 0 or not bh.sa3.group_all or bh.sa1.knn or bh.sa2.knn or not (net.q1.knn and net.q2.knn):
+            return False
+        if len(bh.sa1.conv_blocks) != 1 or len(bh.sa2.conv_blocks) != 1 or list(net.q1.nsample_list) != list(net.q2.nsample_list):
+            return False
+        widths = [c.weight.shape[0] for m in mods for convs in m.conv_blocks for c in convs]
+        widths += [c.weight.shape[0] for m in (bh.sa3, bh.fp3, bh.fp2, bh.fp1) for c in m.mlp_convs] + [bh.conv1.weight.shape[0]]
+        return all(w % 4 == 0 and w <= 1024 for w in widths)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _stack(self, x2d, convs, bns, first_done=False):
+        from hotrack_amd.train_ops import bn_relu
+        for i, (conv, bn) in enumerate(zip(convs, bns)):
+            y = x2d if (first_done and i == 0) else F.linear(x2d, _w2d(conv))
+            x2d = bn_relu(y, bn, self.ws, conv.bias)
+        return x2d
+
+    def _sa_scales(self, mod, xyz, cxyz, feat2d, idxs, center2d=None):
+        """All scales of one SA module.  xyz (B,N,3), cxyz (B,S,3), feat2d (B*N, D)|None, center2d (B*S, D2)|None ->
+        (B, S, sum C3) point-major."""
+        from hotrack_amd.train_ops import sa_layer1
+        B, N, _ = xyz.shape
+        S = cxyz.shape[1]
+        D = 0 if feat2d is None else feat2d.shape[1]
+        w1 = [_w2d(convs[0]) for convs in mod.conv_blocks]
+        a1f = cadd = None
+        if D:
+            wf = w1[0][:, :D] if len(w1) == 1 else torch.cat([w[:, :D] for w in w1], dim=0)
+            a1f = F.linear(feat2d, wf).view(B, N, -1)
+        if center2d is not None:
+            wc = w1[0][:, D + 3:] if len(w1) == 1 else torch.cat([w[:, D + 3:] for w in w1], dim=0)
+            cadd = F.linear(center2d, wc).view(B, S, -1)
+        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[:, D:D + 3] for w in w1])
+        outs = []
+        for i, y1 in enumerate(y1s):
+            K = idxs[i].shape[2]
+            h = self._stack(y1.view(B * S * K, -1), mod.conv_blocks[i], mod.bn_blocks[i], first_done=True)
+            outs.append(h.view(B * S, K, -1).max(dim=1)[0].view(B, S, -1))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
+
+    def _fp(self, mod, xyz1, xyz2, points1, points2):
+        """xyz1 (B,N,3), xyz2 (B,S,3), points1 (B,N,D1)|None, points2 (B,S,D2) -> (B*N, D') rows."""
+        from hotrack_amd import ext
+        from hotrack_amd.train_ops import interpolate_rows
+        B, N, _ = xyz1.shape
+        if xyz2.shape[1] == 1:
+            interp = points2.expand(B, N, points2.shape[2])
+        else:
+            w, i3 = ext.three_nn_weights(xyz1, xyz2)
+            interp = interpolate_rows(points2, i3, w)
+        x = interp if points1 is None else torch.cat([points1, interp], dim=2)
+        return self._stack(x.reshape(B * N, -1), mod.mlp_convs, mod.mlp_bns)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def forward(self, xyz2_cm: torch.Tensor, xyz1_cm: torch.Tensor):
+        """xyz2_cm (B,3,N) hand-frame cloud, xyz1_cm (B,3,J) hand-frame keypoints (no gradient flows into coordinates:
+        they derive from the inputs only) -> f14 (B,C,J) channel-major as `r2` returns it, src2 (B,N,C) point-major."""
+        from hotrack_amd import ext
+        from hotrack_amd import pointnet2_utils as ops
+        from hotrack_amd.train_ops import Workspace
+        net, bh = self.net, self.net.bhand
+        dev = xyz2_cm.device
+        if self.ws is None or self.ws.buf.device != dev:
+            self.ws = Workspace(dev)
+        self.ws.reset()  # one fill launch: the fp64 accumulators of every BatchNorm reduction of this step, both directions
+        xyz = xyz2_cm.detach().transpose(1, 2).contiguous()   # (B,N,3)
+        kp = xyz1_cm.detach().transpose(1, 2).contiguous()    # (B,J,3)
+        B, N, _ = xyz.shape
+        J = kp.shape[1]
+
+        # ---- backbone: sa1, sa2, sa3 (group-all), fp3, fp2, fp1, conv1 -------------------------------------------------
+        S1, S2 = bh.sa1.npoint, bh.sa2.npoint
+        l1_xyz = ext.gather_rows(xyz, ops.furthest_point_sample(xyz, S1))
+        idx1 = ops.ball_query(bh.sa1.radius_list[0], bh.sa1.nsample_list[0], xyz, l1_xyz)
+        l1_feat = self._sa_scales(bh.sa1, xyz, l1_xyz, None, [idx1])                                   # (B,S1,64)
+        l2_xyz = ext.gather_rows(l1_xyz, ops.furthest_point_sample(l1_xyz, S2))
+        idx2 = ops.ball_query(bh.sa2.radius_list[0], bh.sa2.nsample_list[0], l1_xyz, l2_xyz)
+        l2_feat = self._sa_scales(bh.sa2, l1_xyz, l2_xyz, l1_feat.reshape(B * S1, -1), [idx2])        # (B,S2,128)
+        x = torch.cat([l2_xyz, l2_feat], dim=2).view(B * S2, -1)   # group-all: [xyz | feat], centre = origin (not subtracted)
+        l3 = self._stack(x, bh.sa3.mlp_convs, bh.sa3.mlp_bns).view(B, S2, -1).max(dim=1, keepdim=True)[0]   # (B,1,512)
+        l2_out = self._fp(bh.fp3, l2_xyz, l2_xyz[:, :1], l2_feat, l3).view(B, S2, -1)
+        l1_out = self._fp(bh.fp2, l1_xyz, l2_xyz, l1_feat, l2_out).view(B, S1, -1)
+        l0_out = self._fp(bh.fp1, xyz, l1_xyz, xyz, l1_out)                                             # (B*N, 128), skip = xyz
+        from hotrack_amd.train_ops import bn_relu
+        src2 = bn_relu(F.linear(l0_out, _w2d(bh.conv1)), bh.bn1, self.ws, bh.conv1.bias)               # (B*N, C)
+        C = src2.shape[1]
+
+        # ---- q1 -> r1 -> q2 -> r2 around the J keypoints; one kNN search for both neighbourhood sizes ------------------
+        Ks = list(net.q1.nsample_list)
+        kmax = max(Ks)
+        if N <= 2048 and len(set(Ks)) == 2 and len(Ks) == 2:
+            gi, gi_small = ext.knn_indices(kmax, kp, xyz, k2=min(Ks))
+            idxs = [gi if K == kmax else gi_small for K in Ks]
+        else:
+            idxs = [ops.knn(K, kp, xyz)[1] for K in Ks]
+        f11 = self._sa_scales(net.q1, xyz, kp, src2, idxs)                                              # (B,J,C)
+        f12 = self._rearrange(net.r1, f11)                                                                 # (B*J, C)
+        f13 = self._sa_scales(net.q2, xyz, kp, src2, idxs, center2d=f12)
+        f14 = self._rearrange(net.r2, f13).view(B, J, C)
+        return f14.transpose(1, 2), src2.view(B, N, C)
+
+    @staticmethod
+    def _rearrange(mod, tok):
+        """rearrange_module on token-major features tok (B,J,C) -> (B*J, C) (blocks.py: fast formula)."""
+        B, J, C = tok.shape
+        g = tok[:, mod._perm.t()]  # (B, J, re, C)
+        return F.linear(g.reshape(B * J, mod.re * C), mod.linear.weight.squeeze(-1), mod.linear.bias)

@@ -66,6 +66,8 @@ class HandTrackNet(nn.Module):
         self.elide_dead_attention = elide_dead_attention
         self.use_fast_eval = True  # eval + fused backend + GPU -> models/fast_eval.py (set False to force this file's path)
         self._fast = None
+        self.use_fast_train = True  # training on the GPU -> models/fast_train.py (point-major GEMM + fused BatchNorm/ReLU kernels)
+        self._ftrain = None
         self.bhand = PointNet2Msg_fast(cfg, C)
         self.r1 = rearrange_module(channel=C)
         self.r2 = rearrange_module(channel=C)
@@ -134,11 +136,22 @@ class HandTrackNet(nn.Module):
 
         fast = (pointnet_utils.fused_backend() is not None and cam.is_cuda and not self.training
                 and not torch.is_grad_enabled())
-        src2 = self.bhand(xyz2)  # (B,C,N)
-        f11, group_idx = self.q1(xyz2, src2, xyz1, None, return_group_idx=True)
-        f12 = self.r1(f11, True)
-        f13 = self.q2(xyz2, src2, xyz1, f12, pre_group_idx=group_idx)
-        f14 = self.r2(f13, True)
+        ftrain = None
+        use_ft = getattr(self, "_force_fast_train", self.use_fast_train)  # class-level override: tests compare the two paths
+        if self.training and use_ft and cam.is_cuda and pointnet_utils.hip_backend_active():
+            if self._ftrain is None:
+                from .fast_train import FastTrain
+                self._ftrain = FastTrain(self) if FastTrain.supported(self) else False
+            ftrain = self._ftrain or None
+        if ftrain is not None:  # point-major training path, same mathematics (tests/test_gpu_train.py)
+            f14, src2_pm = ftrain.forward(xyz2, xyz1)
+            src2 = None if elide else src2_pm.transpose(1, 2)
+        else:
+            src2 = self.bhand(xyz2)  # (B,C,N)
+            f11, group_idx = self.q1(xyz2, src2, xyz1, None, return_group_idx=True)
+            f12 = self.r1(f11, True)
+            f13 = self.q2(xyz2, src2, xyz1, f12, pre_group_idx=group_idx)
+            f14 = self.r2(f13, True)
         f15, f251 = self.transt(src1=f14, pos1=pos1, src2=src2, pos2=pos2, attn=False, elide_dead=elide,
                                 need_result2=not elide)
         fused = self.c3(f15, pos1, f251, pos2, attn=False, elide_dead=elide)

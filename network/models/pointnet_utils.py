@@ -45,6 +45,11 @@ def set_operator_backend(module) -> None:
     _OPS = module
 
 
+def hip_backend_active() -> bool:
+    """True when the operator namespace is the product's HIP one (not a test-injected CPU oracle)."""
+    return _OPS is None or getattr(_OPS, "__name__", "") == "hotrack_amd.pointnet2_utils"
+
+
 def set_fused_backend(module) -> None:
     """Enable / disable (None) the eval-time fused set-abstraction kernels."""
     global _FUSED

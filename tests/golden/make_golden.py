@@ -242,6 +242,11 @@ def gen_network(ref_pu, ref_hn):
     total64.backward()
     out["train_total_loss_f64"] = np.array(float(total64))
     out["param_grad_norm_f64"] = np.array([0.0 if p.grad is None else float(p.grad.norm()) for _, p in model64.named_parameters()])
+    # element-wise fp64 gradients (first 1024 entries of each live parameter): the truth two fp32 implementations are judged
+    # against when they disagree with each other (train-mode BatchNorm chains amplify fp32 round-off to the per-cent level)
+    for n, p in model64.named_parameters():
+        if p.grad is not None:
+            out["g64/" + n] = p.grad.flatten()[:1024].numpy().astype(np.float64)
     ref_pu.futils = torch_ops
     np.savez_compressed(os.path.join(HERE, "handtracknet_reference.npz"), **out)
     n_none = int(out["param_grad_is_none"].sum())

@@ -15,8 +15,13 @@ sys.path.insert(0, os.path.join(ROOT, "network"))
 pytestmark = pytest.mark.gpu
 
 
-def test_train_step_hip_operators_match_reference_golden(monkeypatch):
+@pytest.mark.parametrize("fast", [False, True])
+def test_train_step_hip_operators_match_reference_golden(monkeypatch, fast):
+    """fast=False: module path (channel-major, the ten reference operators forward + backward);
+    fast=True: point-major training path (models/fast_train.py, hotrack_amd/train_ops.py) -- the default on the GPU."""
     import test_network as tn
+    from models.hand_network import HandTrackNet
+    monkeypatch.setattr(HandTrackNet, "_force_fast_train", fast, raising=False)
     from hotrack_amd import pointnet2_hip
     calls = {}
     for name in pointnet2_hip.EXPORTED:
@@ -38,10 +43,12 @@ def test_train_step_hip_operators_match_reference_golden(monkeypatch):
     truth = gold["param_grad_norm_f64"]
     live = truth > 1e-6 * truth.max()
     np.testing.assert_allclose(gn[live], truth[live], rtol=1e-2, atol=5e-4)
+    assert bool(model._ftrain) == fast
     # the HIP operators (forward and backward) carried the step
-    for name in ("furthest_point_sampling_wrapper", "ball_query_wrapper", "knn_wrapper", "three_nn_wrapper",
-                 "three_interpolate_wrapper", "three_interpolate_grad_wrapper", "group_points_wrapper",
-                 "group_points_grad_wrapper"):
+    names = ("furthest_point_sampling_wrapper", "ball_query_wrapper") if fast else (
+        "furthest_point_sampling_wrapper", "ball_query_wrapper", "knn_wrapper", "three_nn_wrapper", "three_interpolate_wrapper",
+        "three_interpolate_grad_wrapper", "group_points_wrapper", "group_points_grad_wrapper")
+    for name in names:
         assert calls.get(name, 0) > 0, (name, calls)
 
 
@@ -51,3 +58,155 @@ def test_train_step_is_run_to_run_stable():
     a = float(tn._train_step("cuda", True)[2])
     b = float(tn._train_step("cuda", True)[2])
     assert abs(a - b) <= 1e-6 * abs(a)
+
+
+# ---- the point-major training operators one by one ----------------------------------------------------------------------
+@pytest.mark.parametrize("R,C", [(4096, 32), (1000, 64), (21 * 16 * 3, 128), (777, 192), (5000, 384), (333, 512), (7, 4)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_relu_matches_torch_batchnorm(R, C, relu):
+    from hotrack_amd.train_ops import Workspace, bn_relu
+    g = torch.Generator(device="cuda").manual_seed(R + C)
+    y0 = torch.randn(R, C, device="cuda", generator=g) * 2 + 0.5
+    bias = torch.randn(C, device="cuda", generator=g)
+    go = torch.randn(R, C, device="cuda", generator=g)
+    bn_a, bn_b = torch.nn.BatchNorm1d(C).cuda().train(), torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(1 + 0.3 * torch.randn(C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)))
+            bn.bias.copy_(0.2 * torch.randn(C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)))
+            bn.momentum = 0.05
+    ws = Workspace("cuda")
+    ya = y0.clone().requires_grad_(True)
+    ba = bias.clone().requires_grad_(True)
+    ha = bn_relu(ya, bn_a, ws, ba, relu=relu)
+    ha.backward(go)
+    yb = y0.clone().requires_grad_(True)
+    bb = bias.clone().requires_grad_(True)
+    hb = bn_b(yb + bb)
+    hb = torch.relu(hb) if relu else hb
+    hb.backward(go)
+    torch.testing.assert_close(ha, hb, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
+    scale = float(yb.grad.abs().max())
+    torch.testing.assert_close(ya.grad, yb.grad, rtol=1e-4, atol=2e-5 * max(scale, 1.0))
+    torch.testing.assert_close(bn_a.weight.grad, bn_b.weight.grad, rtol=1e-4, atol=1e-4 * float(bn_b.weight.grad.abs().max()))
+    torch.testing.assert_close(bn_a.bias.grad, bn_b.bias.grad, rtol=1e-4, atol=1e-4 * float(bn_b.bias.grad.abs().max()))
+    assert ba.grad is not None and float(ba.grad.abs().max()) == 0.0      # analytically zero
+    assert float(bb.grad.abs().max()) < 1e-3 * float(bn_b.bias.grad.abs().max() + 1)   # torch: round-off only
+
+
+@pytest.mark.parametrize("with_feat,with_centre,Ks", [(False, False, [32]), (True, False, [32]), (True, True, [16, 64]), (True, False, [16, 64])])
+def test_sa_layer1_matches_grouped_reference(with_feat, with_centre, Ks, oracle):
+    from hotrack_amd.train_ops import sa_layer1
+    B, N, S, D, C1 = 3, 300, 21, 24, 32
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xyz = torch.rand(B, N, 3, device="cuda", generator=g)
+    cxyz = torch.rand(B, S, 3, device="cuda", generator=g)
+    feat = torch.randn(B, N, D, device="cuda", generator=g)
+    cfeat = torch.randn(B, S, D, device="cuda", generator=g)
+    idxs = [torch.randint(0, N, (B, S, K), device="cuda", generator=g, dtype=torch.int32) for K in Ks]
+    Cin = (D if with_feat else 0) + 3 + (D if with_centre else 0)
+    Ws = [torch.randn(C1, Cin, device="cuda", generator=g).requires_grad_(True) for _ in Ks]
+    Df = D if with_feat else 0
+
+    def run(fused):
+        for W in Ws:
+            W.grad = None
+        f = feat.clone().requires_grad_(True)
+        cf = cfeat.clone().requires_grad_(True)
+        if fused:
+            a1f = torch.nn.functional.linear(f.view(B * N, D), torch.cat([W[:, :Df] for W in Ws])).view(B, N, -1) if with_feat else None
+            cadd = torch.nn.functional.linear(cf.view(B * S, D), torch.cat([W[:, Df + 3:] for W in Ws])).view(B, S, -1) if with_centre else None
+            outs = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [W[:, Df:Df + 3] for W in Ws])
+        else:
+            outs = []
+            for W, idx in zip(Ws, idxs):
+                K = idx.shape[2]
+                ii = idx.long().view(B, S * K)
+                parts = []
+                if with_feat:
+                    parts.append(torch.gather(f, 1, ii.unsqueeze(-1).expand(-1, -1, D)))
+                parts.append(torch.gather(xyz, 1, ii.unsqueeze(-1).expand(-1, -1, 3)) - cxyz.repeat_interleave(K, dim=1))
+                if with_centre:
+                    parts.append(cf.repeat_interleave(K, dim=1))
+                outs.append(torch.nn.functional.linear(torch.cat(parts, dim=2), W))
+        loss = sum((o * torch.cos(o.detach() * 0.1 + i)).sum() for i, o in enumerate(outs))
+        loss.backward()
+        return [o.detach() for o in outs], f.grad, cf.grad, [W.grad.clone() for W in Ws]
+
+    oa, fa, ca, wa = run(True)
+    ob, fb, cb, wb = run(False)
+    for a, b in zip(oa, ob):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)
+    if with_feat:
+        torch.testing.assert_close(fa, fb, rtol=1e-4, atol=1e-3)
+    if with_centre:
+        torch.testing.assert_close(ca, cb, rtol=1e-4, atol=1e-3)
+    for a, b in zip(wa, wb):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
+
+def test_interpolate_rows_matches_operator_api():
+    from hotrack_amd import pointnet2_utils as ops
+    from hotrack_amd.train_ops import interpolate_rows
+    B, M, n, C = 3, 128, 500, 64
+    g = torch.Generator(device="cuda").manual_seed(9)
+    pts = torch.randn(B, M, C, device="cuda", generator=g)
+    idx = torch.randint(0, M, (B, n, 3), device="cuda", generator=g, dtype=torch.int32)
+    w = torch.rand(B, n, 3, device="cuda", generator=g)
+    w = w / w.sum(-1, keepdim=True)
+    go = torch.randn(B, n, C, device="cuda", generator=g)
+    a = pts.clone().requires_grad_(True)
+    oa = interpolate_rows(a, idx, w)
+    oa.backward(go)
+    b = pts.clone().requires_grad_(True)
+    ob = ops.three_interpolate(b.transpose(1, 2).contiguous(), idx, w)  # channel-major operator (reference API)
+    ob.backward(go.transpose(1, 2).contiguous())
+    torch.testing.assert_close(oa, ob.transpose(1, 2), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_fast_train_path_equals_module_path():
+    """Same weights, same batch: point-major training path vs the channel-major module path.  The forward must agree
+    tightly (loss, BatchNorm running statistics, counters).  Gradients of two fp32 implementations agree only to the
+    per-cent level element-wise (train-mode BatchNorm chains amplify round-off), so each path is judged against the
+    ELEMENT-WISE fp64 gradients of the imported reference's train step (golden `g64/*`, make_golden.py) and the
+    point-major path must not be further from that truth than the module path."""
+    import test_network as tn
+    from models.hand_network import HandTrackNet
+    res = {}
+    for fast in (False, True):
+        HandTrackNet._force_fast_train = fast
+        try:
+            model, ret, total = tn._train_step("cuda", True)
+        finally:
+            del HandTrackNet._force_fast_train
+        assert bool(model._ftrain) == fast
+        res[fast] = (model, float(total))
+    (ma, la), (mb, lb) = res[False], res[True]
+    assert abs(la - lb) < 2e-5 * abs(la), (la, lb)
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    err = {False: [], True: []}
+    for k in pa:
+        assert (pa[k].grad is None) == (pb[k].grad is None), k
+        if pa[k].grad is None:
+            continue
+        t = torch.from_numpy(tn.GOLD["g64/" + k]).cuda()
+        scale = float(t.abs().max())
+        if scale < 1e-6:  # analytically zero (biases in front of a train-mode BatchNorm): round-off in A, exact zeros in B
+            assert float(pb[k].grad.abs().max()) <= 1e-5, k
+            continue
+        for fast, p in ((False, pa[k]), (True, pb[k])):
+            e = float((p.grad.flatten()[:1024].double() - t).abs().max()) / scale
+            assert e < 0.12, (k, fast, e)
+            err[fast].append(e)
+    mean = {f: sum(v) / len(v) for f, v in err.items()}
+    assert mean[True] <= 1.25 * mean[False] + 1e-3, mean
+    ba, bb = dict(ma.named_buffers()), dict(mb.named_buffers())
+    for k in ba:
+        if k.endswith("num_batches_tracked"):
+            assert int(ba[k]) == int(bb[k]), k
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            torch.testing.assert_close(bb[k], ba[k], rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
