@@ -22,6 +22,7 @@
 namespace pn2 {
 
 constexpr int kTT = 256;
+constexpr int kRep = 8;  // the fp64 accumulators exist kRep times (workgroup b adds into copy b % kRep): 8x less same-address contention
 
 struct BnCh {  // per-thread constants of its 4 channels
     float mean[4], invstd[4], g[4], b[4];
@@ -31,8 +32,13 @@ __device__ __forceinline__ void bn_consts(BnCh &k, int C, int c0, long rows, con
                                           const float *__restrict__ gamma, const float *__restrict__ beta, double *var_out) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const double m = sums[c0 + i] / (double)rows;
-        double v = sums[C + c0 + i] / (double)rows - m * m;
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < kRep; ++r) {
+            s1 += sums[(size_t)r * 2 * C + c0 + i];
+            s2 += sums[(size_t)r * 2 * C + C + c0 + i];
+        }
+        const double m = s1 / (double)rows;
+        double v = s2 / (double)rows - m * m;
         v = v > 0.0 ? v : 0.0;
         k.mean[i] = (float)m;
         k.invstd[i] = (float)(1.0 / sqrt(v + (double)eps));
@@ -60,10 +66,11 @@ __device__ __forceinline__ void block_reduce_to_sums(float4 a, float4 b, int Q, 
             t[0] += v.x; t[1] += v.y; t[2] += v.z; t[3] += v.w;
         }
         const int c0 = threadIdx.x * 4;
+        double *dst = sums + (size_t)(blockIdx.x % kRep) * 2 * C;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            atomicAdd(sums + c0 + i, s[i]);
-            atomicAdd(sums + C + c0 + i, t[i]);
+        for (int i = 0; i < 4; ++i) {  // hardware global_atomic_add_f64 (the plain atomicAdd(double) is a CAS loop)
+            unsafeAtomicAdd(dst + c0 + i, s[i]);
+            unsafeAtomicAdd(dst + C + c0 + i, t[i]);
         }
     }
 }
@@ -180,8 +187,13 @@ bn_relu_bwd_apply_kernel(long rows, int C, const float *__restrict__ dH, int ldd
     const float inv_r = (float)(1.0 / (double)rows);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        sg[i] = (float)sums[4 * q + i];
-        sgx[i] = (float)sums[C + 4 * q + i];
+        double a = 0.0, b = 0.0;
+        for (int r = 0; r < kRep; ++r) {
+            a += sums[(size_t)r * 2 * C + 4 * q + i];
+            b += sums[(size_t)r * 2 * C + C + 4 * q + i];
+        }
+        sg[i] = (float)a;
+        sgx[i] = (float)b;
         scale[i] = k.g[i] * k.invstd[i];
     }
     if (blockIdx.x == 0 && rr == 0) {
@@ -286,7 +298,7 @@ sa_layer1_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int 
 
 static int rows_per_block_for(long rows, int C) {
     const int rpp = kTT / (C >> 2);
-    long rpb = (rows + 2047) / 2048;  // ~2048 workgroups on a large problem
+    long rpb = (rows + 1023) / 1024;  // ~1024 workgroups on a large problem
     if (rpb < 4L * rpp) rpb = 4L * rpp;
     return (int)rpb;
 }
@@ -380,3 +392,5 @@ extern "C" int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a
                        a1f_ld, xyz, cxyz, wx, cadd, cadd_ld, idx, out, rel_out);
     return check_launch();
 }
+
+extern "C" int pn2x_bn_sums_doubles(int c) { return 2 * c * pn2::kRep; }

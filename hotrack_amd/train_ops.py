@@ -30,6 +30,8 @@ for _n in ("pn2x_bn_stats", "pn2x_bn_relu_apply", "pn2x_bn_relu_bwd", "pn2x_scat
            "pn2x_sa_layer1"):
     getattr(_lib, _n).restype = _ci
 
+_lib.pn2x_bn_sums_doubles.argtypes = [_ci]
+_lib.pn2x_bn_sums_doubles.restype = _ci
 _f32 = torch.float32
 
 
@@ -48,7 +50,7 @@ class Workspace:
     """Zeroed fp64 accumulators for the BatchNorm reductions of one training step: reset() = one fill launch, take(n)
     hands out consecutive slices.  The capacity grows on demand outside graph capture."""
 
-    def __init__(self, device, capacity: int = 1 << 16):
+    def __init__(self, device, capacity: int = 1 << 19):
         self.buf = torch.zeros(capacity, dtype=torch.float64, device=device)
         self.used = 0
 
@@ -104,7 +106,7 @@ def bn_relu(y: torch.Tensor, bn: torch.nn.Module, ws: Workspace, conv_bias: torc
     track = bn.track_running_stats and bn.running_mean is not None
     return _BnRelu.apply(y, bn.weight, bn.bias, conv_bias, bn.running_mean if track else None, bn.running_var if track else None,
                          bn.num_batches_tracked if track else None, bn.eps, bn.momentum if bn.momentum is not None else 0.1, relu,
-                         ws.take(2 * C), ws.take(2 * C))
+                         ws.take(_lib.pn2x_bn_sums_doubles(C)), ws.take(_lib.pn2x_bn_sums_doubles(C)))
 
 
 def scatter_add_rows(dout: torch.Tensor, idx: torch.Tensor, din: torch.Tensor) -> torch.Tensor:

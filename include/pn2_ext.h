@@ -182,8 +182,10 @@ int pn2x_pose_head(int b, int j, int c, const float *h, const float *w, const fl
  * (library GEMM on point-major rows); what sits between two GEMMs is one pair of streaming kernels per direction.
  * Rows are `c` floats wide (c % 4 == 0, c <= 1024) with a row stride `ld*` (multiple of 4), 16-byte aligned.
  *
- * pn2x_bn_stats: sums[0:c] += sum_r y[r,:], sums[c:2c] += sum_r y[r,:]^2  (fp64 accumulators, zeroed by the caller).
+ * pn2x_bn_stats: per-channel sum_r y[r,:] and sum_r y[r,:]^2 into `sums` -- pn2x_bn_sums_doubles(c) fp64 accumulators zeroed by
+ * the caller (several interleaved copies of the 2c sums: workgroups spread their atomics over the copies).
  */
+int pn2x_bn_sums_doubles(int c);
 int pn2x_bn_stats(long rows, int c, const float *y, int ldy, double *sums, void *stream);
 /*
  * pn2x_bn_relu_apply: batch statistics from `sums` (biased variance, eps inside the sqrt -- torch.nn.BatchNorm semantics),
@@ -199,7 +201,7 @@ int pn2x_bn_relu_apply(long rows, int c, const float *y, int ldy, const double *
 /*
  * pn2x_bn_relu_bwd: with g = dh * [h > 0] (h recomputed from y), xhat = (y - mean) * invstd:
  *   dbeta = sum_r g, dgamma = sum_r g * xhat, dy = gamma * invstd * (g - dbeta / R - xhat * dgamma / R).
- * sums: 2c fp64 accumulators zeroed by the caller (two launches: reduce, apply).  dbias (or NULL): gradient of the bias of
+ * sums: pn2x_bn_sums_doubles(c) fp64 accumulators zeroed by the caller (two launches: reduce, apply).  dbias (or NULL): gradient of the bias of
  * the convolution in front of the BatchNorm -- sum_r dy, identically zero -- written as zeros.
  */
 int pn2x_bn_relu_bwd(long rows, int c, const float *dh, int ldd, const float *y, int ldy, const float *mean,

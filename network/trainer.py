@@ -97,10 +97,22 @@ class Trainer(nn.Module):
         self.to(self.device)
         # ---- data parallelism: one process per GPU, gradient all-reduce over RCCL / xGMI --------------
         self.ddp = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self.optimizer is not None:
-            ids = [self.device.index] if isinstance(self.device, torch.device) and self.device.type == "cuda" else None
-            self.ddp = nn.parallel.DistributedDataParallel(_StepModule(self.model), device_ids=ids,
-                                                           find_unused_parameters=True, broadcast_buffers=False)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # "ddp": torch DistributedDataParallel (bucketed all-reduce overlapped with backward, eager launches).
+        # "flat": ONE all-reduce of a flat gradient buffer between backward and the optimiser -- what lets the step run as
+        # captured HIP graphs under data parallelism (graph: forward+backward | eager: RCCL all-reduce of 16.7 MB | graph:
+        # Adam); parameters that never receive a gradient keep grad=None on every rank, exactly as with "ddp".
+        self.dp_mode = cfg.get("dp", "flat" if getattr(self, "graph_step", False) else "ddp") if self.world > 1 else None
+        self._flat = self._flat_grads = self._opt_graph = None
+        if self.world > 1 and self.optimizer is not None:
+            if self.dp_mode == "ddp":
+                ids = [self.device.index] if isinstance(self.device, torch.device) and self.device.type == "cuda" else None
+                self.ddp = nn.parallel.DistributedDataParallel(_StepModule(self.model), device_ids=ids,
+                                                               find_unused_parameters=True, broadcast_buffers=False)
+            else:  # every rank starts from rank 0's parameters and buffers (what DDP's constructor does)
+                with torch.no_grad():
+                    for t in list(self.model.parameters()) + [b for b in self.model.buffers() if b.is_floating_point()]:
+                        dist.broadcast(t, src=0)
 
     def _make_scheduler(self, last_epoch=-1):
         cfg = self.cfg
@@ -183,6 +195,21 @@ class Trainer(nn.Module):
         return {"track_flag": False, "save_flag": False, "test_flag": False, "IKNet_flag": False}
 
     def _step(self, data, zero=True):
+        if torch.cuda.is_available():
+            from hotrack_amd import gemm_tuning
+            with gemm_tuning.scope():  # recorded gfx950 GEMM solutions (incl. the split-R weight-gradient GEMMs) for this step
+                return self._step_impl(data, zero)
+        return self._step_impl(data, zero)
+
+    def _step_impl(self, data, zero=True):
+        loss_dict = self._forward_backward(data, zero)
+        if self.dp_mode == "flat":
+            self._allreduce_flat()
+            self._scatter_flat()
+        self.optimizer.step()
+        return loss_dict
+
+    def _forward_backward(self, data, zero=True):
         if zero:
             self.optimizer.zero_grad()
         flags = self.init_flag_dict()
@@ -192,14 +219,34 @@ class Trainer(nn.Module):
             ret = self.model(data, flags)
             loss_dict, _ = self.model.compute_loss(data, ret, flags)
         loss_dict = self.summarize_losses(loss_dict)
-        loss_dict["total_loss"].backward()  # DDP: bucketed all-reduce overlapped with backward
-        self.optimizer.step()
+        loss_dict["total_loss"].backward()  # "ddp": bucketed all-reduce overlapped with backward
         return loss_dict
+
+    # ---- "flat" data parallelism: one all-reduce of all gradients -----------------------------------------------------
+    def _allreduce_flat(self):
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        n = sum(g.numel() for g in grads)
+        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
+            self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        self._flat_grads = grads
+        torch.cat([g.reshape(-1) for g in grads], out=self._flat)
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(self._flat, op=dist.ReduceOp.AVG)  # RCCL over xGMI: one 16.7 MB ring / tree all-reduce
+        else:
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+            self._flat.div_(self.world)
+
+    def _scatter_flat(self):
+        views, off = [], 0
+        for g in self._flat_grads:
+            views.append(self._flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        torch._foreach_copy_(self._flat_grads, views)
 
     def update(self, data):
         self.model.train()
         loss_dict = None
-        if getattr(self, "graph_step", False) and self.ddp is None and torch.cuda.is_available():
+        if getattr(self, "graph_step", False) and self.ddp is None and torch.cuda.is_available():  # ("ddp" mode stays eager)
             try:
                 loss_dict = dict(self._graphed_step(data))
             except RuntimeError as exc:  # an op of this configuration cannot be captured: stay eager from now on
@@ -229,6 +276,9 @@ class Trainer(nn.Module):
         for (_, dst), (_, src) in zip(self._leaves(self._static), self._leaves(data)):
             dst.copy_(src, non_blocking=True)
         self._graph.replay()
+        if self._opt_graph is not None:  # data parallel: forward+backward graph | eager all-reduce | optimiser graph
+            self._allreduce_flat()
+            self._opt_graph.replay()
         return self._static_loss
 
     def _capture(self, data, sig):
@@ -259,8 +309,21 @@ class Trainer(nn.Module):
                         v.copy_(opt_snap[p][k]) if p in opt_snap else v.zero_()
         self.optimizer.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._static_loss = self._step(self._static, zero=False)
+        self._opt_graph = None
+        if self.dp_mode == "flat":
+            from hotrack_amd import gemm_tuning
+            with gemm_tuning.scope():
+                with torch.cuda.graph(graph):
+                    self._static_loss = self._forward_backward(self._static, zero=False)
+                self._allreduce_flat()  # eager (collectives stay outside the graphs); also fixes the flat buffer / gradient list
+                opt_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(opt_graph, pool=graph.pool()):
+                    self._scatter_flat()
+                    self.optimizer.step()
+            self._opt_graph = opt_graph
+        else:
+            with torch.cuda.graph(graph):
+                self._static_loss = self._step(self._static, zero=False)
         self._graph, self._graph_sig = graph, sig
 
     def test(self, data, save_flag=False):

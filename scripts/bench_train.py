@@ -21,10 +21,10 @@ def main():
     ap.add_argument("--graph", action="store_true", help="whole-step HIP graph (single GPU)")
     a = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("PN2_DIST_BACKEND", "nccl"))  # gloo: several ranks on one GPU (self-test)
     os.environ.setdefault("HOTRACK_DATA_ROOT", "/tmp/hotrack_bench_data")
     from configs.config import get_config
     from datasets.synthetic import make_frame
@@ -33,7 +33,7 @@ def main():
     args = add_args(argparse.ArgumentParser()).parse_args(["--config", "handtracknet_train_SimGrasp.yml"])
     args.num_points, args.batch_size = 1024, a.batch
     cfg = get_config(args, save=False)
-    cfg["graph_step"] = a.graph and world == 1
+    cfg["graph_step"] = a.graph  # data parallel: forward+backward graph | eager flat all-reduce | Adam graph
     torch.manual_seed(0)
     tr = Trainer(cfg)
     tr.step_epoch()
@@ -54,13 +54,13 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     if rank == 0:
         print(json.dumps({"metric": "HandTrackNet training frames/sec (N=1024)", "value": round(a.batch * world * a.steps / dt, 1),
                           "unit": "frames/s", "n_gpus": world, "ms_per_step": round(dt / a.steps * 1e3, 2), "per_gpu_batch": a.batch,
-                          "scaling": "weak", "graph_step": bool(getattr(tr, "graph_step", False)), "loss": float(loss["total_loss"]), "dtype": "f32", "data": "synthetic"}))
+                          "scaling": "weak", "graph_step": bool(getattr(tr, "graph_step", False)), "dp_mode": tr.dp_mode, "loss": float(loss["total_loss"]), "dtype": "f32", "data": "synthetic"}))
     if world > 1:
         dist.destroy_process_group()
 

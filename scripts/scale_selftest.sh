@@ -32,4 +32,13 @@ for N in 2; do
   grep -q "world_size $N, 3 iterations" /tmp/selftest_train_$N.log || { echo "train.py did not run $N ranks"; tail -20 /tmp/selftest_train_$N.log; exit 1; }
   echo "train.py x$N ranks: ok"
 done
+# the graph-captured data-parallel training step (forward+backward graph | flat all-reduce | Adam graph), 2 ranks on one GPU
+PN2_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29801 \
+    scripts/bench_train.py --steps 10 --warmup 5 --batch 8 --graph 2>&1 | grep '^{' | tee /tmp/selftest_bench_train.json
+python - <<'PY'
+import json
+d = json.loads(open("/tmp/selftest_bench_train.json").read())
+assert d["n_gpus"] == 2 and d["graph_step"] is True and d["dp_mode"] == "flat", d
+print("bench_train --graph x2 ranks: ok (%.2f ms/step on a shared GPU)" % d["ms_per_step"])
+PY
 echo "scale_selftest: all ok"

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, tmp, q):
+def _worker(rank, world, port, tmp, q, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HOTRACK_DATA_ROOT=tmp)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "network"), os.path.join(ROOT, "tests")]
@@ -38,9 +38,10 @@ def _worker(rank, world, port, tmp, q):
     a = add_args(argparse.ArgumentParser()).parse_args(["--config", "handtracknet_train_SimGrasp.yml"])
     a.num_points, a.batch_size = 256, 2
     cfg = get_config(a, save=False)
-    torch.manual_seed(0)  # same initial weights on both ranks (DDP also broadcasts rank 0's)
+    cfg["dp"] = mode
+    torch.manual_seed(rank if mode == "flat" else 0)  # "flat" must broadcast rank 0's weights itself (DDP's constructor does)
     tr = Trainer(cfg)
-    assert tr.ddp is not None
+    assert (tr.ddp is not None) == (mode == "ddp") and tr.dp_mode == mode
     for m in tr.model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
@@ -69,11 +70,14 @@ def _worker(rank, world, port, tmp, q):
 
 
 @pytest.mark.timeout(600)
-def test_ddp_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("mode", ["ddp", "flat"])
+def test_ddp_two_ranks_gloo(tmp_path, mode):
+    """mode "ddp": torch DistributedDataParallel; "flat": Trainer's one-all-reduce-per-step mode (the one that runs as HIP
+    graphs on the GPUs)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=500) for _ in procs]
