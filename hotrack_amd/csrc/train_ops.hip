@@ -83,7 +83,21 @@ bn_stats_kernel(long rows, int C, const float *__restrict__ Y, int ld, int rows_
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float4 s = make_float4(0, 0, 0, 0), t = s;
     if (rr < rpp) {
-        for (long r = r0 + rr; r < r1; r += rpp) {
+        long r = r0 + rr;
+        for (; r + 3L * rpp < r1; r += 4L * rpp) {  // four independent 16-byte loads in flight per thread
+            const float *p = Y + r * ld + 4 * q;
+            const float4 v0 = *reinterpret_cast<const float4 *>(p);
+            const float4 v1 = *reinterpret_cast<const float4 *>(p + (long)rpp * ld);
+            const float4 v2 = *reinterpret_cast<const float4 *>(p + 2L * rpp * ld);
+            const float4 v3 = *reinterpret_cast<const float4 *>(p + 3L * rpp * ld);
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+            t.x += (v0.x * v0.x + v1.x * v1.x) + (v2.x * v2.x + v3.x * v3.x);
+            t.y += (v0.y * v0.y + v1.y * v1.y) + (v2.y * v2.y + v3.y * v3.y);
+            t.z += (v0.z * v0.z + v1.z * v1.z) + (v2.z * v2.z + v3.z * v3.z);
+            t.w += (v0.w * v0.w + v1.w * v1.w) + (v2.w * v2.w + v3.w * v3.w);
+        }
+        for (; r < r1; r += rpp) {
             const float4 v = *reinterpret_cast<const float4 *>(Y + r * ld + 4 * q);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             t.x += v.x * v.x; t.y += v.y * v.y; t.z += v.z * v.z; t.w += v.w * v.w;
@@ -296,10 +310,62 @@ sa_layer1_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int 
     *reinterpret_cast<float4 *>(out + ((size_t)b * sk + r) * (4 * Q) + 4 * q) = acc;
 }
 
+// LDS-slab variant of the two row scatters: a workgroup owns (cloud, cc channels), accumulates every contribution to its
+// [n_dst][cc] slab with ds_add_f32 and adds the slab to the destination once with coalesced 16-byte read-modify-writes --
+// no global atomics (same idea as group_bwd_lds_kernel / interp_bwd_lds_kernel on the channel-major operators).
+template <bool INTERP>
+__global__ void __launch_bounds__(kTT)
+scatter_rows_lds_kernel(int n_dst, int m_src, int C, int cc, const float *__restrict__ dOut, int ldo, const int *__restrict__ idx,
+                        const float *__restrict__ weight, float *__restrict__ dIn, int ldi) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];  // [n_dst][cc]
+    const int b = blockIdx.y, c0 = blockIdx.x * cc;
+    const int nc = (C - c0) < cc ? (C - c0) : cc;
+    const int Qc = nc >> 2;
+    for (int i = threadIdx.x; i < n_dst * cc; i += kTT) slab[i] = 0.f;
+    __syncthreads();
+    const int total = m_src * Qc;
+    for (int e = threadIdx.x; e < total; e += kTT) {
+        const int j = e / Qc, q = e - j * Qc;
+        const float4 v = *reinterpret_cast<const float4 *>(dOut + ((size_t)b * m_src + j) * ldo + c0 + 4 * q);
+        if constexpr (INTERP) {
+            const int *id = idx + ((size_t)b * m_src + j) * 3;
+            const float *w = weight + ((size_t)b * m_src + j) * 3;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float *dst = slab + id[t] * cc + 4 * q;
+                const float wt = w[t];
+                atomicAdd(dst + 0, wt * v.x); atomicAdd(dst + 1, wt * v.y); atomicAdd(dst + 2, wt * v.z); atomicAdd(dst + 3, wt * v.w);
+            }
+        } else {
+            float *dst = slab + idx[(size_t)b * m_src + j] * cc + 4 * q;
+            atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_dst * Qc; e += kTT) {
+        const int row = e / Qc, q = e - row * Qc;
+        float4 *dst = reinterpret_cast<float4 *>(dIn + ((size_t)b * n_dst + row) * ldi + c0 + 4 * q);
+        const float4 a = *reinterpret_cast<const float4 *>(slab + row * cc + 4 * q);
+        float4 d = *dst;
+        d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+        *dst = d;
+    }
+}
+
+// channels per workgroup for the slab kernels: the slab must fit 64 KiB; prefer >= 512 workgroups; 0 = use the atomic kernel
+static int slab_channels(int b, int n_dst, int C) {
+    int cc = (16384 / n_dst) & ~3;
+    if (cc < 4) return 0;
+    if (cc > 64) cc = 64;
+    if (cc > C) cc = C;
+    while (cc > 4 && (long)b * ((C + cc - 1) / cc) < 512) cc = ((cc / 2) + 3) & ~3;
+    return cc;
+}
+
 static int rows_per_block_for(long rows, int C) {
     const int rpp = kTT / (C >> 2);
     long rpb = (rows + 1023) / 1024;  // ~1024 workgroups on a large problem
-    if (rpb < 4L * rpp) rpb = 4L * rpp;
+    if (rpb < 16L * rpp) rpb = 16L * rpp;
     return (int)rpb;
 }
 
@@ -355,6 +421,11 @@ extern "C" int pn2x_scatter_add_rows(int b, int n, int m, int c, const float *do
     if (b == 0 || m == 0 || c == 0) return PN2_OK;
     if (!dout || !idx || !din) return PN2_ENULL;
     if (((uintptr_t)dout | (uintptr_t)din) % 16) return PN2_EINVAL;
+    if (const int cc = slab_channels(b, n, c)) {
+        hipLaunchKernelGGL(scatter_rows_lds_kernel<false>, dim3((c + cc - 1) / cc, b), dim3(kTT), (size_t)n * cc * sizeof(float), (hipStream_t)stream,
+                           n, m, c, cc, dout, ldo, idx, nullptr, din, ldi);
+        return check_launch();
+    }
     const int Q = c / 4;
     const long total = (long)m * Q;
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + kTT - 1) / kTT), b), dim3(kTT), 0, (hipStream_t)stream, n, m, Q,
@@ -369,6 +440,11 @@ extern "C" int pn2x_three_interpolate_pm_grad(int b, int c, int m, int n, const 
     if (b == 0 || n == 0 || c == 0) return PN2_OK;
     if (!dout || !idx || !weight || !dpoints) return PN2_ENULL;
     if (((uintptr_t)dout | (uintptr_t)dpoints) % 16) return PN2_EINVAL;
+    if (const int cc = slab_channels(b, m, c)) {
+        hipLaunchKernelGGL(scatter_rows_lds_kernel<true>, dim3((c + cc - 1) / cc, b), dim3(kTT), (size_t)m * cc * sizeof(float), (hipStream_t)stream,
+                           m, n, c, cc, dout, ldo, idx, weight, dpoints, ldp);
+        return check_launch();
+    }
     const int Q = c / 4;
     const long total = (long)n * Q;
     hipLaunchKernelGGL(interp_pm_bwd_kernel, dim3((unsigned)((total + kTT - 1) / kTT), b), dim3(kTT), 0, (hipStream_t)stream, m, n, Q, dout,

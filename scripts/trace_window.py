@@ -14,8 +14,13 @@ def short(name):
     if name.startswith("Cijk_"):
         m = re.search(r"(Cijk_\w+?_SB)_(MT\d+x\d+x\d+)", name)
         return f"{m.group(1)}_{m.group(2)}..." if m else name[:60]
+    m = re.search(r"at::native::(?:\(anonymous namespace\)::)?(\w+)", name)
+    tag = ""
+    if name.startswith("at::native::") and m:
+        inner = re.findall(r"at::native::(?:\(anonymous namespace\)::)?(\w+)", name)
+        tag = " [" + ",".join(dict.fromkeys(inner[:4])) + "]"
     name = re.sub(r"\(.*", "", name)
-    return name[:110]
+    return (name[:80] + tag)[:130]
 
 
 def main():
