@@ -76,6 +76,9 @@ class KernelTimer:
         for name, a, s, e in self.records:
             if name in ("fps_kernel", "fps_prefix_kernel"):
                 key = (name, a[0], a[1], a[2])  # (b, n, m)
+            elif name == "sa_mlp_max_pair_kernel":  # both scales of a query module in one launch: (b, s, (k0, k1), c1, c2, c3)
+                q0, q1 = a[4]._obj, a[5]._obj
+                key = (name, a[0], q0.s, (q0.k, q1.k), a[1], a[2], a[3])
             else:
                 key = ("sa_mlp_max_kernel", a[0], a[2], a[3], a[4], a[5], a[6])  # (b, s, k, c1, c2, c3)
             by.setdefault(key, []).append(s.elapsed_time(e) * 1e-3)
@@ -85,10 +88,11 @@ class KernelTimer:
 
 def roofline_of(key, sec, per_step):
     """Roofline entry of one kernel: algorithmic work per launch / measured launch duration."""
-    if key[0] == "sa_mlp_max_kernel":
-        _, B, S, K, C1, C2, C3 = key
-        flops = 2.0 * B * S * K * (C1 * C2 + C2 * C3)  # the two MFMA layers the kernel executes per (s,k) position
-        return {"bound": "mfma", "kernel": "sa_mlp_max_kernel<%d,%d,%d> (B=%d,S=%d,K=%d)" % (C1, C2, C3, B, S, K),
+    if key[0].startswith("sa_mlp_max"):
+        kname, B, S, K, C1, C2, C3 = key
+        ksum = sum(K) if isinstance(K, tuple) else K
+        flops = 2.0 * B * S * ksum * (C1 * C2 + C2 * C3)  # the two MFMA layers the kernel executes per (s,k) position
+        return {"bound": "mfma", "kernel": "%s<%d,%d,%d> (B=%d,S=%d,K=%s)" % (kname, C1, C2, C3, B, S, "+".join(map(str, K)) if isinstance(K, tuple) else K),
                 "achieved": round(flops / sec / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step}
@@ -337,7 +341,7 @@ def main():
         # group launches of the same kernel instantiation (q1/q2 share the 128-128-192 instance at two K)
         inst = {}
         for r in per_kernel:
-            name = r["key"][0] + (str(r["key"][4:]) if r["key"][0] == "sa_mlp_max_kernel" else "")
+            name = "sa_mlp_max" + str(r["key"][4:]) if r["key"][0].startswith("sa_mlp_max") else r["key"][0]
             inst.setdefault(name, []).append(r)
         dom = max(inst.values(), key=lambda rs: sum(r["sec"] * r["per_step"] for r in rs)) if inst else []
         roof = None
@@ -353,8 +357,8 @@ def main():
             src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
             pmc = json.load(open(src))
             if roof is not None and roof["bound"] == "mfma":
-                tag = "sa_mlp_max_kernel<%d, %d, %d" % top["key"][4:7]
-                cands = [e for e in pmc["kernels"] if tag in e["kernel"]]
+                tag = "<%d, %d, %d" % top["key"][4:7]
+                cands = [e for e in pmc["kernels"] if top["key"][0] in e["kernel"] and tag in e["kernel"]]
                 if cands:  # the K=64 launch is the larger-grid one of the instance
                     roof["traffic"] = max(cands, key=lambda e: e["grid_threads"])["hbm_bytes"]
                     roof["traffic_source"] = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, reads x2 per "

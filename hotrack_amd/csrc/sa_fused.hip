@@ -64,9 +64,10 @@ struct SaArgs {
 // K (neighbours per centroid) is a template parameter: the max-combine / store part is then straight-line code.
 // MODE fixes which layer-1 operands exist so the LOAD role is branch-free: 0 = xyz only (sa1), 1 = a1f + xyz,
 // 2 = a1f + xyz + cadd, 3 = any combination, tested at run time.
+// The tile loop of one problem, run by workgroup `wg` of the `nwg` workgroups assigned to it (a whole launch, or one share
+// of a launch that serves two scales of a module at once -- sa_mlp_max_pair_kernel below).
 template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
-__global__ void __launch_bounds__(512, MINW)
-sa_mlp_max_kernel(const SaArgs A) {
+__device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int nwg) {
     static_assert(K == 16 || K == 32 || K == 64, "K");
     const bool has_a1f = MODE == 3 ? A.a1f != nullptr : MODE >= 1;
     const bool has_xyz = MODE == 3 ? A.xyz != nullptr : true;
@@ -218,7 +219,7 @@ sa_mlp_max_kernel(const SaArgs A) {
         }
     } else {
         for (int a = 0; a < NB1 - 1; ++a) {  // prologue: the first NB1-1 tiles of this workgroup
-            const int tile = blockIdx.x + a * gridDim.x;
+            const int tile = wg + a * nwg;
             if (tile < num_tiles) {
                 gather(tile, H1ring + a * TM * LD1, 0);
                 gather(tile, H1ring + a * TM * LD1, 1);
@@ -232,7 +233,7 @@ sa_mlp_max_kernel(const SaArgs A) {
     // stamp splits the tile body into separate scheduling regions and keeps epilogues from overlapping MFMAs.
     auto stamp = [&](int it, int slot) {
 #if defined(SA_TRACE) && SA_TRACE
-        if (A.trace && blockIdx.x == 0 && lane == 0 && (w == 0 || w == 4) && it < 8)
+        if (A.trace && wg == 0 && lane == 0 && (w == 0 || w == 4) && it < 8)
             A.trace[((w >> 2) * 8 + it) * 8 + slot] = (long long)__builtin_readcyclecounter();
 #else
         (void)it; (void)slot;
@@ -252,15 +253,15 @@ sa_mlp_max_kernel(const SaArgs A) {
         // pipeline fill: rows of the first half and indices of the second half of the first tile this loop gathers
         HalfIdx I0, I1;
         HalfRows D0, D1;
-        const int first = blockIdx.x + (NB1 - 1) * gridDim.x;
+        const int first = wg + (NB1 - 1) * nwg;
         load_idx(first, 0, I0);
         load_idx(first, 1, I1);
         load_rows(first, I0, D0);
         int it = 0;
-        for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, ++it) {
+        for (int tile = wg; tile < num_tiles; tile += nwg, ++it) {
             stamp(it, 0);
             float *H1n = H1ring + ((it + NB1 - 1) % NB1) * TM * LD1;  // last read by COMPUTE in iteration it-1
-            const int next = tile + (NB1 - 1) * gridDim.x, after = next + gridDim.x;
+            const int next = tile + (NB1 - 1) * nwg, after = next + nwg;
             load_rows(next, I1, D1);    // half 1 of `next`: in flight while half 0 is finished
             load_idx(after, 0, I0);     // indices two halves ahead
             if (next < num_tiles) finish(D0, H1n, 0);
@@ -280,7 +281,7 @@ sa_mlp_max_kernel(const SaArgs A) {
     __builtin_amdgcn_s_setprio(SA_COMPUTE_PRIO);
 #endif
     int it = 0;
-    for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x, ++it) {
+    for (int tile = wg; tile < num_tiles; tile += nwg, ++it) {
         stamp(it, 0);
         float *H1 = H1ring + (it % NB1) * TM * LD1;
         const int b = tile / tiles_per_cloud;
@@ -391,6 +392,26 @@ sa_mlp_max_kernel(const SaArgs A) {
 }
 
 template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
+__global__ void __launch_bounds__(512, MINW)
+sa_mlp_max_kernel(const SaArgs A) {
+    sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K, MODE>(A, blockIdx.x, gridDim.x);
+}
+
+// Both scales of a keypoint-query module (K0 and K1 neighbours, same layer widths) in ONE persistent grid: workgroups
+// [0, n0) own the tiles of problem 0, the rest those of problem 1, each loading only its own scale's weights.  Served
+// separately the K=16 scale has 384 tiles for 256 CUs (every workgroup pulls 160 KB of weights into registers to use them
+// twice, 0.35 of the MFMA peak) and the K=64 scale runs 1344 tiles on 224 workgroups; together the 1728 tiles fill all
+// CUs with ~7 tiles per workgroup, and a launch per module disappears.
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K0, int K1, int MODE>
+__global__ void __launch_bounds__(512, MINW)
+sa_mlp_max_pair_kernel(const SaArgs A0, const SaArgs A1, const int n0) {
+    if ((int)blockIdx.x < n0)
+        sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K0, MODE>(A0, blockIdx.x, n0);
+    else
+        sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K1, MODE>(A1, blockIdx.x - n0, gridDim.x - n0);
+}
+
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
 static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
     constexpr int WP = 4 / WC, TM = WP * 64;
     const int sk = a.S * a.K;
@@ -414,6 +435,41 @@ static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
     const int rounds = (a.num_tiles + max_wg - 1) / max_wg;
     const int grid = (a.num_tiles + rounds - 1) / rounds;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a);
+    return check_launch();
+}
+
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1>
+static void sa_tiles(int b, SaArgs &a) {
+    constexpr int WP = 4 / WC, TM = WP * 64;
+    a.tiles_per_cloud = (a.S * a.K + TM - 1) / TM;
+    a.num_tiles = b * a.tiles_per_cloud;
+    a.lgK = 0;
+    while ((1 << a.lgK) < a.K) ++a.lgK;
+}
+
+template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K0, int K1, int MODE>
+static int launch_sa_pair(int b, SaArgs a0, SaArgs a1, hipStream_t st) {
+    constexpr int WP = 4 / WC, TM = WP * 64;
+    if ((long)b * ((a0.S * a0.K + TM - 1) / TM) + (long)b * ((a1.S * a1.K + TM - 1) / TM) > 2147483647L) return PN2_ERANGE;
+    sa_tiles<C1, C2, C3, WC, RTC, MINW, NB1>(b, a0);
+    sa_tiles<C1, C2, C3, WC, RTC, MINW, NB1>(b, a1);
+    const size_t lds = (size_t)TM * (NB1 * (C1 + SA_PAD) + C2 + SA_PAD) * sizeof(float);
+    auto kfn = sa_mlp_max_pair_kernel<C1, C2, C3, WC, RTC, MINW, NB1, K0, K1, MODE>;
+    static PerDeviceOnce raised;
+    if (lds > 64 * 1024 && raised.first_use())
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int wg_per_cu = (int)((160 * 1024) / lds) < MINW / 2 ? (int)((160 * 1024) / lds) : MINW / 2;
+    const int max_wg = num_compute_units() * (wg_per_cu < 1 ? 1 : wg_per_cu);
+    // same number of rounds for both shares (a tile costs the same in either: 64 positions through the same layers)
+    const int total = a0.num_tiles + a1.num_tiles;
+    int rounds = (total + max_wg - 1) / max_wg;
+    int n0, n1;
+    for (;; ++rounds) {
+        n0 = (a0.num_tiles + rounds - 1) / rounds;
+        n1 = (a1.num_tiles + rounds - 1) / rounds;
+        if (n0 + n1 <= max_wg || rounds > total) break;
+    }
+    hipLaunchKernelGGL(kfn, dim3(n0 + n1), dim3(512), lds, st, a0, a1, n0);
     return check_launch();
 }
 
@@ -468,6 +524,44 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
     if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4, 2, 4, SA_NB1>(b, a, st);
     if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4, 2, 2, SA_NB1>(b, a, st);
     return PN2_ERANGE;
+}
+
+namespace pn2 {
+static int fill_sa_args(const pn2x_sa_problem &p, int c1, SaArgs &a) {
+    if (p.n < 1 || p.s < 1 || p.k < 1) return PN2_EINVAL;
+    if (!p.idx || !p.w2 || !p.b2 || !p.w3 || !p.b3 || !p.out) return PN2_ENULL;
+    if (!p.a1f && !p.xyz) return PN2_ENULL;
+    if (p.xyz && (!p.cxyz || !p.wx)) return PN2_ENULL;
+    if ((p.a1f && (p.a1f_ld < c1 || p.a1f_ld % 4)) || (p.cadd && (p.cadd_ld < c1 || p.cadd_ld % 4))) return PN2_EINVAL;
+    if (((uintptr_t)p.a1f | (uintptr_t)p.cadd | (uintptr_t)p.b1 | (uintptr_t)p.w2 | (uintptr_t)p.w3) % 16 != 0) return PN2_EINVAL;
+    a.N = p.n; a.S = p.s; a.K = p.k; a.lgK = 0;
+    a.a1f = p.a1f; a.a1f_ld = p.a1f_ld; a.cadd_ld = p.cadd_ld; a.xyz = p.xyz; a.cxyz = p.cxyz; a.wx = p.wx; a.b1 = p.b1;
+    a.cadd = p.cadd; a.idx = p.idx; a.w2 = p.w2; a.b2 = p.b2; a.w3 = p.w3; a.b3 = p.b3; a.out = p.out; a.out_b = p.out_b;
+    a.out_s = p.out_s; a.out_c = p.out_c; a.num_tiles = 0; a.tiles_per_cloud = 0; a.trace = nullptr;
+    return PN2_OK;
+}
+}  // namespace pn2
+
+extern "C" int pn2x_sa_mlp_max_pair_supported(int k0, int k1, int c1, int c2, int c3) {
+    return (c1 == 128 && c2 == 128 && c3 == 192 && ((k0 == 16 && k1 == 64) || (k0 == 64 && k1 == 16))) ? 1 : 0;
+}
+
+extern "C" int pn2x_sa_mlp_max_pair(int b, int c1, int c2, int c3, const pn2x_sa_problem *p0, const pn2x_sa_problem *p1, void *stream) {
+    using namespace pn2;
+    if (b < 0 || !p0 || !p1) return b < 0 ? PN2_EINVAL : PN2_ENULL;
+    if (b == 0) return PN2_OK;
+    if (!pn2x_sa_mlp_max_pair_supported(p0->k, p1->k, c1, c2, c3)) return PN2_ERANGE;
+    if (p0->k > p1->k) { const pn2x_sa_problem *t = p0; p0 = p1; p1 = t; }
+    SaArgs a0, a1;
+    int rc = fill_sa_args(*p0, c1, a0);
+    if (rc != PN2_OK) return rc;
+    rc = fill_sa_args(*p1, c1, a1);
+    if (rc != PN2_OK) return rc;
+    const bool fa = a0.a1f && a1.a1f, fx = a0.xyz && a1.xyz, fc0 = a0.cadd != nullptr, fc1 = a1.cadd != nullptr;
+    if (!fa || !fx || fc0 != fc1 || (a0.a1f == nullptr) != (a1.a1f == nullptr)) return PN2_ERANGE;  // both scales: a1f + xyz (+ cadd)
+    hipStream_t st = (hipStream_t)stream;
+    if (fc0) return launch_sa_pair<128, 128, 192, 4, 2, 2, SA_NB1, 16, 64, 2>(b, a0, a1, st);
+    return launch_sa_pair<128, 128, 192, 4, 2, 2, SA_NB1, 16, 64, 1>(b, a0, a1, st);
 }
 
 extern "C" int pn2x_sa_mlp_max_supported(int k, int c1, int c2, int c3) {

@@ -94,6 +94,57 @@ def sa_mlp_max(idx: torch.Tensor, w2, b2, w3, b3, *, a1f=None, xyz=None, cxyz=No
     return out
 
 
+class _SaProblem(ctypes.Structure):
+    """include/pn2_ext.h: pn2x_sa_problem."""
+    _fields_ = [("n", _ci), ("s", _ci), ("k", _ci), ("a1f", _vp), ("a1f_ld", _ci), ("xyz", _vp), ("cxyz", _vp), ("wx", _vp),
+                ("b1", _vp), ("cadd", _vp), ("cadd_ld", _ci), ("idx", _vp), ("w2", _vp), ("b2", _vp), ("w3", _vp), ("b3", _vp),
+                ("out", _vp), ("out_b", _cl), ("out_s", _ci), ("out_c", _ci)]
+
+
+_lib.pn2x_sa_mlp_max_pair.argtypes = [_ci] * 4 + [ctypes.POINTER(_SaProblem)] * 2 + [_vp]
+_lib.pn2x_sa_mlp_max_pair.restype = _ci
+_lib.pn2x_sa_mlp_max_pair_supported.argtypes = [_ci] * 5
+_lib.pn2x_sa_mlp_max_pair_supported.restype = _ci
+
+
+def _sa_problem(idx, w2, b2, w3, b3, a1f, xyz, cxyz, wx, b1, cadd, out) -> _SaProblem:
+    B, S, K = idx.shape
+    C1, C2, C3 = w2.shape[1], w2.shape[0], w3.shape[0]
+    f32 = torch.float32
+    N = a1f.shape[1] if a1f is not None else xyz.shape[1]
+    pa, lda = (None, 0) if a1f is None else _rows(a1f, "a1f", C1)
+    pc, ldc = (None, 0) if cadd is None else _rows(cadd, "cadd", C1)
+    po, ld = _rows(out, "out", C3)
+    return _SaProblem(
+        N, S, K, pa, lda, None if xyz is None else _native._ptr(xyz, "xyz", f32, B * N * 3),
+        None if cxyz is None else _native._ptr(cxyz, "cxyz", f32, B * S * 3), None if wx is None else _native._ptr(wx, "wx", f32, C1 * 3),
+        None if b1 is None else _native._ptr(b1, "b1", f32, C1), pc, ldc, _native._ptr(idx, "idx", torch.int32, B * S * K),
+        _native._ptr(w2, "w2", f32, C2 * C1), _native._ptr(b2, "b2", f32, C2), _native._ptr(w3, "w3", f32, C3 * C2),
+        _native._ptr(b3, "b3", f32, C3), po, out.stride(0), ld, 1)
+
+
+def sa_mlp_max_pair(p0: dict, p1: dict) -> None:
+    """Both scales of a keypoint-query module in ONE launch (pn2x_sa_mlp_max_pair).  p0 / p1: the keyword arguments of
+    sa_mlp_max (idx, w2, b2, w3, b3, a1f, xyz, cxyz, wx, b1, cadd, out -- `out` required, a (B,S,C3) row block).  Falls back
+    to two launches when the combination is not covered by the pair kernel."""
+    keys = ("idx", "w2", "b2", "w3", "b3", "a1f", "xyz", "cxyz", "wx", "b1", "cadd", "out")
+    a = [{k: p.get(k) for k in keys} for p in (p0, p1)]
+    C1, C2, C3 = a[0]["w2"].shape[1], a[0]["w2"].shape[0], a[0]["w3"].shape[0]
+    same = all(tuple(a[1][k].shape) == tuple(a[0][k].shape) for k in ("w2", "w3"))
+    modes = [(p["a1f"] is not None, p["xyz"] is not None, p["cadd"] is not None) for p in a]
+    if not (same and modes[0] == modes[1] and modes[0][0] and modes[0][1]
+            and _lib.pn2x_sa_mlp_max_pair_supported(a[0]["idx"].shape[2], a[1]["idx"].shape[2], C1, C2, C3)):
+        for p in a:
+            sa_mlp_max(p["idx"], p["w2"], p["b2"], p["w3"], p["b3"], a1f=p["a1f"], xyz=p["xyz"], cxyz=p["cxyz"], wx=p["wx"], b1=p["b1"],
+                       cadd=p["cadd"], out=p["out"])
+        return
+    B = a[0]["idx"].shape[0]
+    q0, q1 = (_sa_problem(**p) for p in a)
+    with torch.cuda.device(a[0]["idx"].device):
+        _native._check(_native._call(_lib.pn2x_sa_mlp_max_pair, "sa_mlp_max_pair_kernel", None, B, C1, C2, C3, ctypes.byref(q0),
+                                     ctypes.byref(q1), _native._stream(a[0]["idx"])), "sa_mlp_max_pair")
+
+
 def three_nn_weights(unknown: torch.Tensor, known: torch.Tensor):
     """unknown (B,n,3), known (B,m>=3,3) -> (weight (B,n,3) normalised inverse distances, idx (B,n,3) int32)."""
     B, n, _ = unknown.shape

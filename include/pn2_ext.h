@@ -176,6 +176,28 @@ int pn2x_pose_head(int b, int j, int c, const float *h, const float *w, const fl
                    const float *R, const float *t, float scale, float *kp_hand, float *kp_cam, void *stream);
 
 /*
+ * Both scales of a keypoint-query module (reference PointNetSetAbstractionMsg_GivenCenterPoints, pointnet_utils.py:536-590:
+ * two kNN neighbourhood sizes, same layer widths) in ONE persistent launch: every compute unit stays busy and each
+ * workgroup loads only its own scale's weights (see sa_fused.hip).  A problem = the per-scale arguments of
+ * pn2x_sa_mlp_max.  Supported (pn2x_sa_mlp_max_pair_supported): widths 128-128-192, k = {16, 64}, both problems with the
+ * same set of layer-1 operands (a1f + xyz, optionally + cadd); anything else returns PN2_ERANGE (launch them separately).
+ */
+typedef struct pn2x_sa_problem {
+    int n, s, k;
+    const float *a1f;
+    int a1f_ld;
+    const float *xyz, *cxyz, *wx, *b1, *cadd;
+    int cadd_ld;
+    const int *idx;
+    const float *w2, *b2, *w3, *b3;
+    float *out;
+    long out_b;
+    int out_s, out_c;
+} pn2x_sa_problem;
+int pn2x_sa_mlp_max_pair_supported(int k0, int k1, int c1, int c2, int c3);
+int pn2x_sa_mlp_max_pair(int b, int c1, int c2, int c3, const pn2x_sa_problem *p0, const pn2x_sa_problem *p1, void *stream);
+
+/*
  * ---- training-mode building blocks on point-major activations (hotrack_amd/csrc/train_ops.hip) --------------------------
  * The reference trains every grouped MLP as Conv2d(1x1) + BatchNorm2d + ReLU on channel-major (B, C, S, K) tensors
  * (pointnet_utils.py:399-403, :460-462, :504-506, :577-581).  A 1x1 convolution is a GEMM over all R = B*S*K positions

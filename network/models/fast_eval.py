@@ -166,6 +166,22 @@ class FastEval:
             self._idents[key] = torch.arange(J * K, dtype=torch.int32, device=dev).view(1, J, K).expand(B, J, K).contiguous()
         return self._idents[key]
 
+    @staticmethod
+    def _q_scales(ext, name, plan, q, xyz1, c1q, a_col, cadd, out, c_q):
+        """The scales of one keypoint-query module: both in ONE persistent launch when there are two (ext.sa_mlp_max_pair,
+        which itself falls back to one launch per scale for combinations its kernel does not cover)."""
+        probs = []
+        for i, (idx, a, nb_xyz) in enumerate(plan):
+            p = q[(name, i)]
+            probs.append(dict(idx=idx, w2=p["l2"][0], b2=p["l2"][1], w3=p["l3"][0], b3=p["l3"][1], a1f=a[:, :, a_col:a_col + c1q],
+                              xyz=nb_xyz, cxyz=xyz1, wx=p["wx"], b1=p["b1"],
+                              cadd=None if cadd is None else cadd[:, :, i * c1q:(i + 1) * c1q], out=out[:, :, i * c_q:(i + 1) * c_q]))
+        if len(probs) == 2:
+            ext.sa_mlp_max_pair(*probs)
+        else:
+            for p in probs:
+                ext.sa_mlp_max(p.pop("idx"), p.pop("w2"), p.pop("b2"), p.pop("w3"), p.pop("b3"), **p)
+
     # ------------------------------------------------------------------------------------
     def forward(self, input, flag_dict):
         from hotrack_amd import gemm_tuning
@@ -290,18 +306,12 @@ class FastEval:
                 idx = gi if K == kmax else (gi_small if K == kmin and gi_small is not None else gi[:, :, :K].contiguous())
                 plan.append((idx, F.linear(src2, W).view(B, N, -1), xyz2))
         f11 = torch.empty((B, J, 2 * c_q), **f32)
-        for i, (idx, a, nb_xyz) in enumerate(plan):
-            p = q[("q1", i)]
-            ext.sa_mlp_max(idx, *p["l2"], *p["l3"], a1f=a[:, :, :c1q], xyz=nb_xyz, cxyz=xyz1,
-                           wx=p["wx"], b1=p["b1"], out=f11[:, :, i * c_q:(i + 1) * c_q])
+        self._q_scales(ext, "q1", plan, q, xyz1, c1q, 0, None, f11, c_q)
         Wr, br, perm = P["r1"]
         f12 = F.linear(ext.gather_rows(f11, self._perm_idx(perm, B)).view(B * J, -1), Wr, br)  # (B*J, C)
         cadd = F.linear(f12, P["wc2"]).view(B, J, -1)
         f13 = torch.empty((B, J, 2 * c_q), **f32)
-        for i, (idx, a, nb_xyz) in enumerate(plan):
-            p = q[("q2", i)]
-            ext.sa_mlp_max(idx, *p["l2"], *p["l3"], a1f=a[:, :, c1q:2 * c1q], xyz=nb_xyz, cxyz=xyz1,
-                           wx=p["wx"], b1=p["b1"], cadd=cadd[:, :, i * c1q:(i + 1) * c1q], out=f13[:, :, i * c_q:(i + 1) * c_q])
+        self._q_scales(ext, "q2", plan, q, xyz1, c1q, c1q, cadd, f13, c_q)
         Wr, br, perm = P["r2"]
         f14 = F.linear(ext.gather_rows(f13, self._perm_idx(perm, B)).view(B * J, -1), Wr, br)
 

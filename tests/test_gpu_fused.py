@@ -281,3 +281,38 @@ def test_fast_path_other_shapes_match_module_path(B, N, dup):
             pointnet_utils.set_fused_backend(None)
     for k in ("pred_kp", "pred_kp_handframe", "points_handframe"):
         assert torch.allclose(fast[k], ref[k], atol=2e-4), (k, float((fast[k] - ref[k]).abs().max()))
+
+
+@pytest.mark.parametrize("with_cadd", [False, True])
+@pytest.mark.parametrize("B,N,order", [(3, 300, (16, 64)), (64, 1024, (64, 16)), (1, 1024, (16, 64))])
+def test_sa_mlp_max_pair_equals_two_launches(with_cadd, B, N, order):
+    """Both scales of a keypoint-query module in one persistent launch (pn2x_sa_mlp_max_pair) == two pn2x_sa_mlp_max
+    launches, bit for bit (same tiles, same arithmetic; only the assignment of tiles to workgroups differs)."""
+    from hotrack_amd import ext
+    J, C1, C2, C3 = 21, 128, 128, 192
+    g = torch.Generator(device="cuda").manual_seed(B * 7 + N)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    xyz, kp = torch.rand(B, N, 3, device="cuda", generator=g), torch.rand(B, J, 3, device="cuda", generator=g)
+    a1f_all = r(B, N, 2 * C1) * 0.5
+    cadd_all = r(B, J, 2 * C1) * 0.5 if with_cadd else None
+    probs = []
+    for i, K in enumerate(order):
+        idx = torch.randint(0, N, (B, J, K), device="cuda", generator=g, dtype=torch.int32)
+        probs.append(dict(idx=idx, w2=r(C2, C1) * 0.1, b2=r(C2) * 0.1, w3=r(C3, C2) * 0.1, b3=r(C3) * 0.1,
+                          a1f=a1f_all[:, :, i * C1:(i + 1) * C1], xyz=xyz, cxyz=kp, wx=r(C1, 3), b1=r(C1) * 0.1,
+                          cadd=None if cadd_all is None else cadd_all[:, :, i * C1:(i + 1) * C1]))
+    single = torch.empty(B, J, 2 * C3, device="cuda")
+    pair = torch.empty(B, J, 2 * C3, device="cuda")
+    for i, p in enumerate(probs):
+        ext.sa_mlp_max(p["idx"], p["w2"], p["b2"], p["w3"], p["b3"], a1f=p["a1f"], xyz=p["xyz"], cxyz=p["cxyz"], wx=p["wx"], b1=p["b1"],
+                       cadd=p["cadd"], out=single[:, :, i * C3:(i + 1) * C3])
+    ext.sa_mlp_max_pair(*(dict(p, out=pair[:, :, i * C3:(i + 1) * C3]) for i, p in enumerate(probs)))
+    assert torch.equal(single, pair)
+    # an uncovered combination (K = 32 / 64) silently takes the two-launch route and still gives the same answer
+    p32 = dict(probs[0], idx=torch.randint(0, N, (B, J, 32), device="cuda", generator=g, dtype=torch.int32))
+    a, b2_ = torch.empty(B, J, C3, device="cuda"), torch.empty(B, J, C3, device="cuda")
+    ext.sa_mlp_max(p32["idx"], p32["w2"], p32["b2"], p32["w3"], p32["b3"], a1f=p32["a1f"], xyz=xyz, cxyz=kp, wx=p32["wx"], b1=p32["b1"],
+                   cadd=p32["cadd"], out=a)
+    big = next(p for p in probs if p["idx"].shape[2] == 64)
+    ext.sa_mlp_max_pair(dict(p32, out=b2_), dict(big, out=torch.empty(B, J, C3, device="cuda")))
+    assert torch.equal(a, b2_)
