@@ -168,9 +168,7 @@ bn_relu_bwd_reduce_kernel(long rows, int C, const float *__restrict__ dH, int ld
     if (rr < rpp) {
         BnCh k;
         load_saved(k, 4 * q, mean, invstd, gamma, beta);
-        for (long r = r0 + rr; r < r1; r += rpp) {
-            const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
-            float4 g = *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q);
+        auto acc = [&](const float4 y, float4 g) {
             if (relu) {
                 if (!(bn_act(y.x, k, 0) > 0.f)) g.x = 0.f;
                 if (!(bn_act(y.y, k, 1) > 0.f)) g.y = 0.f;
@@ -182,7 +180,18 @@ bn_relu_bwd_reduce_kernel(long rows, int C, const float *__restrict__ dH, int ld
             t.y += g.y * ((y.y - k.mean[1]) * k.invstd[1]);
             t.z += g.z * ((y.z - k.mean[2]) * k.invstd[2]);
             t.w += g.w * ((y.w - k.mean[3]) * k.invstd[3]);
+        };
+        long r = r0 + rr;
+        for (; r + 3L * rpp < r1; r += 4L * rpp) {  // eight independent 16-byte loads in flight per thread
+            const float *py = Y + r * ldy + 4 * q, *pg = dH + r * ldd + 4 * q;
+            const float4 y0 = *reinterpret_cast<const float4 *>(py), g0 = *reinterpret_cast<const float4 *>(pg);
+            const float4 y1 = *reinterpret_cast<const float4 *>(py + (long)rpp * ldy), g1 = *reinterpret_cast<const float4 *>(pg + (long)rpp * ldd);
+            const float4 y2 = *reinterpret_cast<const float4 *>(py + 2L * rpp * ldy), g2 = *reinterpret_cast<const float4 *>(pg + 2L * rpp * ldd);
+            const float4 y3 = *reinterpret_cast<const float4 *>(py + 3L * rpp * ldy), g3 = *reinterpret_cast<const float4 *>(pg + 3L * rpp * ldd);
+            acc(y0, g0); acc(y1, g1); acc(y2, g2); acc(y3, g3);
         }
+        for (; r < r1; r += rpp)
+            acc(*reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q), *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q));
     }
     block_reduce_to_sums(s, t, Q, rpp, C, sums);
 }

@@ -83,8 +83,12 @@ class Trainer(nn.Module):
             self.graph_step = bool(cfg.get("graph_step", os.environ.get("HOTRACK_GRAPH_STEP", "0") == "1"))
             self._graph = self._graph_sig = self._static = self._static_loss = None
             if cfg["optimizer"] == "Adam":
+                # GPU: the fused multi-tensor Adam (one or two launches over all parameters instead of ~15 foreach kernels;
+                # device-side step counters, so it is graph-capturable as is).  Same update rule: L2 weight decay, no amsgrad.
+                on_gpu = isinstance(self.device, torch.device) and self.device.type == "cuda"
+                kw = dict(fused=True, capturable=self.graph_step) if on_gpu and cfg.get("fused_adam", True) else dict(capturable=self.graph_step)
                 self.optimizer = torch.optim.Adam(params, lr=cfg["learning_rate"], betas=(0.9, 0.999), eps=1e-8,
-                                                  weight_decay=cfg["weight_decay"], capturable=self.graph_step)
+                                                  weight_decay=cfg["weight_decay"], **kw)
             else:
                 self.optimizer = torch.optim.SGD(params, lr=cfg["learning_rate"], momentum=0.9)
             self.scheduler = self._make_scheduler()
