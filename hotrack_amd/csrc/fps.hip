@@ -111,9 +111,17 @@ fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_al
         }
         // fp32 >= 0 (or exactly -1.0f) orders like its bit pattern as a signed int.
         const int bi = f2i(best);
+#if defined(PN2_FPS_PROBE) && PN2_FPS_PROBE == 2   /* timing probe: no DPP reduction */
+        const int wmax = __builtin_amdgcn_readfirstlane(bi);
+#else
         const int wmax = wave_max_i32(bi);
+#endif
+#if defined(PN2_FPS_PROBE) && PN2_FPS_PROBE == 4   /* timing probe: no ballot / ctz */
+        const int wl = it & 63;
+#else
         const uint64_t tie = __ballot(bi == wmax);
         const int wl = __builtin_ctzll(tie);  // first lane == lowest tie rank in this wave
+#endif
 
         int kstar;
         int gbits = wmax;  // bit pattern of the global maximum of this iteration
@@ -161,6 +169,11 @@ fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_al
             // the winning (maximum) running distance of this pick -- input of the post-hoc tie check
             if constexpr (RAD) radii_all[(size_t)blockIdx.x * m + it] = i2f(gbits);
         }
+#if defined(PN2_FPS_PROBE) && PN2_FPS_PROBE == 1   /* timing probe: no dependent centroid read */
+        if constexpr (CENT == kCentLds) {
+            cx += 1e-7f * (float)(kstar & 1);
+        } else
+#endif
         if constexpr (CENT == kCentLds) {
             cx = lxyz[3 * kstar + 0];
             cy = lxyz[3 * kstar + 1];

@@ -75,6 +75,10 @@ int group_fwd_dispatch(int b, int c, int n, int npoints, int nsample, const floa
 }
 
 // ---- backward ---------------------------------------------------------------------------
+// A work item = (position e, chunk of kGgU channels): the kGgU gradient loads of an item are independent and issued
+// together (a thread walking the channels one load at a time sat on one HBM round trip per element: 0.02-0.14 of the
+// HBM roofline), then the LDS adds follow; consecutive threads take consecutive positions -> coalesced rows of grad_out.
+constexpr int kGgU = 8;
 __global__ void __launch_bounds__(kGgThreads)
 group_bwd_lds_kernel(int c, int n, int ps, int cc, const float *__restrict__ grad_out_all,
                      const int *__restrict__ idx_all, float *__restrict__ grad_points_all) {
@@ -86,13 +90,30 @@ group_bwd_lds_kernel(int c, int n, int ps, int cc, const float *__restrict__ gra
     __syncthreads();
     const int *__restrict__ idx = idx_all + (size_t)b * ps;
     const float *__restrict__ g = grad_out_all + ((size_t)b * c + c0) * ps;
-    for (int e = threadIdx.x; e < ps; e += kGgThreads) {
+    const int chunks = (nc + kGgU - 1) / kGgU;
+    for (int item = threadIdx.x; item < ps * chunks; item += kGgThreads) {
+        const int chunk = item / ps, e = item - chunk * ps;
+        const int ch0 = chunk * kGgU;
         const int id = idx[e];
-        for (int ch = 0; ch < nc; ++ch) atomicAdd(&acc[ch * n + id], g[(size_t)ch * ps + e]);
+        float v[kGgU];
+#pragma unroll
+        for (int u = 0; u < kGgU; ++u) v[u] = (ch0 + u < nc) ? g[(size_t)(ch0 + u) * ps + e] : 0.f;
+#pragma unroll
+        for (int u = 0; u < kGgU; ++u)
+            if (ch0 + u < nc) atomicAdd(&acc[(ch0 + u) * n + id], v[u]);
     }
     __syncthreads();
     float *__restrict__ dst = grad_points_all + ((size_t)b * c + c0) * n;
-    for (int i = threadIdx.x; i < nc * n; i += kGgThreads) dst[i] += acc[i];
+    const int total = nc * n;
+    int i = threadIdx.x;
+    for (; i + 3 * kGgThreads < total; i += 4 * kGgThreads) {  // four independent read-modify-writes in flight
+        const float d0 = dst[i], d1 = dst[i + kGgThreads], d2 = dst[i + 2 * kGgThreads], d3 = dst[i + 3 * kGgThreads];
+        dst[i] = d0 + acc[i];
+        dst[i + kGgThreads] = d1 + acc[i + kGgThreads];
+        dst[i + 2 * kGgThreads] = d2 + acc[i + 2 * kGgThreads];
+        dst[i + 3 * kGgThreads] = d3 + acc[i + 3 * kGgThreads];
+    }
+    for (; i < total; i += kGgThreads) dst[i] += acc[i];
 }
 
 __global__ void __launch_bounds__(kGgThreads)
@@ -110,6 +131,9 @@ int group_bwd_dispatch(int b, int c, int n, int npoints, int nsample, const floa
     const long ps_l = (long)npoints * nsample;
     if (b == 0 || c == 0 || ps_l == 0) return PN2_OK;
     const int ps = (int)ps_l;
+    // inverted index + LDS-staged segment sums (scatter_cm.hip); shapes it does not cover (very long position lists, a
+    // scratch that would have to grow during graph capture) take the LDS-atomic slab kernel below
+    if (scatter_cm_dispatch(1, b, c, n, ps, grad_out, idx, nullptr, grad_points, st) == PN2_OK) return PN2_OK;
     const int lds_budget = 64 * 1024;
     int cc = lds_budget / (int)(sizeof(float) * (size_t)n);
     if (cc >= 1) {

@@ -48,6 +48,9 @@ int interp_fwd_dispatch(int b, int c, int m, int n, const float *points, const i
     return check_launch();
 }
 
+// A work item = (query j, chunk of kIpU channels): its kIpU gradient loads are independent and issued together, then the
+// 3 x kIpU LDS adds (see group_bwd_lds_kernel: one load at a time was a latency chain, 0.04 of the HBM roofline).
+constexpr int kIpU = 8;
 __global__ void __launch_bounds__(kIpThreads)
 interp_bwd_lds_kernel(int c, int n, int m, int cc, const float *__restrict__ grad_out_all,
                       const int *__restrict__ idx_all, const float *__restrict__ weight_all,
@@ -59,21 +62,39 @@ interp_bwd_lds_kernel(int c, int n, int m, int cc, const float *__restrict__ gra
     for (int i = threadIdx.x; i < nc * m; i += kIpThreads) acc[i] = 0.f;
     __syncthreads();
     const float *__restrict__ g = grad_out_all + ((size_t)b * c + c0) * n;
-    for (int j = threadIdx.x; j < n; j += kIpThreads) {
+    const int chunks = (nc + kIpU - 1) / kIpU;
+    for (int item = threadIdx.x; item < n * chunks; item += kIpThreads) {
+        const int chunk = item / n, j = item - chunk * n;
+        const int ch0 = chunk * kIpU;
         const int *__restrict__ id = idx_all + ((size_t)b * n + j) * 3;
         const float *__restrict__ w = weight_all + ((size_t)b * n + j) * 3;
         const int i0 = id[0], i1 = id[1], i2 = id[2];
         const float w0 = w[0], w1 = w[1], w2 = w[2];
-        for (int ch = 0; ch < nc; ++ch) {
-            const float go = g[(size_t)ch * n + j];
-            atomicAdd(&acc[ch * m + i0], go * w0);
-            atomicAdd(&acc[ch * m + i1], go * w1);
-            atomicAdd(&acc[ch * m + i2], go * w2);
+        float v[kIpU];
+#pragma unroll
+        for (int u = 0; u < kIpU; ++u) v[u] = (ch0 + u < nc) ? g[(size_t)(ch0 + u) * n + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < kIpU; ++u) {
+            if (ch0 + u < nc) {
+                float *a = acc + (ch0 + u) * m;
+                atomicAdd(a + i0, v[u] * w0);
+                atomicAdd(a + i1, v[u] * w1);
+                atomicAdd(a + i2, v[u] * w2);
+            }
         }
     }
     __syncthreads();
     float *__restrict__ dst = grad_points_all + ((size_t)b * c + c0) * m;
-    for (int i = threadIdx.x; i < nc * m; i += kIpThreads) dst[i] += acc[i];
+    const int total = nc * m;
+    int i = threadIdx.x;
+    for (; i + 3 * kIpThreads < total; i += 4 * kIpThreads) {
+        const float d0 = dst[i], d1 = dst[i + kIpThreads], d2 = dst[i + 2 * kIpThreads], d3 = dst[i + 3 * kIpThreads];
+        dst[i] = d0 + acc[i];
+        dst[i + kIpThreads] = d1 + acc[i + kIpThreads];
+        dst[i + 2 * kIpThreads] = d2 + acc[i + 2 * kIpThreads];
+        dst[i + 3 * kIpThreads] = d3 + acc[i + 3 * kIpThreads];
+    }
+    for (; i < total; i += kIpThreads) dst[i] += acc[i];
 }
 
 __global__ void __launch_bounds__(kIpThreads)
@@ -95,6 +116,7 @@ interp_bwd_atomic_kernel(int c, int n, int m, const float *__restrict__ grad_out
 int interp_bwd_dispatch(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
                         float *grad_points, hipStream_t st) {
     if (b == 0 || c == 0 || n == 0) return PN2_OK;
+    if (scatter_cm_dispatch(3, b, c, m, n, grad_out, idx, weight, grad_points, st) == PN2_OK) return PN2_OK;  // see scatter_cm.hip
     int cc = (64 * 1024) / (int)(sizeof(float) * (size_t)m);
     if (cc >= 1) {
         if (cc > 16) cc = 16;

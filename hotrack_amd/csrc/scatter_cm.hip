@@ -1,0 +1,160 @@
+// scatter_cm.hip -- atomics-free backward of group_points / gather_points / three_interpolate on the reference's
+// channel-major layout (grad_out (B,C,M), grad_points (B,C,N)).
+//
+// Replaces the data path of group_points_grad_kernel_fast / gather_points_grad_kernel_fast / three_interpolate_grad_kernel_fast
+// (reference group_points_gpu.cu:8-25, sampling_gpu.cu:46-63, interpolate_gpu.cu:192-214: one global atomicAdd per element).
+// fp32 atomics -- global or LDS -- retire about one lane per clock per CU on MI355X, which held the LDS-slab kernels of
+// round 1 at 0.02-0.14 of the HBM roofline.  Here the index list of each cloud is inverted once (counting sort by target:
+// offsets + order, train_ops.hip) and a workgroup that owns (cloud, cc channels) stages its [cc][M] slice of grad_out in LDS
+// with coalesced loads; every (target i, channel) then SUMS its contributions with plain LDS reads and adds the result to
+// grad_points with one coalesced read-modify-write (the reference's accumulate-into-the-caller's-buffer semantics).
+#include <mutex>
+#include <unordered_map>
+
+#include "pn2_common.h"
+#include "../../include/pn2_ext.h"
+
+namespace pn2 {
+
+int *stream_scratch_ints(size_t count, hipStream_t st) {
+    struct Buf { int *p = nullptr; size_t n = 0; };
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, Buf> bufs;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    Buf &b = bufs[((unsigned long long)dev << 48) ^ (unsigned long long)(uintptr_t)st];
+    if (b.n >= count) return b.p;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;  // cannot allocate inside a capture
+    }
+    // the old buffer may still be in use by work already enqueued on this stream: free it in stream order
+    if (b.p) (void)hipFreeAsync(b.p, st);
+    const size_t want = count + count / 2;
+    if (hipMallocAsync((void **)&b.p, want * sizeof(int), st) != hipSuccess) {
+        (void)hipGetLastError();
+        b.p = nullptr; b.n = 0;
+        return nullptr;
+    }
+    b.n = want;
+    return b.p;
+}
+
+constexpr int kScT = 1024;  // 16 waves per workgroup: the LDS slab allows only ~2 workgroups per CU, the waves hide the update latency
+
+// LDS: [cc][m_src] slice of grad_out | offsets (n_dst + 1) | order (L) | weights (L, T == 3): the inverted lists are walked
+// from LDS too (per-item dependent global loads -- offsets, then order, then the value -- were a latency chain).
+template <int T>
+__global__ void __launch_bounds__(kScT)
+cm_segment_sum_kernel(int c, int n_dst, int m_src, int cc, const float *__restrict__ grad_out_all, const int *__restrict__ offsets_all,
+                      const int *__restrict__ order_all, const float *__restrict__ weight_all, float *__restrict__ grad_points_all) {
+    extern __shared__ __attribute__((aligned(16))) float G[];
+    const int L = m_src * T;
+    int *loff = reinterpret_cast<int *>(G + (size_t)cc * m_src);
+    int *lord = loff + n_dst + 1;
+    float *lw = reinterpret_cast<float *>(lord + L);
+    const int b = blockIdx.y, c0 = blockIdx.x * cc;
+    const int nc = (c - c0) < cc ? (c - c0) : cc;
+    const float *__restrict__ src = grad_out_all + ((size_t)b * c + c0) * m_src;
+    const int tot = nc * m_src;
+    if ((((uintptr_t)src) & 15) == 0 && (tot & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < tot; i += kScT * 4) *reinterpret_cast<float4 *>(G + i) = *reinterpret_cast<const float4 *>(src + i);
+    } else {
+        for (int i = threadIdx.x; i < tot; i += kScT) G[i] = src[i];
+    }
+    const int *__restrict__ offsets = offsets_all + (size_t)b * (n_dst + 1);
+    const int *__restrict__ order = order_all + (size_t)b * L;
+    for (int i = threadIdx.x; i <= n_dst; i += kScT) loff[i] = offsets[i];
+    for (int i = threadIdx.x; i < L; i += kScT) lord[i] = order[i];
+    if constexpr (T == 3) {
+        const float *__restrict__ weight = weight_all + (size_t)b * L;
+        for (int i = threadIdx.x; i < L; i += kScT) lw[i] = weight[i];
+    }
+    __syncthreads();
+    float *__restrict__ dst = grad_points_all + ((size_t)b * c + c0) * n_dst;
+    const int total = n_dst * nc;
+    constexpr int U = 4;  // items per thread in flight
+    for (int item0 = threadIdx.x; item0 < total; item0 += U * kScT) {
+        int p0[U], p1[U], chn[U];
+        float d[U], acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {  // list bounds first (LDS): targets nobody contributed to cost no HBM traffic at all
+            const int item = item0 + u * kScT;
+            p0[u] = p1[u] = 0;
+            chn[u] = 0;
+            if (item < total) {
+                const int ch = item / n_dst, i = item - ch * n_dst;  // consecutive threads -> consecutive targets: coalesced update
+                chn[u] = ch;
+                p0[u] = loff[i];
+                p1[u] = loff[i + 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = p1[u] > p0[u] ? dst[item0 + u * kScT] : 0.f;  // the U loads are issued together
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float *__restrict__ g = G + chn[u] * m_src;
+            acc[u] = 0.f;
+            for (int p = p0[u]; p < p1[u]; ++p) {
+                const int e = lord[p];
+                if constexpr (T == 1) acc[u] += g[e];
+                else acc[u] += lw[e] * g[e / 3];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (p1[u] > p0[u]) dst[item0 + u * kScT] = d[u] + acc[u];
+    }
+}
+
+size_t scatter_cm_scratch_ints(int t, int b, int n_dst, int m_src) { return (size_t)b * ((size_t)n_dst + 1 + (size_t)m_src * t); }
+
+int scatter_cm_dispatch(int t, int b, int c, int n_dst, int m_src, const float *grad_out, const int *idx, const float *weight,
+                        float *grad_points, hipStream_t st, int *scratch, size_t scratch_ints) {
+    if (b == 0 || c == 0 || m_src == 0) return PN2_OK;
+    const size_t l = (size_t)m_src * t;
+    const size_t meta = (size_t)n_dst + 1 + l * (t == 3 ? 2 : 1);  // ints / floats next to the slab
+    if ((size_t)n_dst + 1 + 256 > 16384 || meta + m_src > 16384) return PN2_ERANGE;  // 64 KiB of LDS per workgroup
+    int cc = (int)((16384 - meta) / m_src);
+    if (cc > 16) cc = 16;
+    if (cc > c) cc = c;
+    while (cc > 1 && (long)b * ((c + cc - 1) / cc) < 512) cc = (cc + 1) / 2;  // >= 2 workgroups of 16 waves per CU
+    const size_t need = scatter_cm_scratch_ints(t, b, n_dst, m_src);
+    if (!scratch) {
+        scratch = stream_scratch_ints(need, st);
+        if (!scratch) return PN2_ERANGE;
+    } else if (scratch_ints < need) {
+        return PN2_ESCRATCH;
+    }
+    int *offsets = scratch, *order = scratch + (size_t)b * (n_dst + 1);
+    int rc = inverse_index_launch(b, n_dst, (int)l, idx, offsets, order, st);
+    if (rc != PN2_OK) return rc;
+    const dim3 grid((c + cc - 1) / cc, b);
+    const size_t lds = ((size_t)cc * m_src + meta) * sizeof(float);
+    if (t == 1)
+        hipLaunchKernelGGL(cm_segment_sum_kernel<1>, grid, dim3(kScT), lds, st, c, n_dst, m_src, cc, grad_out, offsets, order, weight, grad_points);
+    else
+        hipLaunchKernelGGL(cm_segment_sum_kernel<3>, grid, dim3(kScT), lds, st, c, n_dst, m_src, cc, grad_out, offsets, order, weight, grad_points);
+    return check_launch();
+}
+
+}  // namespace pn2
+
+// Operator-API backward with caller-provided scratch (graph-capture safe: nothing is allocated inside):
+//   t = 1  group_points_grad / gather_points_grad (m_src = npoints * nsample positions, idx (b, m_src))
+//   t = 3  three_interpolate_grad                 (m_src = n query points, idx / weight (b, n, 3))
+extern "C" long pn2x_scatter_cm_scratch_ints(int t, int b, int n_dst, int m_src) {
+    if ((t != 1 && t != 3) || b < 0 || n_dst < 1 || m_src < 0) return -1;
+    return (long)pn2::scatter_cm_scratch_ints(t, b, n_dst, m_src);
+}
+
+extern "C" int pn2x_scatter_cm(int t, int b, int c, int n_dst, int m_src, const float *grad_out, const int *idx, const float *weight,
+                               float *grad_points, int *scratch, long scratch_ints, void *stream) {
+    using namespace pn2;
+    if ((t != 1 && t != 3) || b < 0 || c < 0 || n_dst < 1 || m_src < 0 || scratch_ints < 0) return PN2_EINVAL;
+    if (b == 0 || c == 0 || m_src == 0) return PN2_OK;
+    if (!grad_out || !idx || !grad_points || !scratch || (t == 3 && !weight)) return PN2_ENULL;
+    return scatter_cm_dispatch(t, b, c, n_dst, m_src, grad_out, idx, weight, grad_points, (hipStream_t)stream, scratch, (size_t)scratch_ints);
+}

@@ -371,6 +371,81 @@ static int slab_channels(int b, int n_dst, int C) {
     return cc;
 }
 
+// ---- atomics-free row scatters: inverse index (CSR) + owner-computes segment sum --------------------------------------------
+// fp32 LDS / L2 atomics retire about one lane per clock per CU on this part, so the slab kernels above top out around
+// 0.2-0.25 T adds/s.  Here the index list of a cloud is inverted once (counting sort by target row: offsets + order), and
+// every (target row, channel quad) SUMS its contributions with plain coalesced 16-byte row reads -- no atomics in the data
+// path, nothing to pre-zero, every output row written exactly once.
+__global__ void __launch_bounds__(kTT)
+inverse_index_kernel(int n_dst, int L, const int *__restrict__ idx_all, int *__restrict__ offsets_all, int *__restrict__ order_all) {
+    extern __shared__ int cnt[];  // [n_dst + 1] counts -> running cursors; then [kTT] chunk totals
+    int *part = cnt + n_dst + 1;
+    const int b = blockIdx.x;
+    const int *__restrict__ idx = idx_all + (size_t)b * L;
+    int *__restrict__ offsets = offsets_all + (size_t)b * (n_dst + 1);
+    int *__restrict__ order = order_all + (size_t)b * L;
+    for (int i = threadIdx.x; i <= n_dst; i += kTT) cnt[i] = 0;
+    __syncthreads();
+    auto key = [&](int e) { const int k = idx[e]; return k < 0 ? 0 : (k >= n_dst ? n_dst - 1 : k); };  // (out-of-range indices cannot corrupt LDS)
+    for (int e = threadIdx.x; e < L; e += kTT) atomicAdd(&cnt[key(e)], 1);
+    __syncthreads();
+    // exclusive scan: each thread owns a contiguous chunk
+    const int chunk = (n_dst + kTT - 1) / kTT;
+    const int i0 = threadIdx.x * chunk, i1 = (i0 + chunk) < n_dst ? (i0 + chunk) : n_dst;
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) sum += cnt[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < kTT; ++t) { const int v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = i0; i < i1; ++i) {
+        const int v = cnt[i];
+        offsets[i] = run;
+        cnt[i] = run;  // cursor
+        run += v;
+    }
+    if (threadIdx.x == 0) offsets[n_dst] = L;
+    __syncthreads();
+    for (int e = threadIdx.x; e < L; e += kTT) order[atomicAdd(&cnt[key(e)], 1)] = e;
+}
+
+template <int T>  // index entries per source row: 1 = plain row scatter, 3 = three-NN interpolation (weighted)
+__global__ void __launch_bounds__(kTT)
+rows_segment_sum_kernel(int n_dst, int m_src, int Q, const float *__restrict__ dOut, int ldo, const int *__restrict__ offsets_all,
+                        const int *__restrict__ order_all, const float *__restrict__ weight_all, float *__restrict__ dIn, int ldi,
+                        int accumulate) {
+    const int b = blockIdx.y;
+    const long item = (long)blockIdx.x * kTT + threadIdx.x;
+    if (item >= (long)n_dst * Q) return;
+    const int i = (int)(item / Q), q = (int)(item % Q);
+    const int *__restrict__ offsets = offsets_all + (size_t)b * (n_dst + 1);
+    const int *__restrict__ order = order_all + (size_t)b * m_src * T;
+    const float *__restrict__ src = dOut + (size_t)b * m_src * ldo + 4 * q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int p1 = offsets[i + 1];
+    for (int p = offsets[i]; p < p1; ++p) {
+        const int e = order[p];
+        const int j = T == 1 ? e : e / T;
+        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)j * ldo);
+        if constexpr (T == 1) {
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        } else {
+            const float w = weight_all[(size_t)b * m_src * T + e];
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+    }
+    float4 *dst = reinterpret_cast<float4 *>(dIn + ((size_t)b * n_dst + i) * ldi + 4 * q);
+    if (accumulate) {
+        const float4 d = *dst;
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+    }
+    *dst = acc;
+}
+
 static int rows_per_block_for(long rows, int C) {
     const int rpp = kTT / (C >> 2);
     long rpb = (rows + 1023) / 1024;  // ~1024 workgroups on a large problem
@@ -479,3 +554,37 @@ extern "C" int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a
 }
 
 extern "C" int pn2x_bn_sums_doubles(int c) { return 2 * c * pn2::kRep; }
+
+namespace pn2 {
+int inverse_index_launch(int b, int n_dst, int l, const int *idx, int *offsets, int *order, hipStream_t st) {
+    const size_t lds = ((size_t)n_dst + 1 + kTT) * sizeof(int);
+    if (lds > 64 * 1024) return PN2_ERANGE;
+    hipLaunchKernelGGL(inverse_index_kernel, dim3(b), dim3(kTT), lds, st, n_dst, l, idx, offsets, order);
+    return check_launch();
+}
+}  // namespace pn2
+
+extern "C" int pn2x_inverse_index(int b, int n_dst, int l, const int *idx, int *offsets, int *order, void *stream) {
+    using namespace pn2;
+    if (b < 0 || n_dst < 1 || l < 0) return PN2_EINVAL;
+    if (b == 0) return PN2_OK;
+    if (!idx || !offsets || !order) return PN2_ENULL;
+    return inverse_index_launch(b, n_dst, l, idx, offsets, order, (hipStream_t)stream);
+}
+
+extern "C" int pn2x_rows_segment_sum(int b, int n_dst, int m_src, int t, int c, const float *dout, int ldo, const int *offsets,
+                                     const int *order, const float *weight, float *din, int ldi, int accumulate, void *stream) {
+    using namespace pn2;
+    if (b < 0 || n_dst < 1 || m_src < 0 || c < 0 || c % 4 || ldo < c || ldo % 4 || ldi < c || ldi % 4 || (t != 1 && t != 3)) return PN2_EINVAL;
+    if (b == 0 || c == 0) return PN2_OK;
+    if (!dout || !offsets || !order || !din || (t == 3 && !weight)) return PN2_ENULL;
+    if (((uintptr_t)dout | (uintptr_t)din) % 16) return PN2_EINVAL;
+    const int Q = c / 4;
+    const long total = (long)n_dst * Q;
+    const dim3 grid((unsigned)((total + kTT - 1) / kTT), b);
+    if (t == 1)
+        hipLaunchKernelGGL(rows_segment_sum_kernel<1>, grid, dim3(kTT), 0, (hipStream_t)stream, n_dst, m_src, Q, dout, ldo, offsets, order, weight, din, ldi, accumulate);
+    else
+        hipLaunchKernelGGL(rows_segment_sum_kernel<3>, grid, dim3(kTT), 0, (hipStream_t)stream, n_dst, m_src, Q, dout, ldo, offsets, order, weight, din, ldi, accumulate);
+    return check_launch();
+}

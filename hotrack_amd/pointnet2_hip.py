@@ -55,6 +55,27 @@ _lib.pn2_strerror.argtypes = [_ci]
 _lib.pn2_abi_version.restype = _ci
 _lib.pn2_last_hip_error.restype = _ci
 
+_lib.pn2x_scatter_cm_scratch_ints.argtypes = [_ci, _ci, _ci, _ci]
+_lib.pn2x_scatter_cm_scratch_ints.restype = ctypes.c_long
+_lib.pn2x_scatter_cm.argtypes = [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp]
+_lib.pn2x_scatter_cm.restype = _ci
+_PN2_ERANGE = -3
+
+
+def _scatter_cm(t, b, c, n_dst, m_src, grad_out, idx_ptr, w_ptr, out_ptr, dev, stream):
+    """Atomics-free backward with torch-allocated scratch (pn2_ext.h: pn2x_scatter_cm) -- capture-safe.  False when the
+    shape is not covered: the caller then uses the reference-signature entry."""
+    need = _lib.pn2x_scatter_cm_scratch_ints(t, b, n_dst, m_src)
+    if need < 0:
+        return False
+    scratch = torch.empty(max(int(need), 1), dtype=torch.int32, device=dev)
+    rc = _lib.pn2x_scatter_cm(t, b, c, n_dst, m_src, grad_out, idx_ptr, w_ptr, out_ptr, scratch.data_ptr(), need, stream)
+    if rc == _PN2_ERANGE:
+        return False
+    _check(rc, "scatter_cm")
+    return True
+
+
 ABI_VERSION = _lib.pn2_abi_version()
 KNN_MAX_K = 200  # interpolate_gpu.cu:30-31
 
@@ -145,7 +166,8 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     i = _ptr(idx, "idx", _i32, b * npoints * nsample)
     o = _ptr(grad_points, "grad_points", _f32, b * c * n)
     with torch.cuda.device(grad_out.device):
-        _check(_lib.pn2_group_points_grad(b, c, n, npoints, nsample, g, i, o, _stream(grad_out)), "group_points_grad")
+        if not _scatter_cm(1, b, c, n, npoints * nsample, g, i, None, o, grad_out.device, _stream(grad_out)):
+            _check(_lib.pn2_group_points_grad(b, c, n, npoints, nsample, g, i, o, _stream(grad_out)), "group_points_grad")
     return 1
 
 
@@ -165,7 +187,8 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
     i = _ptr(idx, "idx", _i32, b * npoints)
     o = _ptr(grad_points, "grad_points", _f32, b * c * n)
     with torch.cuda.device(grad_out.device):
-        _check(_lib.pn2_gather_points_grad(b, c, n, npoints, g, i, o, _stream(grad_out)), "gather_points_grad")
+        if not _scatter_cm(1, b, c, n, npoints, g, i, None, o, grad_out.device, _stream(grad_out)):
+            _check(_lib.pn2_gather_points_grad(b, c, n, npoints, g, i, o, _stream(grad_out)), "gather_points_grad")
     return 1
 
 
@@ -208,7 +231,8 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     w = _ptr(weight, "weight", _f32, b * n * 3)
     o = _ptr(grad_points, "grad_points", _f32, b * c * m)
     with torch.cuda.device(grad_out.device):
-        _check(_lib.pn2_three_interpolate_grad(b, c, n, m, g, i, w, o, _stream(grad_out)), "three_interpolate_grad")
+        if not _scatter_cm(3, b, c, m, n, g, i, w, o, grad_out.device, _stream(grad_out)):
+            _check(_lib.pn2_three_interpolate_grad(b, c, n, m, g, i, w, o, _stream(grad_out)), "three_interpolate_grad")
 
 
 EXPORTED = (

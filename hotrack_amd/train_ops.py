@@ -30,6 +30,11 @@ for _n in ("pn2x_bn_stats", "pn2x_bn_relu_apply", "pn2x_bn_relu_bwd", "pn2x_scat
            "pn2x_sa_layer1"):
     getattr(_lib, _n).restype = _ci
 
+_lib.pn2x_inverse_index.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp]
+_lib.pn2x_inverse_index.restype = _ci
+_lib.pn2x_rows_segment_sum.argtypes = [_ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _vp]
+_lib.pn2x_rows_segment_sum.restype = _ci
+INVERSE_MAX_ROWS = 16127  # pn2x_inverse_index keeps n_dst + 1 + 256 counters in 64 KiB of LDS
 _lib.pn2x_bn_sums_doubles.argtypes = [_ci]
 _lib.pn2x_bn_sums_doubles.restype = _ci
 _f32 = torch.float32
@@ -109,6 +114,30 @@ def bn_relu(y: torch.Tensor, bn: torch.nn.Module, ws: Workspace, conv_bias: torc
                          ws.take(_lib.pn2x_bn_sums_doubles(C)), ws.take(_lib.pn2x_bn_sums_doubles(C)))
 
 
+def inverse_index(idx: torch.Tensor, n_dst: int):
+    """idx (B, L) int32 with values in [0, n_dst) -> (offsets (B, n_dst+1), order (B, L)) int32: the positions of every target."""
+    B, L = idx.shape
+    offsets = torch.empty((B, n_dst + 1), dtype=torch.int32, device=idx.device)
+    order = torch.empty((B, L), dtype=torch.int32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _native._check(_lib.pn2x_inverse_index(B, n_dst, L, _native._ptr(idx, "idx", torch.int32, B * L), offsets.data_ptr(), order.data_ptr(),
+                                               _native._stream(idx)), "inverse_index")
+    return offsets, order
+
+
+def rows_segment_sum(dout: torch.Tensor, inv, n_dst: int, din: torch.Tensor, weight: torch.Tensor = None, accumulate: bool = False):
+    """din[b, i, :] (+)= sum over the entries e of target i of (weight[b, e] *) dout[b, e (// 3), :]  -- no atomics, every row of
+    din written once.  dout (B,M,C) contiguous; inv = inverse_index(idx.view(B, -1), n_dst); din (B,n_dst,>=C) rows."""
+    B, M, C = dout.shape
+    offsets, order = inv
+    t = 1 if weight is None else 3
+    with torch.cuda.device(dout.device):
+        _native._check(_lib.pn2x_rows_segment_sum(B, n_dst, M, t, C, _native._ptr(dout, "dout", _f32, B * M * C), C, offsets.data_ptr(),
+                                                  order.data_ptr(), _p(weight), din.data_ptr(), din.stride(1), 1 if accumulate else 0,
+                                                  _native._stream(dout)), "rows_segment_sum")
+    return din
+
+
 def scatter_add_rows(dout: torch.Tensor, idx: torch.Tensor, din: torch.Tensor) -> torch.Tensor:
     """din[b, idx[b,j], :] += dout[b, j, :]; dout (B,M,C) contiguous, idx (B,M) int32, din (B,N,>=C) rows (may be a column block)."""
     B, M, C = dout.shape
@@ -154,14 +183,17 @@ class _SaLayer1(torch.autograd.Function):
         n, a1f_shape, cadd_shape, S = ctx.meta
         idxs, rels = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         dev = douts[0].device
-        d_a1f = torch.zeros(a1f_shape, dtype=_f32, device=dev) if a1f_shape is not None else None
+        fits = a1f_shape is not None and a1f_shape[1] <= INVERSE_MAX_ROWS
+        d_a1f = (torch.empty if fits else torch.zeros)(a1f_shape, dtype=_f32, device=dev) if a1f_shape is not None else None
         d_cadd = torch.empty(cadd_shape, dtype=_f32, device=dev) if cadd_shape is not None else None
         d_wx = []
         col = 0
         for dy, idx, rel in zip(douts, idxs, rels):
             dy = dy.contiguous()
             B, SK, C1 = dy.shape
-            if d_a1f is not None:
+            if d_a1f is not None and fits:  # owner-computes segment sum over the inverted neighbour lists: no atomics, no pre-zeroing
+                rows_segment_sum(dy, inverse_index(idx.view(B, SK), a1f_shape[1]), a1f_shape[1], d_a1f[:, :, col:col + C1])
+            elif d_a1f is not None:
                 scatter_add_rows(dy, idx.view(B, SK), d_a1f[:, :, col:col + C1])
             if d_cadd is not None:
                 torch.sum(dy.view(B, S, SK // S, C1), dim=2, out=d_cadd[:, :, col:col + C1])
@@ -194,6 +226,10 @@ class _InterpRows(torch.autograd.Function):
         idx, weight = ctx.saved_tensors
         dout = dout.contiguous()
         B, n, C = dout.shape
+        if ctx.m <= INVERSE_MAX_ROWS:
+            dp = torch.empty((B, ctx.m, C), dtype=_f32, device=dout.device)
+            rows_segment_sum(dout, inverse_index(idx.view(B, n * 3), ctx.m), ctx.m, dp, weight=weight)
+            return dp, None, None
         dp = torch.zeros((B, ctx.m, C), dtype=_f32, device=dout.device)
         with torch.cuda.device(dout.device):
             _native._check(_lib.pn2x_three_interpolate_pm_grad(B, C, ctx.m, n, dout.data_ptr(), C, idx.data_ptr(), weight.data_ptr(),

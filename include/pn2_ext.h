@@ -250,6 +250,33 @@ int pn2x_scatter_add_rows(int b, int n, int m, int c, const float *dout, int ldo
 int pn2x_three_interpolate_pm_grad(int b, int c, int m, int n, const float *dout, int ldo, const int *idx,
                                    const float *weight, float *dpoints, int ldp, void *stream);
 
+/*
+ * Atomics-free form of the two row scatters above: invert the index list of every cloud once --
+ *   pn2x_inverse_index: idx (b, l) with values in [0, n_dst)  ->  offsets (b, n_dst + 1), order (b, l): entries
+ *   order[offsets[i] .. offsets[i+1]) are the positions e of idx with idx[e] == i   (n_dst <= 16127) --
+ * then every target row SUMS its contributions (pn2x_rows_segment_sum):
+ *   t == 1:  din[b, i, :] (+)= sum_{e in list(i)} dout[b, e, :]                      (transpose of pn2x_gather_rows)
+ *   t == 3:  din[b, i, :] (+)= sum_{e in list(i)} weight[b, e] * dout[b, e / 3, :]   (transpose of pn2x_three_interpolate_pm;
+ *            idx / weight are the (b, m_src, 3) tensors flattened)
+ * accumulate == 0 overwrites (nothing to pre-zero), != 0 adds to din.  The order inside a list is unspecified.
+ */
+int pn2x_inverse_index(int b, int n_dst, int l, const int *idx, int *offsets, int *order, void *stream);
+int pn2x_rows_segment_sum(int b, int n_dst, int m_src, int t, int c, const float *dout, int ldo, const int *offsets,
+                          const int *order, const float *weight, float *din, int ldi, int accumulate, void *stream);
+
+/*
+ * Backward of group_points / gather_points (t = 1) and three_interpolate (t = 3) on the reference's channel-major layout with
+ * CALLER-provided scratch (pn2x_scatter_cm_scratch_ints int32 elements): same results as pn2_group_points_grad /
+ * pn2_gather_points_grad / pn2_three_interpolate_grad (accumulates into grad_points), but nothing is allocated inside, so
+ * the call can be captured into a HIP graph.  (The reference-signature entries use a library-owned per-stream scratch and
+ * fall back to their LDS-atomic kernels when that scratch would have to grow during a capture.)
+ *   grad_out (b, c, m_src); idx (b, m_src) [t = 1] or (b, m_src, 3) with weight (b, m_src, 3) [t = 3]; grad_points (b, c, n_dst).
+ * PN2_ERANGE: shape not covered (n_dst > 16127 or lists longer than 64 KiB of LDS) -- use the pn2_* entry.
+ */
+long pn2x_scatter_cm_scratch_ints(int t, int b, int n_dst, int m_src);
+int pn2x_scatter_cm(int t, int b, int c, int n_dst, int m_src, const float *grad_out, const int *idx, const float *weight,
+                    float *grad_points, int *scratch, long scratch_ints, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

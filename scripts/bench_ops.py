@@ -24,6 +24,30 @@ def timeit(fn, iters=50, warm=5):
     return s.elapsed_time(e) / iters * 1e3  # us
 
 
+def timeit_graph(fn, reps=10, iters=20):
+    """GPU time per call with the host out of the loop: `reps` calls captured into one HIP graph, replayed `iters` times."""
+    fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / (iters * reps) * 1e3  # us
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, default=64)
@@ -71,27 +95,33 @@ def main():
         b = B if N <= 1024 else max(1, B // 8)
         f = torch.randn(b, C, N, device="cuda", generator=g)
         idx = torch.randint(0, N, (b, P, S), device="cuda", dtype=torch.int32, generator=g)
-        us = timeit(lambda: ops.grouping_operation(f, idx))
+        us = timeit_graph(lambda: ops.grouping_operation(f, idx))
         nb = b * (4 * P * S + 4 * C * min(N, P * S) + 4 * C * P * S)
         rec("group_fwd", us, nb, B=b, C=C, N=N, P=P, S=S)
         go = torch.randn(b, C, P, S, device="cuda", generator=g)
         f2 = f.clone().requires_grad_(True)
         out = ops.grouping_operation(f2, idx)
         us = timeit(lambda: torch.autograd.grad(out, f2, go, retain_graph=True))
-        rec("group_bwd", us, nb, B=b, C=C, N=N, P=P, S=S)
+        gp = torch.zeros_like(f)
+        from hotrack_amd import pointnet2_hip as native
+        us_k = timeit_graph(lambda: native.group_points_grad_wrapper(b, C, N, P, S, go, idx, gp))  # kernel only (accumulates)
+        rec("group_bwd", us_k, nb, B=b, C=C, N=N, P=P, S=S, us_autograd=round(us, 2))
 
     for C, M, n in [(256, 128, 256), (128, 256, 1024)]:
         f = torch.randn(B, C, M, device="cuda", generator=g)
         idx = torch.randint(0, M, (B, n, 3), device="cuda", dtype=torch.int32, generator=g)
         w = torch.rand(B, n, 3, device="cuda", generator=g)
-        us = timeit(lambda: ops.three_interpolate(f, idx, w))
+        us = timeit_graph(lambda: ops.three_interpolate(f, idx, w))
         nb = B * (4 * C * M + 24 * n + 4 * C * n)
         rec("interp_fwd", us, nb, B=B, C=C, M=M, n=n)
         f2 = f.clone().requires_grad_(True)
         out = ops.three_interpolate(f2, idx, w)
         go = torch.randn_like(out)
         us = timeit(lambda: torch.autograd.grad(out, f2, go, retain_graph=True))
-        rec("interp_bwd", us, nb, B=B, C=C, M=M, n=n)
+        gp = torch.zeros_like(f)
+        from hotrack_amd import pointnet2_hip as native
+        us_k = timeit_graph(lambda: native.three_interpolate_grad_wrapper(B, C, n, M, go, idx, w, gp))  # kernel only (accumulates)
+        rec("interp_bwd", us_k, nb, B=B, C=C, M=M, n=n, us_autograd=round(us, 2))
 
     if a.out:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
