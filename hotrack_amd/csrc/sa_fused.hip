@@ -24,6 +24,17 @@
 #define SA_PAD 4  /* LDS row padding in floats (row stride C + SA_PAD); must keep rows 16-byte aligned */
 #endif
 
+// keeps the prefetching ds_reads of the MFMA loops where they are written (the scheduler otherwise sinks them back to
+// their use); -DSA_PREFETCH=0 restores the round-1 order for A/B measurements
+#ifndef SA_PREFETCH
+#define SA_PREFETCH 1
+#endif
+#if SA_PREFETCH
+#define SA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SA_SCHED_FENCE() ((void)0)
+#endif
+
 namespace pn2 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -296,11 +307,21 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
 #pragma unroll
                     for (int ct = 0; ct < NT2; ++ct) acc[rt][ct] = (f32x4){bias2[ct], bias2[ct], bias2[ct], bias2[ct]};
                 const float *arow = H1 + (wp * 64 + r0 * 16 + li) * LD1 + 4 * g;
+                // A fragments are fetched ONE k-step ahead: with the ds_reads issued right before their use the matrix
+                // pipe idled an LDS round trip per k-step (the only other wave of this SIMD is a LOAD wave: nothing fills it)
+                float4 an[RTC];
+#pragma unroll
+                for (int rt = 0; rt < RTC; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1);
 #pragma unroll
                 for (int tq = 0; tq < C1 / 16; ++tq) {
                     float4 a[RTC];
 #pragma unroll
-                    for (int rt = 0; rt < RTC; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1 + 16 * tq);
+                    for (int rt = 0; rt < RTC; ++rt) a[rt] = an[rt];
+                    if (tq + 1 < C1 / 16) {
+#pragma unroll
+                        for (int rt = 0; rt < RTC; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1 + 16 * (tq + 1));
+                        SA_SCHED_FENCE();
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -337,11 +358,19 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
 #pragma unroll
                     for (int ct = 0; ct < NT3; ++ct) acc[rt][ct] = (f32x4){bias3[ct], bias3[ct], bias3[ct], bias3[ct]};
                 const float *arow = H2 + (wp * 64 + r0 * 16 + li) * LD2 + 4 * g;
+                float4 an[RTC];
+#pragma unroll
+                for (int rt = 0; rt < RTC; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD2);
 #pragma unroll
                 for (int tq = 0; tq < C2 / 16; ++tq) {
                     float4 a[RTC];
 #pragma unroll
-                    for (int rt = 0; rt < RTC; ++rt) a[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD2 + 16 * tq);
+                    for (int rt = 0; rt < RTC; ++rt) a[rt] = an[rt];
+                    if (tq + 1 < C2 / 16) {
+#pragma unroll
+                        for (int rt = 0; rt < RTC; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD2 + 16 * (tq + 1));
+                        SA_SCHED_FENCE();
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll

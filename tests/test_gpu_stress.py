@@ -66,7 +66,7 @@ def test_group_and_fused_sa_full_size(data):
     (ops.grouping_operation(f2, idx) * gsel).sum().backward()
     lhs = float((grouped.double() * gsel.double()).sum())
     rhs = float((feat.double() * f2.grad.double()).sum())
-    assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
+    assert abs(lhs - rhs) < 5e-6 * max(1.0, abs(lhs))  # 5.4e8 fp32 products on each side, ~1000 adds per gradient element
     # fused SA scale [C+3 -> 64 -> 64 -> 128] vs unfused torch on the materialised group
     g = torch.Generator(device="cuda").manual_seed(1)
     W1 = torch.randn(64, C + 3, device="cuda", generator=g) * 0.2
