@@ -178,22 +178,30 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
             for (int r = 0; r < RPT; r += RPC) D.cs[r] = load_xyz(cb_ + (unsigned)(I.ss[r] * 3));
         }
     };
+    // The LOAD role shares its SIMD's issue port with a COMPUTE wave: every VALU instruction here can delay an MFMA issue by a
+    // slot (layer 2 ran at 36 cycles per MFMA against 32.3 in layer 3, when the loaders mostly wait on memory).  So the
+    // layer-1 arithmetic is written with the packed fp32 ops (v_pk_add / v_pk_fma / v_pk_max: two channels per instruction)
+    // and explicit FMAs: about half the VALU instructions per row.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto finish = [&](const HalfRows &D, float *__restrict__ H1, int h) {
+        const f32x2 w0x = {wxr[0][0], wxr[1][0]}, w0y = {wxr[0][1], wxr[1][1]}, w0z = {wxr[0][2], wxr[1][2]};
+        const f32x2 w1x = {wxr[2][0], wxr[3][0]}, w1y = {wxr[2][1], wxr[3][1]}, w1z = {wxr[2][2], wxr[3][2]};
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            float4 v = b1r;
-            if (has_a1f) { v.x += D.a[r].x; v.y += D.a[r].y; v.z += D.a[r].z; v.w += D.a[r].w; }
-            if (has_cadd) { const float4 c = D.c[r - r % RPC]; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+            f32x2 v0 = {b1r.x, b1r.y}, v1 = {b1r.z, b1r.w};
+            if (has_a1f) { v0 += (f32x2){D.a[r].x, D.a[r].y}; v1 += (f32x2){D.a[r].z, D.a[r].w}; }
+            if (has_cadd) { const float4 c = D.c[r - r % RPC]; v0 += (f32x2){c.x, c.y}; v1 += (f32x2){c.z, c.w}; }
             if (has_xyz) {
                 const f32x3 cs = D.cs[r - r % RPC];
                 const float dx = D.pj[r].x - cs.x, dy = D.pj[r].y - cs.y, dz = D.pj[r].z - cs.z;
-                v.x += wxr[0][0] * dx + wxr[0][1] * dy + wxr[0][2] * dz;
-                v.y += wxr[1][0] * dx + wxr[1][1] * dy + wxr[1][2] * dz;
-                v.z += wxr[2][0] * dx + wxr[2][1] * dy + wxr[2][2] * dz;
-                v.w += wxr[3][0] * dx + wxr[3][1] * dy + wxr[3][2] * dz;
+                const f32x2 dx2 = {dx, dx}, dy2 = {dy, dy}, dz2 = {dz, dz};
+                v0 = __builtin_elementwise_fma(w0x, dx2, __builtin_elementwise_fma(w0y, dy2, __builtin_elementwise_fma(w0z, dz2, v0)));
+                v1 = __builtin_elementwise_fma(w1x, dx2, __builtin_elementwise_fma(w1y, dy2, __builtin_elementwise_fma(w1z, dz2, v1)));
             }
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r * STR) * LD1 + 4 * c4) = v;
+            const f32x2 z = {0.f, 0.f};
+            v0 = __builtin_elementwise_max(v0, z);
+            v1 = __builtin_elementwise_max(v1, z);
+            *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r * STR) * LD1 + 4 * c4) = make_float4(v0.x, v0.y, v1.x, v1.y);
         }
     };
     auto gather = [&](int tile, float *__restrict__ H1, int h) {  // unpipelined: prologue only
