@@ -245,7 +245,7 @@ knn_wave_kernel(int n, int m, int k, const float *__restrict__ unknown_all, cons
 // private memory (k <= 200).  Correct for any m; not tuned.
 __global__ void __launch_bounds__(64)
 knn_thread_kernel(int n, int m, int k, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
-                  float *__restrict__ dist2_all, int *__restrict__ idx_all) {
+                  float *__restrict__ dist2_all, int *__restrict__ idx_all, int k2, int *__restrict__ idx2_all) {
     const int b = blockIdx.y;
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= n) return;
@@ -263,15 +263,21 @@ knn_thread_kernel(int n, int m, int k, const float *__restrict__ unknown_all, co
         best[j] = d;
         besti[j] = i;
     }
-    float *od = dist2_all + ((size_t)b * n + q) * k;
     int *oi = idx_all + ((size_t)b * n + q) * k;
-    for (int i = 0; i < k; ++i) { od[i] = best[i]; oi[i] = besti[i]; }
+    for (int i = 0; i < k; ++i) oi[i] = besti[i];
+    if (dist2_all) {  // index-only callers (pn2x_knn_indices) pass no distance buffer
+        float *od = dist2_all + ((size_t)b * n + q) * k;
+        for (int i = 0; i < k; ++i) od[i] = best[i];
+    }
+    if (idx2_all) {   // the first k2 entries again, contiguous (the smaller neighbourhood of a multi-scale module)
+        int *o2 = idx2_all + ((size_t)b * n + q) * k2;
+        for (int i = 0; i < k2; ++i) o2[i] = besti[i];
+    }
 }
 
 int knn_dispatch(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2,
                  int *idx, hipStream_t st, int k2, int *idx2) {
     if (b == 0 || n == 0) return PN2_OK;
-    if ((!dist2 || idx2) && m > 64 * 32) return PN2_ERANGE;  // the index-only / prefix variants cover the wave kernel
     dim3 grid((n + 3) / 4, b);
 #define PN2_KNN_CASE(PP)                                                                                    \
     if (m <= 64 * PP) {                                                                                     \
@@ -281,7 +287,7 @@ int knn_dispatch(int b, int n, int m, int k, const float *unknown, const float *
     PN2_KNN_CASE(1) PN2_KNN_CASE(2) PN2_KNN_CASE(4) PN2_KNN_CASE(8) PN2_KNN_CASE(16) PN2_KNN_CASE(32)
 #undef PN2_KNN_CASE
     dim3 grid2((n + 63) / 64, b);
-    hipLaunchKernelGGL(knn_thread_kernel, grid2, dim3(64), 0, st, n, m, k, unknown, known, dist2, idx);
+    hipLaunchKernelGGL(knn_thread_kernel, grid2, dim3(64), 0, st, n, m, k, unknown, known, dist2, idx, k2, idx2);
     return check_launch();
 }
 

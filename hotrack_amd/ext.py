@@ -317,10 +317,6 @@ def knn_indices(k: int, unknown: torch.Tensor, known: torch.Tensor, k2: int = 0)
     every list as a second contiguous (B,n,k2) tensor (returns a pair)."""
     B, n, _ = unknown.shape
     m = known.shape[1]
-    if m > 2048:  # beyond the wave kernel: the operator API
-        from . import pointnet2_utils as ops
-        idx = ops.knn(k, unknown, known)[1]
-        return (idx, idx[:, :, :k2].contiguous()) if k2 else idx
     pu, pk = _native._ptr(unknown, "unknown", torch.float32, B * n * 3), _native._ptr(known, "known", torch.float32, B * m * 3)
     idx = torch.empty((B, n, k), dtype=torch.int32, device=unknown.device)
     idx2 = torch.empty((B, n, k2), dtype=torch.int32, device=unknown.device) if k2 else None

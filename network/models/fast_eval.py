@@ -32,7 +32,7 @@ def _lin_relu(x2d: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tens
 
 
 class FastEval:
-    MAX_POINTS = 2048  # the index-only kNN (one search for both neighbourhood sizes) covers clouds up to 64 x 32 points
+    MAX_POINTS = 16384  # the register-resident FPS with the prefix shortcut covers clouds up to 1024 x 16 points
 
     def __init__(self, net):
         self.net = net

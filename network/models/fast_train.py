@@ -123,7 +123,7 @@ class FastTrain:
         # ---- q1 -> r1 -> q2 -> r2 around the J keypoints; one kNN search for both neighbourhood sizes ------------------
         Ks = list(net.q1.nsample_list)
         kmax = max(Ks)
-        if N <= 2048 and len(set(Ks)) == 2 and len(Ks) == 2:
+        if len(set(Ks)) == 2 and len(Ks) == 2:
             gi, gi_small = ext.knn_indices(kmax, kp, xyz, k2=min(Ks))
             idxs = [gi if K == kmax else gi_small for K in Ks]
         else:

@@ -253,7 +253,7 @@ def test_tail_kernels_match_torch():
     assert torch.equal(ext.knn_indices(64, q, xyz), ops.knn(64, q, xyz)[1])
 
 
-@pytest.mark.parametrize("B,N,dup", [(33, 1024, False), (3, 512, False), (2, 2048, False), (2, 1024, True)])
+@pytest.mark.parametrize("B,N,dup", [(33, 1024, False), (3, 512, False), (2, 2048, False), (2, 1024, True), (2, 4096, False), (1, 6000, False)])
 def test_fast_path_other_shapes_match_module_path(B, N, dup):
     """Fast path vs module path beyond the default shape: the gathered-row layer-1 branch (B*N >= 32768), other point
     counts, and clouds with duplicated points (tied FPS arg-maxima -> the second sampling level really runs)."""

@@ -271,7 +271,8 @@ def test_ball_query_picks_matches_gather_then_query():
 def test_knn_indices_prefix_output():
     from hotrack_amd import ext, pointnet2_utils as ops
     g = torch.Generator().manual_seed(21)
-    for B, n, m, k, k2 in ((4, 21, 1024, 64, 16), (2, 21, 512, 64, 16), (3, 5, 100, 7, 7), (1, 1, 64, 64, 1), (2, 30, 2048, 200, 4)):
+    for B, n, m, k, k2 in ((4, 21, 1024, 64, 16), (2, 21, 512, 64, 16), (3, 5, 100, 7, 7), (1, 1, 64, 64, 1), (2, 30, 2048, 200, 4),
+                           (2, 21, 5000, 64, 16), (1, 7, 2049, 3, 2)):  # m > 2048: the general kernel behind the same index-only entry
         q, x = torch.rand(B, n, 3, generator=g).cuda(), torch.rand(B, m, 3, generator=g).cuda()
         ref = ops.knn(k, q, x)[1]
         idx, small = ext.knn_indices(k, q, x, k2=k2)
