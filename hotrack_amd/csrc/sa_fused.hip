@@ -529,6 +529,9 @@ static int launch_sa(int b, const SaArgs &a, hipStream_t st) {
     return PN2_ERANGE;
 }
 
+#ifndef SA_RTC128
+#define SA_RTC128 2  /* row tiles live at once in the 128-128-192 instance; 4 = one pass per layer, but spills (measured: see profiles) */
+#endif
 #ifndef SA_NB1
 #define SA_NB1 2  /* H1 ring depth; 3 measured no better (profiles/r01_misc_measurements.md) */
 #endif
@@ -559,7 +562,7 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
     hipStream_t st = (hipStream_t)stream;
     if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2, 4, 4, SA_NB1>(b, a, st);
     if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sa<64, 64, 128, 4, 2, 4, SA_NB1>(b, a, st);
-    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4, 2, 2, SA_NB1>(b, a, st);
+    if (c1 == 128 && c2 == 128 && c3 == 192) return launch_sa<128, 128, 192, 4, SA_RTC128, 2, SA_NB1>(b, a, st);
     return PN2_ERANGE;
 }
 
@@ -597,8 +600,8 @@ extern "C" int pn2x_sa_mlp_max_pair(int b, int c1, int c2, int c3, const pn2x_sa
     const bool fa = a0.a1f && a1.a1f, fx = a0.xyz && a1.xyz, fc0 = a0.cadd != nullptr, fc1 = a1.cadd != nullptr;
     if (!fa || !fx || fc0 != fc1 || (a0.a1f == nullptr) != (a1.a1f == nullptr)) return PN2_ERANGE;  // both scales: a1f + xyz (+ cadd)
     hipStream_t st = (hipStream_t)stream;
-    if (fc0) return launch_sa_pair<128, 128, 192, 4, 2, 2, SA_NB1, 16, 64, 2>(b, a0, a1, st);
-    return launch_sa_pair<128, 128, 192, 4, 2, 2, SA_NB1, 16, 64, 1>(b, a0, a1, st);
+    if (fc0) return launch_sa_pair<128, 128, 192, 4, SA_RTC128, 2, SA_NB1, 16, 64, 2>(b, a0, a1, st);
+    return launch_sa_pair<128, 128, 192, 4, SA_RTC128, 2, SA_NB1, 16, 64, 1>(b, a0, a1, st);
 }
 
 extern "C" int pn2x_sa_mlp_max_supported(int k, int c1, int c2, int c3) {
