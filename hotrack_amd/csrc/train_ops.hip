@@ -144,6 +144,60 @@ bn_relu_apply_kernel(long rows, int C, const float *__restrict__ Y, int ldy, con
     }
 }
 
+// gradient of  out[g, c] = max_k h[g*K + k, c]  seen from row r = g*K + k: dout[g, c] where k is the recorded arg-max, else 0
+__device__ __forceinline__ float4 max_grad(const float *__restrict__ dOut, int ldd, const int *__restrict__ arg, int C, int K, long r, int q) {
+    const long grp = r / K;
+    const int k = (int)(r - grp * K);
+    const float4 d = *reinterpret_cast<const float4 *>(dOut + grp * ldd + 4 * q);
+    const int4 a = *reinterpret_cast<const int4 *>(arg + grp * C + 4 * q);
+    return make_float4(a.x == k ? d.x : 0.f, a.y == k ? d.y : 0.f, a.z == k ? d.z : 0.f, a.w == k ? d.w : 0.f);
+}
+
+// relu(BatchNorm(y)) followed by the max over the K rows of every group (the neighbourhood reduction of a set-abstraction
+// scale, pointnet_utils.py:403,581): the (rows x C) activations are never written; arg records the first arg-max row.
+__global__ void __launch_bounds__(kTT)
+bn_relu_max_kernel(long groups, int K, int C, const float *__restrict__ Y, int ldy, const double *__restrict__ sums,
+                   const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ conv_bias, float eps,
+                   float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
+                   float *__restrict__ save_mean, float *__restrict__ save_invstd, float *__restrict__ out, int *__restrict__ arg) {
+    const int Q = C >> 2;
+    const long item = (long)blockIdx.x * kTT + threadIdx.x;
+    const long rows = groups * K;
+    const int q = (int)(item % Q);
+    BnCh k;
+    double var[4];
+    bn_consts(k, C, 4 * q, rows, sums, eps, gamma, beta, var);
+    if (item < Q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q + i;
+            save_mean[c] = k.mean[i];
+            save_invstd[c] = k.invstd[i];
+            if (running_mean) {
+                const float bm = k.mean[i] + (conv_bias ? conv_bias[c] : 0.f);
+                const float bv = (float)(rows > 1 ? var[i] * ((double)rows / (double)(rows - 1)) : var[i]);
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * bm;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * bv;
+            }
+        }
+        if (q == 0 && nbt) *nbt += 1;
+    }
+    const long grp = item / Q;
+    if (grp >= groups) return;
+    const float *__restrict__ y = Y + grp * K * ldy + 4 * q;
+    float m[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    int am[4] = {0, 0, 0, 0};
+    for (int kk = 0; kk < K; ++kk) {
+        const float4 v = *reinterpret_cast<const float4 *>(y + (long)kk * ldy);
+        const float h[4] = {bn_act(v.x, k, 0), bn_act(v.y, k, 1), bn_act(v.z, k, 2), bn_act(v.w, k, 3)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (h[i] > m[i]) { m[i] = h[i]; am[i] = kk; }
+    }
+    *reinterpret_cast<float4 *>(out + grp * C + 4 * q) = make_float4(fmaxf(m[0], 0.f), fmaxf(m[1], 0.f), fmaxf(m[2], 0.f), fmaxf(m[3], 0.f));
+    *reinterpret_cast<int4 *>(arg + grp * C + 4 * q) = make_int4(am[0], am[1], am[2], am[3]);
+}
+
 struct BnSaved {
     float mean[4], invstd[4], g[4], b[4];
 };
@@ -159,7 +213,8 @@ __device__ __forceinline__ void load_saved(BnCh &k, int c0, const float *__restr
 __global__ void __launch_bounds__(kTT)
 bn_relu_bwd_reduce_kernel(long rows, int C, const float *__restrict__ dH, int ldd, const float *__restrict__ Y, int ldy,
                           const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
-                          const float *__restrict__ beta, int rows_per_block, int relu, double *__restrict__ sums) {
+                          const float *__restrict__ beta, int rows_per_block, int relu, double *__restrict__ sums,
+                          const int *__restrict__ arg, int K) {
     const int Q = C >> 2, rpp = kTT / Q;
     const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
     const long r0 = (long)blockIdx.x * rows_per_block;
@@ -182,6 +237,10 @@ bn_relu_bwd_reduce_kernel(long rows, int C, const float *__restrict__ dH, int ld
             t.w += g.w * ((y.w - k.mean[3]) * k.invstd[3]);
         };
         long r = r0 + rr;
+        if (arg) {  // dH is d(max over K) (rows / K groups): only the arg-max row of a group receives it
+            for (; r < r1; r += rpp)
+                acc(*reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q), max_grad(dH, ldd, arg, C, K, r, q));
+        }
         for (; r + 3L * rpp < r1; r += 4L * rpp) {  // eight independent 16-byte loads in flight per thread
             const float *py = Y + r * ldy + 4 * q, *pg = dH + r * ldd + 4 * q;
             const float4 y0 = *reinterpret_cast<const float4 *>(py), g0 = *reinterpret_cast<const float4 *>(pg);
@@ -200,7 +259,8 @@ __global__ void __launch_bounds__(kTT)
 bn_relu_bwd_apply_kernel(long rows, int C, const float *__restrict__ dH, int ldd, const float *__restrict__ Y, int ldy,
                          const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
                          const float *__restrict__ beta, const double *__restrict__ sums, int rows_per_block, int relu,
-                         float *__restrict__ dY, int ldo, float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dbias) {
+                         float *__restrict__ dY, int ldo, float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dbias,
+                         const int *__restrict__ arg, int K) {
     const int Q = C >> 2, rpp = kTT / Q;
     const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
     if (rr >= rpp) return;
@@ -231,7 +291,7 @@ bn_relu_bwd_apply_kernel(long rows, int C, const float *__restrict__ dH, int ldd
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     for (long r = r0 + rr; r < r1; r += rpp) {
         const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
-        float4 g = *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q);
+        float4 g = arg ? max_grad(dH, ldd, arg, C, K, r, q) : *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q);
         const float yy[4] = {y.x, y.y, y.z, y.w};
         float gg[4] = {g.x, g.y, g.z, g.w}, o[4];
 #pragma unroll
@@ -492,9 +552,41 @@ extern "C" int pn2x_bn_relu_bwd(long rows, int c, const float *dh, int ldd, cons
     const int rpb = rows_per_block_for(rows, c);
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, grid, dim3(kTT), 0, (hipStream_t)stream, rows, c, dh, ldd, y, ldy, mean, invstd, gamma,
-                       beta, rpb, relu, sums);
+                       beta, rpb, relu, sums, (const int *)nullptr, 1);
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, grid, dim3(kTT), 0, (hipStream_t)stream, rows, c, dh, ldd, y, ldy, mean, invstd, gamma,
-                       beta, sums, rpb, relu, dy, ldo, dgamma, dbeta, dbias);
+                       beta, sums, rpb, relu, dy, ldo, dgamma, dbeta, dbias, (const int *)nullptr, 1);
+    return check_launch();
+}
+
+extern "C" int pn2x_bn_relu_max(long groups, int k, int c, const float *y, int ldy, const double *sums, const float *gamma,
+                                const float *beta, const float *conv_bias, float eps, float momentum, float *running_mean,
+                                float *running_var, long long *num_batches_tracked, float *save_mean, float *save_invstd, float *out,
+                                int *arg, void *stream) {
+    using namespace pn2;
+    if (groups < 1 || k < 1 || bad_c(c) || ldy < c || ldy % 4) return PN2_EINVAL;
+    if (!y || !sums || !gamma || !beta || !save_mean || !save_invstd || !out || !arg) return PN2_ENULL;
+    if (((uintptr_t)y | (uintptr_t)out | (uintptr_t)arg) % 16) return PN2_EINVAL;
+    const long items = groups * (c / 4);
+    hipLaunchKernelGGL(bn_relu_max_kernel, dim3((unsigned)((items + kTT - 1) / kTT)), dim3(kTT), 0, (hipStream_t)stream, groups, k, c, y, ldy,
+                       sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd,
+                       out, arg);
+    return check_launch();
+}
+
+extern "C" int pn2x_bn_relu_max_bwd(long groups, int k, int c, const float *dout, const int *arg, const float *y, int ldy,
+                                    const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums, float *dy,
+                                    int ldo, float *dgamma, float *dbeta, float *dbias, void *stream) {
+    using namespace pn2;
+    if (groups < 1 || k < 1 || bad_c(c) || ldy < c || ldy % 4 || ldo < c || ldo % 4) return PN2_EINVAL;
+    if (!dout || !arg || !y || !mean || !invstd || !gamma || !beta || !sums || !dy || !dgamma || !dbeta) return PN2_ENULL;
+    if (((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy | (uintptr_t)arg) % 16) return PN2_EINVAL;
+    const long rows = groups * k;
+    const int rpb = rows_per_block_for(rows, c);
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, grid, dim3(kTT), 0, (hipStream_t)stream, rows, c, dout, c, y, ldy, mean, invstd, gamma, beta,
+                       rpb, 1, sums, arg, k);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, grid, dim3(kTT), 0, (hipStream_t)stream, rows, c, dout, c, y, ldy, mean, invstd, gamma, beta,
+                       sums, rpb, 1, dy, ldo, dgamma, dbeta, dbias, arg, k);
     return check_launch();
 }
 

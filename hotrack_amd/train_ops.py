@@ -35,6 +35,10 @@ _lib.pn2x_inverse_index.restype = _ci
 _lib.pn2x_rows_segment_sum.argtypes = [_ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _vp]
 _lib.pn2x_rows_segment_sum.restype = _ci
 INVERSE_MAX_ROWS = 16127  # pn2x_inverse_index keeps n_dst + 1 + 256 counters in 64 KiB of LDS
+_lib.pn2x_bn_relu_max.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_bn_relu_max.restype = _ci
+_lib.pn2x_bn_relu_max_bwd.argtypes = [_cl, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
+_lib.pn2x_bn_relu_max_bwd.restype = _ci
 _lib.pn2x_bn_sums_doubles.argtypes = [_ci]
 _lib.pn2x_bn_sums_doubles.restype = _ci
 _f32 = torch.float32
@@ -112,6 +116,54 @@ def bn_relu(y: torch.Tensor, bn: torch.nn.Module, ws: Workspace, conv_bias: torc
     return _BnRelu.apply(y, bn.weight, bn.bias, conv_bias, bn.running_mean if track else None, bn.running_var if track else None,
                          bn.num_batches_tracked if track else None, bn.eps, bn.momentum if bn.momentum is not None else 0.1, relu,
                          ws.take(_lib.pn2x_bn_sums_doubles(C)), ws.take(_lib.pn2x_bn_sums_doubles(C)))
+
+
+class _BnReluMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, K, gamma, beta, conv_bias, running_mean, running_var, nbt, eps, momentum, ws_f, ws_b):
+        py, ldy = _rows2d(y, "y")
+        R, C = y.shape
+        G = R // K
+        out = torch.empty((G, C), dtype=_f32, device=y.device)
+        arg = torch.empty((G, C), dtype=torch.int32, device=y.device)
+        saved = torch.empty((2, C), dtype=_f32, device=y.device)
+        st = _native._stream(y)
+        with torch.cuda.device(y.device):
+            _native._check(_lib.pn2x_bn_stats(R, C, py, ldy, ws_f.data_ptr(), st), "bn_stats")
+            _native._check(_lib.pn2x_bn_relu_max(G, K, C, py, ldy, ws_f.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(conv_bias), float(eps),
+                                                 float(momentum), _p(running_mean), _p(running_var), _p(nbt), saved[0].data_ptr(),
+                                                 saved[1].data_ptr(), out.data_ptr(), arg.data_ptr(), st), "bn_relu_max")
+        ctx.save_for_backward(y, gamma, beta, saved, arg)
+        ctx.ws_b, ctx.K, ctx.has_bias = ws_b, K, conv_bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, beta, saved, arg = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, C = y.shape
+        dy = torch.empty((R, C), dtype=_f32, device=y.device)
+        dpar = torch.empty((3, C), dtype=_f32, device=y.device)
+        with torch.cuda.device(y.device):
+            _native._check(_lib.pn2x_bn_relu_max_bwd(R // ctx.K, ctx.K, C, dout.data_ptr(), arg.data_ptr(), y.data_ptr(), y.stride(0),
+                                                     saved[0].data_ptr(), saved[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                     ctx.ws_b.data_ptr(), dy.data_ptr(), C, dpar[0].data_ptr(), dpar[1].data_ptr(),
+                                                     dpar[2].data_ptr(), _native._stream(y)), "bn_relu_max_bwd")
+        return dy, None, dpar[0], dpar[1], (dpar[2] if ctx.has_bias else None), None, None, None, None, None, None, None
+
+
+def bn_relu_max(y: torch.Tensor, K: int, bn: torch.nn.Module, ws: Workspace, conv_bias: torch.Tensor = None) -> torch.Tensor:
+    """max over each group of K consecutive rows of relu(BatchNorm_train(y + conv_bias)): y (G*K, C) -> (G, C).  The last layer
+    of a set-abstraction scale + its neighbourhood reduction without writing the (G*K, C) activations; same statistics /
+    running-statistics semantics as bn_relu."""
+    R, C = y.shape
+    if R % K:
+        raise ValueError("bn_relu_max: rows must be a multiple of K")
+    track = bn.track_running_stats and bn.running_mean is not None
+    n = _lib.pn2x_bn_sums_doubles(C)
+    return _BnReluMax.apply(y, K, bn.weight, bn.bias, conv_bias, bn.running_mean if track else None, bn.running_var if track else None,
+                            bn.num_batches_tracked if track else None, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                            ws.take(n), ws.take(n))
 
 
 def inverse_index(idx: torch.Tensor, n_dst: int):

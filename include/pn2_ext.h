@@ -277,6 +277,21 @@ long pn2x_scatter_cm_scratch_ints(int t, int b, int n_dst, int m_src);
 int pn2x_scatter_cm(int t, int b, int c, int n_dst, int m_src, const float *grad_out, const int *idx, const float *weight,
                     float *grad_points, int *scratch, long scratch_ints, void *stream);
 
+/*
+ * relu(BatchNorm_train(y)) followed by the max over the k rows of every group (the neighbourhood reduction that ends a
+ * set-abstraction scale, reference pointnet_utils.py:403,581), without writing the (groups*k, c) activations:
+ *   out (groups, c) = max_k relu(bn(y[g*k + kk, :]));  arg (groups, c) int32 = the first arg-max row kk.
+ * Statistics / running-statistics semantics as pn2x_bn_relu_apply (sums from pn2x_bn_stats over all groups*k rows).
+ * pn2x_bn_relu_max_bwd: backward through max + ReLU + BatchNorm given dout (groups, c): only the arg-max row of a group
+ * receives dout (times the ReLU mask); dy (groups*k, ldo), dgamma, dbeta, dbias as pn2x_bn_relu_bwd.
+ */
+int pn2x_bn_relu_max(long groups, int k, int c, const float *y, int ldy, const double *sums, const float *gamma, const float *beta,
+                     const float *conv_bias, float eps, float momentum, float *running_mean, float *running_var,
+                     long long *num_batches_tracked, float *save_mean, float *save_invstd, float *out, int *arg, void *stream);
+int pn2x_bn_relu_max_bwd(long groups, int k, int c, const float *dout, const int *arg, const float *y, int ldy, const float *mean,
+                         const float *invstd, const float *gamma, const float *beta, double *sums, float *dy, int ldo, float *dgamma,
+                         float *dbeta, float *dbias, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

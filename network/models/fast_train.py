@@ -43,11 +43,14 @@ class FastTrain:
         return all(w % 4 == 0 and w <= 1024 for w in widths)
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _stack(self, x2d, convs, bns, first_done=False):
-        from hotrack_amd.train_ops import bn_relu
+    def _stack(self, x2d, convs, bns, first_done=False, max_over=0):
+        """[1x1 conv + train-mode BatchNorm + ReLU]*; max_over = K > 0: the last layer also takes the max over every K
+        consecutive rows (its full-size activations are then never written)."""
+        from hotrack_amd.train_ops import bn_relu, bn_relu_max
+        last = len(convs) - 1
         for i, (conv, bn) in enumerate(zip(convs, bns)):
             y = x2d if (first_done and i == 0) else F.linear(x2d, _w2d(conv))
-            x2d = bn_relu(y, bn, self.ws, conv.bias)
+            x2d = bn_relu_max(y, max_over, bn, self.ws, conv.bias) if (max_over and i == last) else bn_relu(y, bn, self.ws, conv.bias)
         return x2d
 
     def _sa_scales(self, mod, xyz, cxyz, feat2d, idxs, center2d=None):
@@ -69,8 +72,8 @@ class FastTrain:
         outs = []
         for i, y1 in enumerate(y1s):
             K = idxs[i].shape[2]
-            h = self._stack(y1.view(B * S * K, -1), mod.conv_blocks[i], mod.bn_blocks[i], first_done=True)
-            outs.append(h.view(B * S, K, -1).max(dim=1)[0].view(B, S, -1))
+            h = self._stack(y1.view(B * S * K, -1), mod.conv_blocks[i], mod.bn_blocks[i], first_done=True, max_over=K)
+            outs.append(h.view(B, S, -1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
 
     def _fp(self, mod, xyz1, xyz2, points1, points2):
@@ -112,7 +115,7 @@ class FastTrain:
         idx2 = ops.ball_query(bh.sa2.radius_list[0], bh.sa2.nsample_list[0], l1_xyz, l2_xyz)
         l2_feat = self._sa_scales(bh.sa2, l1_xyz, l2_xyz, l1_feat.reshape(B * S1, -1), [idx2])        # (B,S2,128)
         x = torch.cat([l2_xyz, l2_feat], dim=2).view(B * S2, -1)   # group-all: [xyz | feat], centre = origin (not subtracted)
-        l3 = self._stack(x, bh.sa3.mlp_convs, bh.sa3.mlp_bns).view(B, S2, -1).max(dim=1, keepdim=True)[0]   # (B,1,512)
+        l3 = self._stack(x, bh.sa3.mlp_convs, bh.sa3.mlp_bns, max_over=S2).view(B, 1, -1)                    # (B,1,512)
         l2_out = self._fp(bh.fp3, l2_xyz, l2_xyz[:, :1], l2_feat, l3).view(B, S2, -1)
         l1_out = self._fp(bh.fp2, l1_xyz, l2_xyz, l1_feat, l2_out).view(B, S1, -1)
         l0_out = self._fp(bh.fp1, xyz, l1_xyz, xyz, l1_out)                                             # (B*N, 128), skip = xyz

@@ -210,3 +210,32 @@ def test_fast_train_path_equals_module_path():
             assert int(ba[k]) == int(bb[k]), k
         elif k.endswith("running_mean") or k.endswith("running_var"):
             torch.testing.assert_close(bb[k], ba[k], rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("G,K,C", [(300, 32, 64), (21 * 5, 16, 192), (64, 128, 512), (7, 3, 4)])
+def test_bn_relu_max_matches_unfused(G, K, C):
+    """Fused BatchNorm + ReLU + max over K rows (forward, arg-max routing of the gradient, running statistics) vs
+    bn_relu followed by torch.max."""
+    from hotrack_amd.train_ops import Workspace, bn_relu, bn_relu_max
+    g = torch.Generator(device="cuda").manual_seed(G + K)
+    y0 = torch.randn(G * K, C, device="cuda", generator=g) * 1.5 - 0.2
+    go = torch.randn(G, C, device="cuda", generator=g)
+    bias = torch.randn(C, device="cuda", generator=g)
+    res = []
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm1d(C).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.3 * torch.randn(C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)))
+            bn.bias.copy_(0.2 * torch.randn(C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)))
+        ws = Workspace("cuda")
+        y = y0.clone().requires_grad_(True)
+        b = bias.clone().requires_grad_(True)
+        out = bn_relu_max(y, K, bn, ws, b) if fused else bn_relu(y, bn, ws, b).view(G, K, C).max(dim=1)[0]
+        out.backward(go)
+        res.append((out.detach(), y.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+    a, b_ = res
+    assert torch.equal(a[0], b_[0])
+    torch.testing.assert_close(a[1], b_[1], rtol=1e-5, atol=1e-6)   # same arg-max routing (ties: both take the first row)
+    torch.testing.assert_close(a[2], b_[2], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a[3], b_[3], rtol=1e-5, atol=1e-5)
+    assert torch.equal(a[4], b_[4]) and torch.equal(a[5], b_[5])
