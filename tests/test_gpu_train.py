@@ -239,3 +239,24 @@ def test_bn_relu_max_matches_unfused(G, K, C):
     torch.testing.assert_close(a[2], b_[2], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(a[3], b_[3], rtol=1e-5, atol=1e-5)
     assert torch.equal(a[4], b_[4]) and torch.equal(a[5], b_[5])
+
+
+def test_graph_captured_data_parallel_step_two_ranks_one_gpu():
+    """Trainer's "flat" data-parallel mode under torch.distributed.run: forward+backward HIP graph | one all-reduce of the flat
+    gradient buffer | optimiser HIP graph.  Two ranks share this GPU over gloo (RCCL refuses two ranks on one device; the
+    collective call site is the same), launched the way the driver launches bench.py."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PN2_DIST_BACKEND="gloo", HOTRACK_DATA_ROOT="/tmp/hotrack_test_dp")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "scripts", "bench_train.py"), "--steps", "6", "--warmup", "4",
+                          "--batch", "8", "--graph"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["graph_step"] is True and d["dp_mode"] == "flat" and d["loss"] == d["loss"]
