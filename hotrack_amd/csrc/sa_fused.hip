@@ -26,6 +26,12 @@
 
 // keeps the prefetching ds_reads of the MFMA loops where they are written (the scheduler otherwise sinks them back to
 // their use); -DSA_PREFETCH=0 restores the round-1 order for A/B measurements
+#ifndef SA_LOADER_PRIO
+#define SA_LOADER_PRIO 0
+#endif
+#ifndef SA_PROBE
+#define SA_PROBE 0  /* timing probes of the LOAD role (scripts/probes): 1 = no row gathers, 2 = no layer-1 arithmetic / LDS writes, 4 = no index loads */
+#endif
 #ifndef SA_PREFETCH
 #define SA_PREFETCH 1
 #endif
@@ -47,8 +53,51 @@ __device__ __forceinline__ f32x3 load_xyz(const float *p) {
     return v;
 }
 
+// Buffer descriptor (SRSRC) loads: wave-uniform base in SGPRs + one 32-bit per-lane byte offset, hardware bounds check
+// (reads past `bytes` return 0).  Built from scalars only, so hipcc keeps the descriptor in SGPRs (no waterfall loop).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+// (whole-vector bit casts: __builtin_bit_cast(float, v.x) on a vector ELEMENT reads element 0 whatever the subscript
+// with this hipcc -- clang takes the address of the vector for the element lvalue.)
+// a * b + c on the 24-bit integer multiplier (full rate; v_mul_lo_u32 is quarter rate).  In asm: hipcc's __umul24 is a
+// device-library call, which this file's no-IEEE-mode functions (see _build.py) cannot inline.
+__device__ __forceinline__ unsigned mad24(int a, unsigned b_uniform, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned mul24(int a, unsigned b_uniform) {
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(b_uniform), "v"(a));
+    return r;
+}
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+// voff: per-lane byte offset (bounds-checked against the descriptor), soff: wave-uniform byte offset added to the base
+__device__ __forceinline__ float4 ld_b128(rsrc_t r, unsigned voff, int soff) {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+// acc + w * d.lo / acc + w * d.hi on two channels at once (v_pk_fma_f32 with the broadcast chosen by op_sel).  Written in
+// asm so that `d` is a REAL register pair: when hipcc forms the broadcast itself it pairs the one live value with whatever
+// register follows it, and if that neighbour is the destination of a load still in flight the hazard tracker waits for
+// the load -- the loader's prefetches were drained by an s_waitcnt vmcnt(0) in front of the first FMA of every half tile.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma_lo(f32x2 w, f32x2 d, f32x2 acc) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(w), "v"(d), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fma_hi(f32x2 w, f32x2 d, f32x2 acc) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(r) : "v"(w), "v"(d), "v"(acc));
+    return r;
+}
+
 struct SaArgs {
-    int N, S, K, lgK;
+    int B, N, S, K, lgK;
     const float *a1f;   // (B,N,a1f_ld>=C1) point-major per-point feature term of layer 1, or nullptr
     const float *xyz;   // (B,N,3) point coordinates, or nullptr (no relative-coordinate term)
     const float *cxyz;  // (B,S,3) centroid coordinates (with xyz)
@@ -99,7 +148,7 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     float *H1ring = smem;
     float *H2 = smem + NB1 * TM * LD1;
 
-    const int tid = threadIdx.x;
+    const int tid = (int)__builtin_amdgcn_workitem_id_x();  // builtins, not threadIdx / blockIdx: those are device-library calls here (see mad24)
     const int lane = tid & 63;
     const int w = tid >> 6;
     const bool compute = w < 4;  // wave-uniform role
@@ -135,80 +184,106 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     // All loads use clamped (always valid) addresses and no per-row branches.
     constexpr int RPT = (TM / 2) / (256 / Q1);  // rows per loader thread per half tile
     static_assert((TM / 2) % (256 / Q1) == 0, "half tile rows split evenly over the loader threads");
-    // A thread's rows are STR apart, so RPC consecutive ones lie in the same K-block = the same centroid: its
-    // coordinates / additive term are loaded once per group, not per row.
-    constexpr int STR = 256 / Q1;
-    constexpr int RPC = (K / STR) < 1 ? 1 : ((K / STR) > RPT ? RPT : (K / STR));
-    const int row0 = lt / Q1;
-    struct HalfIdx { int jj[RPT], ss[RPT]; };
-    struct HalfRows { float4 a[RPT], c[RPT]; f32x3 pj[RPT], cs[RPT]; };
-    auto load_idx = [&](int tile, int h, HalfIdx &I) {
-        tile = tile < num_tiles ? tile : num_tiles - 1;  // past-the-end halves are fetched (valid addresses), never written
-        const int b = tile / tiles_per_cloud;
-        const int pos0 = (tile - b * tiles_per_cloud) * TM + h * (TM / 2);
-        const int *__restrict__ idxb = A.idx + (size_t)b * SK;
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            int p = pos0 + row0 + r * STR;
-            p = p < SK ? p : SK - 1;  // rows past the end belong to no centroid: computed, never stored
-            I.jj[r] = idxb[p];
-            I.ss[r] = p >> lgK;
-        }
+    static_assert(RPT == 1 || RPT == 2 || RPT == 4, "a thread's neighbour indices are ONE 4/8/16-byte load");
+    // A thread owns RPT CONSECUTIVE rows (positions): their neighbour indices are one load, and since K is a multiple of
+    // RPT they belong to one centroid, whose coordinates / additive term are loaded once per half tile.
+    const int row0 = (lt / Q1) * RPT;
+    // Tile cursor: tile = wg + i*nwg -> (cloud b, tile t inside the cloud), advanced incrementally (no division in
+    // the loops).
+    const int cur_db = nwg / tiles_per_cloud, cur_dt = nwg - cur_db * tiles_per_cloud;
+    struct Cursor { int tile, b, t; };
+    auto cursor_at = [&](int tile) { Cursor c; c.tile = tile; c.b = tile / tiles_per_cloud; c.t = tile - c.b * tiles_per_cloud; return c; };
+    auto cursor_next = [&](Cursor c) {
+        c.tile += nwg; c.b += cur_db; c.t += cur_dt;
+        if (c.t >= tiles_per_cloud) { c.t -= tiles_per_cloud; ++c.b; }
+        return c;
     };
-    auto load_rows = [&](int tile, const HalfIdx &I, HalfRows &D) {
-        tile = tile < num_tiles ? tile : num_tiles - 1;
-        const int b = tile / tiles_per_cloud;
-        // wave-uniform (scalar) per-cloud bases + 32-bit per-lane offsets: few VALU ops per row next to the MFMA stream
+    // Every instruction of this role costs the tile about one issue slot (4 cycles): next to a streaming MFMA wave the
+    // SIMD hardly issues anything else (neither s_setprio nor fewer / more loads change that: scripts/probes/sa_probe.sh),
+    // so the role's instructions execute in the matrix pipe's bubbles and the COMPUTE waves wait for them at the barriers.
+    // Hence: gathers through buffer descriptors (a load = ONE v_mad_u32_u24 for its 32-bit offset + the buffer_load,
+    // against ~4 VALU ops of 64-bit address arithmetic per flat load), no per-row clamps (positions past S*K in a cloud's
+    // last tile read zero through the bounds check of the per-cloud descriptors of idx / cxyz / cadd; a1f and xyz rows
+    // are addressed by neighbour index, always inside the cloud, so one descriptor for the whole tensor + a scalar cloud
+    // offset does), per-centroid constants formed once per half tile.  Past-the-end tiles are fetched from the last
+    // cloud (valid addresses), never written.
+    const unsigned c4x16 = 16u * c4, row0x4 = 4u * row0;
+    const unsigned a1f_ldb = 4u * (unsigned)A.a1f_ld, cadd_ldb = 4u * (unsigned)A.cadd_ld;
+    const unsigned idx_cloud = 4u * (unsigned)SK, a1f_cloud = (unsigned)N * a1f_ldb, xyz_cloud = 12u * (unsigned)N;
+    const unsigned cxyz_cloud = 12u * (unsigned)S, cadd_cloud = (unsigned)S * cadd_ldb;
+    const rsrc_t ra_all = make_rsrc(A.a1f, has_a1f ? (unsigned)A.B * a1f_cloud : 0u);
+    const rsrc_t rx_all = make_rsrc(A.xyz, has_xyz ? (unsigned)A.B * xyz_cloud : 0u);
+    struct HalfIdx { int jj[RPT], ss; };
+    struct HalfRows { float4 a[RPT], pj[RPT], c, cs; };  // pj / cs: (x, y, z, the following record's x -- unused)
+    auto load_idx = [&](const Cursor &cu, int h, HalfIdx &I) {
+        const int b = cu.b < A.B ? cu.b : A.B - 1;
+        const int pos0 = cu.t * TM + h * (TM / 2);
+        const rsrc_t ri = make_rsrc(reinterpret_cast<const char *>(A.idx) + (size_t)b * idx_cloud, idx_cloud);
+        if constexpr (RPT == 4) {
+            const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)row0x4, 4 * pos0, 0));
+            I.jj[0] = v.x; I.jj[1] = v.y; I.jj[2] = v.z; I.jj[3] = v.w;
+        } else if constexpr (RPT == 2) {
+            const i32x2 v = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(ri, (int)row0x4, 4 * pos0, 0));
+            I.jj[0] = v.x; I.jj[1] = v.y;
+        } else {
+            I.jj[0] = (int)__builtin_amdgcn_raw_buffer_load_b32(ri, (int)row0x4, 4 * pos0, 0);
+        }
+        I.ss = (pos0 + row0) >> lgK;
+    };
+    auto load_rows = [&](const Cursor &cu, const HalfIdx &I, HalfRows &D) {
+        const int b = cu.b < A.B ? cu.b : A.B - 1;
         if (has_a1f) {
-            const float *__restrict__ a1b = A.a1f + (size_t)b * N * A.a1f_ld;
+            const int so = (int)((unsigned)b * a1f_cloud);
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) D.a[r] = *reinterpret_cast<const float4 *>(a1b + (unsigned)(I.jj[r] * A.a1f_ld + 4 * c4));
+            for (int r = 0; r < RPT; ++r) D.a[r] = ld_b128(ra_all, mad24(I.jj[r], a1f_ldb, c4x16), so);
         }
         if (has_cadd) {
-            const float *__restrict__ cab = A.cadd + (size_t)b * S * A.cadd_ld;
-#pragma unroll
-            for (int r = 0; r < RPT; r += RPC) D.c[r] = *reinterpret_cast<const float4 *>(cab + (unsigned)(I.ss[r] * A.cadd_ld + 4 * c4));
+            const rsrc_t rd = make_rsrc(reinterpret_cast<const char *>(A.cadd) + (size_t)b * cadd_cloud, cadd_cloud);
+            D.c = ld_b128(rd, mad24(I.ss, cadd_ldb, c4x16), 0);
         }
         if (has_xyz) {
-            const float *__restrict__ xb_ = A.xyz + (size_t)b * N * 3;
-            const float *__restrict__ cb_ = A.cxyz + (size_t)b * S * 3;
+            const int so = (int)((unsigned)b * xyz_cloud);
+            const rsrc_t rc = make_rsrc(reinterpret_cast<const char *>(A.cxyz) + (size_t)b * cxyz_cloud, cxyz_cloud);
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) D.pj[r] = load_xyz(xb_ + (unsigned)(I.jj[r] * 3));
-#pragma unroll
-            for (int r = 0; r < RPT; r += RPC) D.cs[r] = load_xyz(cb_ + (unsigned)(I.ss[r] * 3));
+            for (int r = 0; r < RPT; ++r) D.pj[r] = ld_b128(rx_all, mul24(I.jj[r], 12u), so);
+            D.cs = ld_b128(rc, mul24(I.ss, 12u), 0);
         }
     };
     // The LOAD role shares its SIMD's issue port with a COMPUTE wave: every VALU instruction here can delay an MFMA issue by a
     // slot (layer 2 ran at 36 cycles per MFMA against 32.3 in layer 3, when the loaders mostly wait on memory).  So the
-    // layer-1 arithmetic is written with the packed fp32 ops (v_pk_add / v_pk_fma / v_pk_max: two channels per instruction)
-    // and explicit FMAs: about half the VALU instructions per row.
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // layer-1 arithmetic is written with the packed fp32 ops (v_pk_add / v_pk_fma: two channels per instruction)
+    // and explicit FMAs, and the per-centroid constants (b1 + cadd) are formed once per group of rows.
     auto finish = [&](const HalfRows &D, float *__restrict__ H1, int h) {
+#ifdef SA_FINISH_PRIO
+        __builtin_amdgcn_s_setprio(SA_FINISH_PRIO);
+#endif
         const f32x2 w0x = {wxr[0][0], wxr[1][0]}, w0y = {wxr[0][1], wxr[1][1]}, w0z = {wxr[0][2], wxr[1][2]};
         const f32x2 w1x = {wxr[2][0], wxr[3][0]}, w1y = {wxr[2][1], wxr[3][1]}, w1z = {wxr[2][2], wxr[3][2]};
+        // the half tile's centroid: constant term b1 (+ cadd) and coordinates
+        f32x2 t0 = {b1r.x, b1r.y}, t1 = {b1r.z, b1r.w};
+        if (has_cadd) { t0 += (f32x2){D.c.x, D.c.y}; t1 += (f32x2){D.c.z, D.c.w}; }
+        const f32x2 cxy = {D.cs.x, D.cs.y}, czw = {D.cs.z, D.cs.w};
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            f32x2 v0 = {b1r.x, b1r.y}, v1 = {b1r.z, b1r.w};
+            f32x2 v0 = t0, v1 = t1;
             if (has_a1f) { v0 += (f32x2){D.a[r].x, D.a[r].y}; v1 += (f32x2){D.a[r].z, D.a[r].w}; }
-            if (has_cadd) { const float4 c = D.c[r - r % RPC]; v0 += (f32x2){c.x, c.y}; v1 += (f32x2){c.z, c.w}; }
             if (has_xyz) {
-                const f32x3 cs = D.cs[r - r % RPC];
-                const float dx = D.pj[r].x - cs.x, dy = D.pj[r].y - cs.y, dz = D.pj[r].z - cs.z;
-                const f32x2 dx2 = {dx, dx}, dy2 = {dy, dy}, dz2 = {dz, dz};
-                v0 = __builtin_elementwise_fma(w0x, dx2, __builtin_elementwise_fma(w0y, dy2, __builtin_elementwise_fma(w0z, dz2, v0)));
-                v1 = __builtin_elementwise_fma(w1x, dx2, __builtin_elementwise_fma(w1y, dy2, __builtin_elementwise_fma(w1z, dz2, v1)));
+                const f32x2 dxy = (f32x2){D.pj[r].x, D.pj[r].y} - cxy, dzw = (f32x2){D.pj[r].z, D.pj[r].w} - czw;
+                v0 = pk_fma_lo(w0x, dxy, pk_fma_hi(w0y, dxy, pk_fma_lo(w0z, dzw, v0)));
+                v1 = pk_fma_lo(w1x, dxy, pk_fma_hi(w1y, dxy, pk_fma_lo(w1z, dzw, v1)));
             }
-            const f32x2 z = {0.f, 0.f};
-            v0 = __builtin_elementwise_max(v0, z);
-            v1 = __builtin_elementwise_max(v1, z);
-            *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r * STR) * LD1 + 4 * c4) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r) * LD1 + 4 * c4) =
+                make_float4(fmax_raw(v0.x, 0.f), fmax_raw(v0.y, 0.f), fmax_raw(v1.x, 0.f), fmax_raw(v1.y, 0.f));
         }
+#ifdef SA_FINISH_PRIO
+        __builtin_amdgcn_s_setprio(SA_LOADER_PRIO);
+#endif
     };
-    auto gather = [&](int tile, float *__restrict__ H1, int h) {  // unpipelined: prologue only
+    auto gather = [&](const Cursor &cu, float *__restrict__ H1, int h) {  // unpipelined: prologue only
         HalfIdx I;
         HalfRows D;
-        load_idx(tile, h, I);
-        load_rows(tile, I, D);
+        load_idx(cu, h, I);
+        load_rows(cu, I, D);
         finish(D, H1, h);
     };
 
@@ -237,11 +312,11 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
             }
         }
     } else {
-        for (int a = 0; a < NB1 - 1; ++a) {  // prologue: the first NB1-1 tiles of this workgroup
-            const int tile = wg + a * nwg;
-            if (tile < num_tiles) {
-                gather(tile, H1ring + a * TM * LD1, 0);
-                gather(tile, H1ring + a * TM * LD1, 1);
+        Cursor cu = cursor_at(wg);
+        for (int a = 0; a < NB1 - 1; ++a, cu = cursor_next(cu)) {  // prologue: the first NB1-1 tiles of this workgroup
+            if (cu.tile < num_tiles) {
+                gather(cu, H1ring + a * TM * LD1, 0);
+                gather(cu, H1ring + a * TM * LD1, 1);
             }
         }
     }
@@ -265,34 +340,48 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
         // (then latency-critical) loads issued between the MFMAs; now its loads run one to two half-tiles ahead and
         // the matrix-core role is the critical path, so default priority is better (sweep, profiles/r01_misc_measurements.md:
         // prio 0 / 1 / 3 -> K=64 launch 71.2 / 72.5 / 72.6 us, sa1 37.8 / 39.6 / 39.7 us).
-#ifndef SA_LOADER_PRIO
-#define SA_LOADER_PRIO 0
-#endif
         __builtin_amdgcn_s_setprio(SA_LOADER_PRIO);
         // pipeline fill: rows of the first half and indices of the second half of the first tile this loop gathers
         HalfIdx I0, I1;
         HalfRows D0, D1;
-        const int first = wg + (NB1 - 1) * nwg;
-        load_idx(first, 0, I0);
-        load_idx(first, 1, I1);
-        load_rows(first, I0, D0);
+        Cursor nx = cursor_at(wg + (NB1 - 1) * nwg);  // the tile whose rows this iteration finishes
+        Cursor af = cursor_next(nx);                  // the one after it (indices / first rows in flight)
+        load_idx(nx, 0, I0);
+        load_idx(nx, 1, I1);
+        load_rows(nx, I0, D0);
         int it = 0;
         for (int tile = wg; tile < num_tiles; tile += nwg, ++it) {
             stamp(it, 0);
             float *H1n = H1ring + ((it + NB1 - 1) % NB1) * TM * LD1;  // last read by COMPUTE in iteration it-1
-            const int next = tile + (NB1 - 1) * nwg, after = next + nwg;
-            load_rows(next, I1, D1);    // half 1 of `next`: in flight while half 0 is finished
-            load_idx(after, 0, I0);     // indices two halves ahead
-            if (next < num_tiles) finish(D0, H1n, 0);
+#if !(SA_PROBE & 1)
+            load_rows(nx, I1, D1);    // half 1 of `nx`: in flight while half 0 is finished
+#endif
+            stamp(it, 7);
+#if !(SA_PROBE & 4)
+            load_idx(af, 0, I0);      // indices two halves ahead
+#endif
+            stamp(it, 1);
+#if !(SA_PROBE & 2)
+            if (nx.tile < num_tiles) finish(D0, H1n, 0);
+#endif
             stamp(it, 2);
             __syncthreads();  // B1
             stamp(it, 3);
-            load_rows(after, I0, D0);   // half 0 of the following tile
-            load_idx(after, 1, I1);
-            if (next < num_tiles) finish(D1, H1n, 1);
+#if !(SA_PROBE & 1)
+            load_rows(af, I0, D0);    // half 0 of the following tile
+#endif
+#if !(SA_PROBE & 4)
+            load_idx(af, 1, I1);
+#endif
+            stamp(it, 4);
+#if !(SA_PROBE & 2)
+            if (nx.tile < num_tiles) finish(D1, H1n, 1);
+#endif
             stamp(it, 5);
             __syncthreads();  // B2
             stamp(it, 6);
+            nx = af;
+            af = cursor_next(af);
         }
         return;
     }
@@ -300,11 +389,14 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     __builtin_amdgcn_s_setprio(SA_COMPUTE_PRIO);
 #endif
     int it = 0;
-    for (int tile = wg; tile < num_tiles; tile += nwg, ++it) {
+    Cursor cc = cursor_at(wg);
+    // one store per centroid: lane group g writes channel tile ct = g (the row maxima are in every lane group)
+    const int oc_lane = (wc * NT3 + g) * 16 + li;
+    for (int tile = wg; tile < num_tiles; tile += nwg, ++it, cc = cursor_next(cc)) {
         stamp(it, 0);
         float *H1 = H1ring + (it % NB1) * TM * LD1;
-        const int b = tile / tiles_per_cloud;
-        const int pos0 = (tile - b * tiles_per_cloud) * TM;
+        const int b = cc.b;
+        const int pos0 = cc.t * TM;
         {
             // ---- layer 2 on the matrix cores ------------------------------------------------------------
 #pragma unroll
@@ -409,16 +501,22 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
                 for (int ct = 0; ct < NT3; ++ct) m[0][ct] = fmax_raw(fmax3_raw(m[0][ct], m[1][ct], m[2][ct]), m[3][ct]);
             }
             constexpr int rstep = K >> 4;  // row tiles per centroid
+            float *__restrict__ outb = out + (size_t)b * A.out_b;
 #pragma unroll
             for (int rt = 0; rt < 4; rt += rstep) {
                 const int s = ((pos0 + wp * 64) >> lgK) + rt / rstep;
 #pragma unroll
-                for (int ct = 0; ct < NT3; ++ct) {
-                    const float v = rows_max4(m[rt][ct]);  // the 16 positions of a row tile sit in the 4 lane rows
-                    if (g == 0 && s < S) {
-                        const int oc = (wc * NT3 + ct) * 16 + li;
-                        out[(size_t)b * A.out_b + (size_t)s * A.out_s + (size_t)oc * A.out_c] = fmaxf(v, 0.f);  // relu commutes with max
-                    }
+                for (int ct0 = 0; ct0 < NT3; ct0 += 4) {
+                    // the 16 positions of a row tile sit in the 4 lane rows; after rows_max4 every lane row holds the max
+                    float v = rows_max4(m[rt][ct0]);
+#pragma unroll
+                    for (int j = 1; j < 4; ++j)
+                        if (ct0 + j < NT3) {
+                            const float vj = rows_max4(m[rt][ct0 + j]);
+                            v = g == j ? vj : v;
+                        }
+                    if (ct0 + g < NT3 && s < S)
+                        outb[(size_t)s * A.out_s + (size_t)(oc_lane + 16 * ct0) * A.out_c] = fmaxf(v, 0.f);  // relu commutes with max
                 }
             }
         }
@@ -430,8 +528,8 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
 
 template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
 __global__ void __launch_bounds__(512, MINW)
-sa_mlp_max_kernel(const SaArgs A) {
-    sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K, MODE>(A, blockIdx.x, gridDim.x);
+sa_mlp_max_kernel(const SaArgs A, const int grid) {
+    sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K, MODE>(A, (int)__builtin_amdgcn_workgroup_id_x(), grid);
 }
 
 // Both scales of a keypoint-query module (K0 and K1 neighbours, same layer widths) in ONE persistent grid: workgroups
@@ -441,11 +539,12 @@ sa_mlp_max_kernel(const SaArgs A) {
 // CUs with ~7 tiles per workgroup, and a launch per module disappears.
 template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K0, int K1, int MODE>
 __global__ void __launch_bounds__(512, MINW)
-sa_mlp_max_pair_kernel(const SaArgs A0, const SaArgs A1, const int n0) {
-    if ((int)blockIdx.x < n0)
-        sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K0, MODE>(A0, blockIdx.x, n0);
+sa_mlp_max_pair_kernel(const SaArgs A0, const SaArgs A1, const int n0, const int n1) {
+    const int wg = (int)__builtin_amdgcn_workgroup_id_x();
+    if (wg < n0)
+        sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K0, MODE>(A0, wg, n0);
     else
-        sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K1, MODE>(A1, blockIdx.x - n0, gridDim.x - n0);
+        sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K1, MODE>(A1, wg - n0, n1);
 }
 
 template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
@@ -456,6 +555,7 @@ static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
     const long num_tiles_l = (long)b * a.tiles_per_cloud;
     if (num_tiles_l > 2147483647L) return PN2_ERANGE;
     a.num_tiles = (int)num_tiles_l;
+    a.B = b;
     a.lgK = 0;
     while ((1 << a.lgK) < a.K) ++a.lgK;
     const size_t lds = (size_t)TM * (NB1 * (C1 + SA_PAD) + C2 + SA_PAD) * sizeof(float);
@@ -471,7 +571,7 @@ static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
     // (1344 tiles: 224 workgroups x 6 instead of 256 of which 64 run 6 and 192 run 5).
     const int rounds = (a.num_tiles + max_wg - 1) / max_wg;
     const int grid = (a.num_tiles + rounds - 1) / rounds;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a, grid);
     return check_launch();
 }
 
@@ -480,6 +580,7 @@ static void sa_tiles(int b, SaArgs &a) {
     constexpr int WP = 4 / WC, TM = WP * 64;
     a.tiles_per_cloud = (a.S * a.K + TM - 1) / TM;
     a.num_tiles = b * a.tiles_per_cloud;
+    a.B = b;
     a.lgK = 0;
     while ((1 << a.lgK) < a.K) ++a.lgK;
 }
@@ -506,7 +607,7 @@ static int launch_sa_pair(int b, SaArgs a0, SaArgs a1, hipStream_t st) {
         n1 = (a1.num_tiles + rounds - 1) / rounds;
         if (n0 + n1 <= max_wg || rounds > total) break;
     }
-    hipLaunchKernelGGL(kfn, dim3(n0 + n1), dim3(512), lds, st, a0, a1, n0);
+    hipLaunchKernelGGL(kfn, dim3(n0 + n1), dim3(512), lds, st, a0, a1, n0, n1);
     return check_launch();
 }
 
@@ -536,6 +637,14 @@ static int launch_sa(int b, const SaArgs &a, hipStream_t st) {
 #define SA_NB1 2  /* H1 ring depth; 3 measured no better (profiles/r01_misc_measurements.md) */
 #endif
 static long long *g_sa_trace = nullptr;
+// The gathers address memory through 32-bit buffer offsets formed with 24-bit multiplies (sa_body): the a1f / xyz tensors
+// (one descriptor each, scalar cloud offset) and every cloud's idx / cxyz / cadd block must stay below 4 GiB, row indices
+// and row strides (bytes) below 2^24.
+static bool sa_ranges_ok(long b, long n, long s, long k, long a1f_ld, long cadd_ld) {
+    const long lim = 0xffffffffL;
+    return n < (1L << 24) && s < (1L << 24) && 4 * a1f_ld < (1L << 24) && 4 * cadd_ld < (1L << 24) &&
+           4 * b * n * (a1f_ld > 3 ? a1f_ld : 3) <= lim && 4 * s * (cadd_ld > 3 ? cadd_ld : 3) <= lim && 4 * s * k <= lim;
+}
 }  // namespace pn2
 
 extern "C" void pn2x_debug_set_sa_trace(void *device_buffer_2x8x8_int64) { pn2::g_sa_trace = (long long *)device_buffer_2x8x8_int64; }
@@ -553,9 +662,10 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
     if (xyz && (!cxyz || !wx)) return PN2_ENULL;
     if ((a1f && (a1f_ld < c1 || a1f_ld % 4)) || (cadd && (cadd_ld < c1 || cadd_ld % 4))) return PN2_EINVAL;
     if (!(k == 16 || k == 32 || k == 64)) return PN2_ERANGE;
+    if (!sa_ranges_ok(b, n, s, k, a1f ? a1f_ld : 0, cadd ? cadd_ld : 0)) return PN2_ERANGE;
     if (((uintptr_t)a1f | (uintptr_t)cadd | (uintptr_t)b1 | (uintptr_t)w2 | (uintptr_t)w3) % 16 != 0) return PN2_EINVAL;
     SaArgs a;
-    a.N = n; a.S = s; a.K = k; a.lgK = 0;
+    a.B = b; a.N = n; a.S = s; a.K = k; a.lgK = 0;
     a.a1f = a1f; a.a1f_ld = a1f_ld; a.cadd_ld = cadd_ld; a.xyz = xyz; a.cxyz = cxyz; a.wx = wx; a.b1 = b1; a.cadd = cadd; a.idx = idx;
     a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out; a.out_b = out_b; a.out_s = out_s; a.out_c = out_c;
     a.num_tiles = 0; a.tiles_per_cloud = 0; a.trace = g_sa_trace;
@@ -567,14 +677,15 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
 }
 
 namespace pn2 {
-static int fill_sa_args(const pn2x_sa_problem &p, int c1, SaArgs &a) {
+static int fill_sa_args(int b, const pn2x_sa_problem &p, int c1, SaArgs &a) {
     if (p.n < 1 || p.s < 1 || p.k < 1) return PN2_EINVAL;
     if (!p.idx || !p.w2 || !p.b2 || !p.w3 || !p.b3 || !p.out) return PN2_ENULL;
     if (!p.a1f && !p.xyz) return PN2_ENULL;
     if (p.xyz && (!p.cxyz || !p.wx)) return PN2_ENULL;
     if ((p.a1f && (p.a1f_ld < c1 || p.a1f_ld % 4)) || (p.cadd && (p.cadd_ld < c1 || p.cadd_ld % 4))) return PN2_EINVAL;
     if (((uintptr_t)p.a1f | (uintptr_t)p.cadd | (uintptr_t)p.b1 | (uintptr_t)p.w2 | (uintptr_t)p.w3) % 16 != 0) return PN2_EINVAL;
-    a.N = p.n; a.S = p.s; a.K = p.k; a.lgK = 0;
+    if (!sa_ranges_ok(b, p.n, p.s, p.k, p.a1f ? p.a1f_ld : 0, p.cadd ? p.cadd_ld : 0)) return PN2_ERANGE;
+    a.B = 0; a.N = p.n; a.S = p.s; a.K = p.k; a.lgK = 0;
     a.a1f = p.a1f; a.a1f_ld = p.a1f_ld; a.cadd_ld = p.cadd_ld; a.xyz = p.xyz; a.cxyz = p.cxyz; a.wx = p.wx; a.b1 = p.b1;
     a.cadd = p.cadd; a.idx = p.idx; a.w2 = p.w2; a.b2 = p.b2; a.w3 = p.w3; a.b3 = p.b3; a.out = p.out; a.out_b = p.out_b;
     a.out_s = p.out_s; a.out_c = p.out_c; a.num_tiles = 0; a.tiles_per_cloud = 0; a.trace = nullptr;
@@ -593,9 +704,9 @@ extern "C" int pn2x_sa_mlp_max_pair(int b, int c1, int c2, int c3, const pn2x_sa
     if (!pn2x_sa_mlp_max_pair_supported(p0->k, p1->k, c1, c2, c3)) return PN2_ERANGE;
     if (p0->k > p1->k) { const pn2x_sa_problem *t = p0; p0 = p1; p1 = t; }
     SaArgs a0, a1;
-    int rc = fill_sa_args(*p0, c1, a0);
+    int rc = fill_sa_args(b, *p0, c1, a0);
     if (rc != PN2_OK) return rc;
-    rc = fill_sa_args(*p1, c1, a1);
+    rc = fill_sa_args(b, *p1, c1, a1);
     if (rc != PN2_OK) return rc;
     const bool fa = a0.a1f && a1.a1f, fx = a0.xyz && a1.xyz, fc0 = a0.cadd != nullptr, fc1 = a1.cadd != nullptr;
     if (!fa || !fx || fc0 != fc1 || (a0.a1f == nullptr) != (a1.a1f == nullptr)) return PN2_ERANGE;  // both scales: a1f + xyz (+ cadd)

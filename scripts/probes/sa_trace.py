@@ -17,7 +17,7 @@ ext.sa_mlp_max(idx,w2,b2,w3,b3,a1f=a1f,xyz=xyz,cxyz=cxyz,wx=wx,b1=b1)
 torch.cuda.synchronize()
 lib.pn2x_debug_set_sa_trace(None)
 t=tr.cpu().view(2,8,8)
-names=["start","mfma2 done|idx loaded","H2 written|half0 done","after B1","mfma3 done|a1f loaded","epilogue|half1 done","after B2","xyz loaded"]
+names=["start","mfma2 done|idx loaded","H2 written|half0 done","after B1","mfma3 done|a1f loaded","epilogue|half1 done","after B2","xyz loaded|rows issued"]
 for role,rn in ((0,"compute wave0"),(1,"loader wave4")):
     print(rn)
     for it in range(6):
