@@ -26,6 +26,15 @@
 
 // keeps the prefetching ds_reads of the MFMA loops where they are written (the scheduler otherwise sinks them back to
 // their use); -DSA_PREFETCH=0 restores the round-1 order for A/B measurements
+#ifndef SA_DEFER_EPILOGUE
+/* 1 = a tile's max-pool + store runs after the first k-step of the NEXT tile's layer 2 instead of between the last MFMA of
+   layer 3 and the barrier.  Measured SLOWER (pair launch 76.5 -> 77.6 us): VALU work placed inside the MFMA stream is not
+   free on this part, it costs the matrix pipe more than the same instructions cost in the bubble. */
+#define SA_DEFER_EPILOGUE 0
+#endif
+#ifndef SA_OVERLAP_WRITEOUT
+#define SA_OVERLAP_WRITEOUT 1  /* layer 2: ReLU -> H2 write-out of pass p after the first k-step of pass p+1 (second accumulator set) */
+#endif
 #ifndef SA_LOADER_PRIO
 #define SA_LOADER_PRIO 0
 #endif
@@ -390,36 +399,101 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
 #endif
     int it = 0;
     Cursor cc = cursor_at(wg);
+    constexpr int NP = 4 / RTC, NQ2 = C1 / 16, NQ3 = C2 / 16;
+    constexpr int rstep = K >> 4;  // row tiles per centroid (K = 16 -> 1, 32 -> 2, 64 -> 4)
     // one store per centroid: lane group g writes channel tile ct = g (the row maxima are in every lane group)
     const int oc_lane = (wc * NT3 + g) * 16 + li;
+    const unsigned out_cloud = 4u * ((unsigned)(S - 1) * (unsigned)A.out_s + (unsigned)(C3 - 1) * (unsigned)A.out_c + 1u);
+    // Max-pool + store of a tile (optionally deferred into the next tile's layer 2, see SA_DEFER_EPILOGUE; loop-carried then:
+    // the row-tile maxima m, the tile's cloud and first position).  The stores go through a buffer descriptor whose bounds
+    // check drops the lanes that have nothing to write (offset -1): no exec-mask branch around the store.
+    float m[4][NT3];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NT3; ++ct) m[rt][ct] = 0.f;
+    int e_b = 0, e_pos0 = 0;
+    bool e_pending = false;
+    auto epilogue = [&]() {
+        if constexpr (K == 32) {
+#pragma unroll
+            for (int ct = 0; ct < NT3; ++ct) {
+                m[0][ct] = fmax_raw(m[0][ct], m[1][ct]);
+                m[2][ct] = fmax_raw(m[2][ct], m[3][ct]);
+            }
+        }
+        if constexpr (K == 64) {
+#pragma unroll
+            for (int ct = 0; ct < NT3; ++ct) m[0][ct] = fmax_raw(fmax3_raw(m[0][ct], m[1][ct], m[2][ct]), m[3][ct]);
+        }
+        const rsrc_t ro = make_rsrc(out + (size_t)e_b * A.out_b, e_pending ? out_cloud : 0u);
+#pragma unroll
+        for (int rt = 0; rt < 4; rt += rstep) {
+            const int s = ((e_pos0 + wp * 64) >> lgK) + rt / rstep;
+#pragma unroll
+            for (int ct0 = 0; ct0 < NT3; ct0 += 4) {
+                // the 16 positions of a row tile sit in the 4 lane rows; after rows_max4 every lane row holds the max
+                float v = rows_max4(m[rt][ct0]);
+#pragma unroll
+                for (int j = 1; j < 4; ++j)
+                    if (ct0 + j < NT3) {
+                        const float vj = rows_max4(m[rt][ct0 + j]);
+                        v = g == j ? vj : v;
+                    }
+                const unsigned off = 4u * ((unsigned)s * (unsigned)A.out_s + (unsigned)(oc_lane + 16 * ct0) * (unsigned)A.out_c);
+                const bool ok = ct0 + g < NT3 && s < S;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v, 0.f)), ro, (int)(ok ? off : 0xffffffffu), 0, 0);  // relu commutes with max
+            }
+        }
+    };
+    auto frag2 = [&](const float *H1, int p, int tq, int rt) {
+        return *reinterpret_cast<const float4 *>(H1 + (wp * 64 + (p * RTC + rt) * 16 + li) * LD1 + 4 * g + 16 * tq);
+    };
+    // first A fragments of the first tile (later ones are fetched under the last MFMAs of the previous tile's layer 3: half 0
+    // of the next H1 tile is complete since that tile's barrier B1)
+    // -- possible when the rows of the first pass all lie in half 0: one position group, RTC*16 <= TM/2)
+    constexpr bool PREFETCH_NEXT = WP == 1 && RTC * 16 <= TM / 2;
+    float4 an2[RTC];
+#pragma unroll
+    for (int rt = 0; rt < RTC; ++rt) an2[rt] = frag2(H1ring, 0, 0, rt);
     for (int tile = wg; tile < num_tiles; tile += nwg, ++it, cc = cursor_next(cc)) {
         stamp(it, 0);
-        float *H1 = H1ring + (it % NB1) * TM * LD1;
-        const int b = cc.b;
-        const int pos0 = cc.t * TM;
+        const float *H1 = H1ring + (it % NB1) * TM * LD1;
+        const float *H1next = H1ring + ((it + 1) % NB1) * TM * LD1;
         {
             // ---- layer 2 on the matrix cores ------------------------------------------------------------
-#pragma unroll
-            for (int r0 = 0; r0 < 4; r0 += RTC) {
-                f32x4 acc[RTC][NT2];
+            // NP passes of RTC row tiles.  A fragments are fetched ONE k-step ahead, across pass boundaries too (with the
+            // ds_reads issued right before their use the matrix pipe idled an LDS round trip per k-step: the only other
+            // wave of this SIMD is a LOAD wave, nothing fills it), and a pass's ReLU -> H2 write-out is issued after the
+            // first k-step of the NEXT pass (its own accumulator set), i.e. in the shadow of running MFMAs.
+            f32x4 acc[2][RTC][NT2];
+            auto writeout2 = [&](int p) {  // relu -> H2 (D tile: row = g*4 + r, col = li)
 #pragma unroll
                 for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < NT2; ++ct) acc[rt][ct] = (f32x4){bias2[ct], bias2[ct], bias2[ct], bias2[ct]};
-                const float *arow = H1 + (wp * 64 + r0 * 16 + li) * LD1 + 4 * g;
-                // A fragments are fetched ONE k-step ahead: with the ds_reads issued right before their use the matrix
-                // pipe idled an LDS round trip per k-step (the only other wave of this SIMD is a LOAD wave: nothing fills it)
-                float4 an[RTC];
+                    for (int ct = 0; ct < NT2; ++ct) {
+                        float *dst = H2 + (wp * 64 + (p * RTC + rt) * 16 + g * 4) * LD2 + (wc * NT2 + ct) * 16 + li;
 #pragma unroll
-                for (int rt = 0; rt < RTC; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1);
+                        for (int r = 0; r < 4; ++r) dst[r * LD2] = fmaxf(acc[p & 1][rt][ct][r], 0.f);
+                    }
+            };
+            float4 an[RTC];
 #pragma unroll
-                for (int tq = 0; tq < C1 / 16; ++tq) {
+            for (int rt = 0; rt < RTC; ++rt) an[rt] = PREFETCH_NEXT ? an2[rt] : frag2(H1, 0, 0, rt);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int rt = 0; rt < RTC; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < NT2; ++ct) acc[p & 1][rt][ct] = (f32x4){bias2[ct], bias2[ct], bias2[ct], bias2[ct]};
+#pragma unroll
+                for (int tq = 0; tq < NQ2; ++tq) {
                     float4 a[RTC];
 #pragma unroll
                     for (int rt = 0; rt < RTC; ++rt) a[rt] = an[rt];
-                    if (tq + 1 < C1 / 16) {
+                    if (tq + 1 < NQ2 || p + 1 < NP) {
 #pragma unroll
-                        for (int rt = 0; rt < RTC; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD1 + 16 * (tq + 1));
+                        for (int rt = 0; rt < RTC; ++rt) an[rt] = tq + 1 < NQ2 ? frag2(H1, p, tq + 1, rt) : frag2(H1, p + 1, 0, rt);
                         SA_SCHED_FENCE();
                     }
 #pragma unroll
@@ -429,48 +503,55 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
                             const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
 #pragma unroll
                             for (int ct = 0; ct < NT2; ++ct)
-                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
+                                acc[p & 1][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2r[ct][4 * tq + j], acc[p & 1][rt][ct], 0, 0, 0);
                         }
+#if SA_DEFER_EPILOGUE
+                    if (tq == 0 && p == 0) epilogue();  // the previous tile's max-pool + store (nothing is written when there was none)
+#endif
+#if SA_OVERLAP_WRITEOUT
+                    if (tq == 0 && p > 0) writeout2(p - 1);
+#endif
                 }
-                if (r0 + RTC >= 4) stamp(it, 1);
-                // relu -> H2 (D tile: row = g*4 + r, col = li)
-#pragma unroll
-                for (int rt = 0; rt < RTC; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < NT2; ++ct) {
-                        float *dst = H2 + (wp * 64 + (r0 + rt) * 16 + g * 4) * LD2 + (wc * NT2 + ct) * 16 + li;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[r * LD2] = fmaxf(acc[rt][ct][r], 0.f);
-                    }
+#if !SA_OVERLAP_WRITEOUT
+                writeout2(p);
+#endif
             }
+            stamp(it, 1);
+#if SA_OVERLAP_WRITEOUT
+            writeout2(NP - 1);
+#endif
         }
         stamp(it, 2);
         __syncthreads();  // B1: H2 complete
         stamp(it, 3);
         {
-            // ---- layer 3 + max over the K neighbours ----------------------------------------------------
-            float m[4][NT3];  // per row tile: max over its 16 positions (still spread over the 4 lane groups)
+            // ---- layer 3 + max over the 16 positions of every row tile ------------------------------------------
+            auto frag3 = [&](int p, int tq, int rt) {
+                return *reinterpret_cast<const float4 *>(H2 + (wp * 64 + (p * RTC + rt) * 16 + li) * LD2 + 4 * g + 16 * tq);
+            };
+            float4 an[RTC];
 #pragma unroll
-            for (int r0 = 0; r0 < 4; r0 += RTC) {
+            for (int rt = 0; rt < RTC; ++rt) an[rt] = frag3(0, 0, rt);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
                 f32x4 acc[RTC][NT3];
 #pragma unroll
                 for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
                     for (int ct = 0; ct < NT3; ++ct) acc[rt][ct] = (f32x4){bias3[ct], bias3[ct], bias3[ct], bias3[ct]};
-                const float *arow = H2 + (wp * 64 + r0 * 16 + li) * LD2 + 4 * g;
-                float4 an[RTC];
 #pragma unroll
-                for (int rt = 0; rt < RTC; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD2);
-#pragma unroll
-                for (int tq = 0; tq < C2 / 16; ++tq) {
+                for (int tq = 0; tq < NQ3; ++tq) {
                     float4 a[RTC];
 #pragma unroll
                     for (int rt = 0; rt < RTC; ++rt) a[rt] = an[rt];
-                    if (tq + 1 < C2 / 16) {
+                    if (tq + 1 < NQ3 || p + 1 < NP) {
 #pragma unroll
-                        for (int rt = 0; rt < RTC; ++rt) an[rt] = *reinterpret_cast<const float4 *>(arow + rt * 16 * LD2 + 16 * (tq + 1));
-                        SA_SCHED_FENCE();
+                        for (int rt = 0; rt < RTC; ++rt) an[rt] = tq + 1 < NQ3 ? frag3(p, tq + 1, rt) : frag3(p + 1, 0, rt);
+                    } else if (PREFETCH_NEXT) {  // last k-step of the tile: the first fragments of the NEXT tile's layer 2
+#pragma unroll
+                        for (int rt = 0; rt < RTC; ++rt) an2[rt] = frag2(H1next, 0, 0, rt);
                     }
+                    SA_SCHED_FENCE();
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -485,45 +566,23 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
                 for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
                     for (int ct = 0; ct < NT3; ++ct)
-                        m[r0 + rt][ct] = fmax_raw(fmax3_raw(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2]), acc[rt][ct][3]);
+                        m[p * RTC + rt][ct] = fmax_raw(fmax3_raw(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2]), acc[rt][ct][3]);
             }
             stamp(it, 4);
-            // combine row tiles that belong to the same centroid (K = 16 -> 1, 32 -> 2, 64 -> 4 tiles)
-            if constexpr (K == 32) {
-#pragma unroll
-                for (int ct = 0; ct < NT3; ++ct) {
-                    m[0][ct] = fmax_raw(m[0][ct], m[1][ct]);
-                    m[2][ct] = fmax_raw(m[2][ct], m[3][ct]);
-                }
-            }
-            if constexpr (K == 64) {
-#pragma unroll
-                for (int ct = 0; ct < NT3; ++ct) m[0][ct] = fmax_raw(fmax3_raw(m[0][ct], m[1][ct], m[2][ct]), m[3][ct]);
-            }
-            constexpr int rstep = K >> 4;  // row tiles per centroid
-            float *__restrict__ outb = out + (size_t)b * A.out_b;
-#pragma unroll
-            for (int rt = 0; rt < 4; rt += rstep) {
-                const int s = ((pos0 + wp * 64) >> lgK) + rt / rstep;
-#pragma unroll
-                for (int ct0 = 0; ct0 < NT3; ct0 += 4) {
-                    // the 16 positions of a row tile sit in the 4 lane rows; after rows_max4 every lane row holds the max
-                    float v = rows_max4(m[rt][ct0]);
-#pragma unroll
-                    for (int j = 1; j < 4; ++j)
-                        if (ct0 + j < NT3) {
-                            const float vj = rows_max4(m[rt][ct0 + j]);
-                            v = g == j ? vj : v;
-                        }
-                    if (ct0 + g < NT3 && s < S)
-                        outb[(size_t)s * A.out_s + (size_t)(oc_lane + 16 * ct0) * A.out_c] = fmaxf(v, 0.f);  // relu commutes with max
-                }
-            }
+            e_b = cc.b;
+            e_pos0 = cc.t * TM;
+            e_pending = true;
+#if !SA_DEFER_EPILOGUE
+            epilogue();
+#endif
         }
         stamp(it, 5);
         __syncthreads();  // B2: H1[next] complete, H2 reusable
         stamp(it, 6);
     }
+#if SA_DEFER_EPILOGUE
+    epilogue();  // the last tile's (a workgroup without tiles writes nothing: e_pending is false)
+#endif
 }
 
 template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
@@ -640,8 +699,9 @@ static long long *g_sa_trace = nullptr;
 // The gathers address memory through 32-bit buffer offsets formed with 24-bit multiplies (sa_body): the a1f / xyz tensors
 // (one descriptor each, scalar cloud offset) and every cloud's idx / cxyz / cadd block must stay below 4 GiB, row indices
 // and row strides (bytes) below 2^24.
-static bool sa_ranges_ok(long b, long n, long s, long k, long a1f_ld, long cadd_ld) {
+static bool sa_ranges_ok(long b, long n, long s, long k, long a1f_ld, long cadd_ld, long c3, long out_s, long out_c) {
     const long lim = 0xffffffffL;
+    if (out_s < 0 || out_c < 0 || 4 * ((s - 1) * out_s + (c3 - 1) * out_c + 1) >= lim) return false;  // one store descriptor per cloud
     return n < (1L << 24) && s < (1L << 24) && 4 * a1f_ld < (1L << 24) && 4 * cadd_ld < (1L << 24) &&
            4 * b * n * (a1f_ld > 3 ? a1f_ld : 3) <= lim && 4 * s * (cadd_ld > 3 ? cadd_ld : 3) <= lim && 4 * s * k <= lim;
 }
@@ -662,7 +722,7 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
     if (xyz && (!cxyz || !wx)) return PN2_ENULL;
     if ((a1f && (a1f_ld < c1 || a1f_ld % 4)) || (cadd && (cadd_ld < c1 || cadd_ld % 4))) return PN2_EINVAL;
     if (!(k == 16 || k == 32 || k == 64)) return PN2_ERANGE;
-    if (!sa_ranges_ok(b, n, s, k, a1f ? a1f_ld : 0, cadd ? cadd_ld : 0)) return PN2_ERANGE;
+    if (!sa_ranges_ok(b, n, s, k, a1f ? a1f_ld : 0, cadd ? cadd_ld : 0, c3, out_s, out_c)) return PN2_ERANGE;
     if (((uintptr_t)a1f | (uintptr_t)cadd | (uintptr_t)b1 | (uintptr_t)w2 | (uintptr_t)w3) % 16 != 0) return PN2_EINVAL;
     SaArgs a;
     a.B = b; a.N = n; a.S = s; a.K = k; a.lgK = 0;
@@ -677,14 +737,14 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
 }
 
 namespace pn2 {
-static int fill_sa_args(int b, const pn2x_sa_problem &p, int c1, SaArgs &a) {
+static int fill_sa_args(int b, const pn2x_sa_problem &p, int c1, int c3, SaArgs &a) {
     if (p.n < 1 || p.s < 1 || p.k < 1) return PN2_EINVAL;
     if (!p.idx || !p.w2 || !p.b2 || !p.w3 || !p.b3 || !p.out) return PN2_ENULL;
     if (!p.a1f && !p.xyz) return PN2_ENULL;
     if (p.xyz && (!p.cxyz || !p.wx)) return PN2_ENULL;
     if ((p.a1f && (p.a1f_ld < c1 || p.a1f_ld % 4)) || (p.cadd && (p.cadd_ld < c1 || p.cadd_ld % 4))) return PN2_EINVAL;
     if (((uintptr_t)p.a1f | (uintptr_t)p.cadd | (uintptr_t)p.b1 | (uintptr_t)p.w2 | (uintptr_t)p.w3) % 16 != 0) return PN2_EINVAL;
-    if (!sa_ranges_ok(b, p.n, p.s, p.k, p.a1f ? p.a1f_ld : 0, p.cadd ? p.cadd_ld : 0)) return PN2_ERANGE;
+    if (!sa_ranges_ok(b, p.n, p.s, p.k, p.a1f ? p.a1f_ld : 0, p.cadd ? p.cadd_ld : 0, c3, p.out_s, p.out_c)) return PN2_ERANGE;
     a.B = 0; a.N = p.n; a.S = p.s; a.K = p.k; a.lgK = 0;
     a.a1f = p.a1f; a.a1f_ld = p.a1f_ld; a.cadd_ld = p.cadd_ld; a.xyz = p.xyz; a.cxyz = p.cxyz; a.wx = p.wx; a.b1 = p.b1;
     a.cadd = p.cadd; a.idx = p.idx; a.w2 = p.w2; a.b2 = p.b2; a.w3 = p.w3; a.b3 = p.b3; a.out = p.out; a.out_b = p.out_b;
@@ -704,9 +764,9 @@ extern "C" int pn2x_sa_mlp_max_pair(int b, int c1, int c2, int c3, const pn2x_sa
     if (!pn2x_sa_mlp_max_pair_supported(p0->k, p1->k, c1, c2, c3)) return PN2_ERANGE;
     if (p0->k > p1->k) { const pn2x_sa_problem *t = p0; p0 = p1; p1 = t; }
     SaArgs a0, a1;
-    int rc = fill_sa_args(b, *p0, c1, a0);
+    int rc = fill_sa_args(b, *p0, c1, c3, a0);
     if (rc != PN2_OK) return rc;
-    rc = fill_sa_args(b, *p1, c1, a1);
+    rc = fill_sa_args(b, *p1, c1, c3, a1);
     if (rc != PN2_OK) return rc;
     const bool fa = a0.a1f && a1.a1f, fx = a0.xyz && a1.xyz, fc0 = a0.cadd != nullptr, fc1 = a1.cadd != nullptr;
     if (!fa || !fx || fc0 != fc1 || (a0.a1f == nullptr) != (a1.a1f == nullptr)) return PN2_ERANGE;  // both scales: a1f + xyz (+ cadd)
