@@ -79,6 +79,8 @@ class KernelTimer:
             elif name == "sa_mlp_max_pair_kernel":  # both scales of a query module in one launch: (b, s, (k0, k1), c1, c2, c3)
                 q0, q1 = a[4]._obj, a[5]._obj
                 key = (name, a[0], q0.s, (q0.k, q1.k), a[1], a[2], a[3])
+            elif name == "mlp2_rows_kernel":  # two fused per-point layers: (rows, c1, c2, c3)
+                key = (name, a[0], a[1], a[2], a[3])
             else:
                 key = ("sa_mlp_max_kernel", a[0], a[2], a[3], a[4], a[5], a[6])  # (b, s, k, c1, c2, c3)
             by.setdefault(key, []).append(s.elapsed_time(e) * 1e-3)
@@ -93,6 +95,13 @@ def roofline_of(key, sec, per_step):
         ksum = sum(K) if isinstance(K, tuple) else K
         flops = 2.0 * B * S * ksum * (C1 * C2 + C2 * C3)  # the two MFMA layers the kernel executes per (s,k) position
         return {"bound": "mfma", "kernel": "%s<%d,%d,%d> (B=%d,S=%d,K=%s)" % (kname, C1, C2, C3, B, S, "+".join(map(str, K)) if isinstance(K, tuple) else K),
+                "achieved": round(flops / sec / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step}
+    if key[0] == "mlp2_rows_kernel":
+        _, R, C1, C2, C3 = key
+        flops = 2.0 * R * (C1 * C2 + C2 * C3)
+        return {"bound": "mfma", "kernel": "mlp2_rows_kernel<%d,%d,%d> (rows=%d)" % (C1, C2, C3, R),
                 "achieved": round(flops / sec / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step}

@@ -109,6 +109,74 @@ kabsch_kernel(int b, int xb, int num, const float *__restrict__ x_all, const flo
     }
 }
 
+// Backward of the fit (R, t) = Kabsch(x, y) with respect to y, in closed form (pn2_ext.h: pn2x_kabsch_backward).
+// With w = sum_i (x_i - cx)(y_i - cy)^T, R w = Sym symmetric (R^T is the polar factor of w):
+//     dL/dw = 2 R^T hat(u),  u = K^-1 axial((B - B^T) / 2),  K = tr(Sym) I - Sym,  B = R G^T,
+// where G = dL/dR - (dL/dt) cx^T collects the rotation gradient (t = cy - R cx), and then
+//     dL/dy_i = (x_i - cx)^T dL/dw + (dL/dt)^T / num        (sum_i (x_i - cx) = 0, so centring y adds nothing).
+// The same derivative autograd takes through an SVD; ~90 element-wise torch launches on (B,3,3) tensors otherwise.
+__global__ void __launch_bounds__(64)
+kabsch_bwd_kernel(int b, int xb, int num, const float *__restrict__ x_all, const float *__restrict__ y_all,
+                  const float *__restrict__ R_all, const float *__restrict__ gR_all, const float *__restrict__ gt_all,
+                  float *__restrict__ dy_all) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= b) return;
+    const float *x = x_all + (size_t)(xb == 1 ? 0 : i) * num * 3, *y = y_all + (size_t)i * num * 3;
+    double cx[3] = {0, 0, 0}, cy[3] = {0, 0, 0};
+    for (int p = 0; p < num; ++p)
+        for (int a = 0; a < 3; ++a) { cx[a] += x[3 * p + a]; cy[a] += y[3 * p + a]; }
+    const double inv = 1.0 / num;
+    for (int a = 0; a < 3; ++a) { cx[a] *= inv; cy[a] *= inv; }
+    double w[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int p = 0; p < num; ++p)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) w[a][c] += ((double)x[3 * p + a] - cx[a]) * ((double)y[3 * p + c] - cy[c]);
+    double R[3][3], G[3][3], gt[3];
+    for (int a = 0; a < 3; ++a) gt[a] = gt_all ? (double)gt_all[(size_t)i * 3 + a] : 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) {
+            R[a][c] = R_all[(size_t)i * 9 + 3 * a + c];
+            G[a][c] = (gR_all ? (double)gR_all[(size_t)i * 9 + 3 * a + c] : 0.0) - gt[a] * cx[c];
+        }
+    double sym[3][3], Bm[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0, q = 0;
+            for (int k = 0; k < 3; ++k) { s += R[a][k] * w[k][c]; q += R[a][k] * G[c][k]; }
+            sym[a][c] = s;
+            Bm[a][c] = q;
+        }
+    for (int a = 0; a < 3; ++a)
+        for (int c = a + 1; c < 3; ++c) sym[a][c] = sym[c][a] = 0.5 * (sym[a][c] + sym[c][a]);
+    const double tr = sym[0][0] + sym[1][1] + sym[2][2];
+    double K[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) K[a][c] = (a == c ? tr : 0.0) - sym[a][c];
+    const double pv[3] = {0.5 * (Bm[2][1] - Bm[1][2]), 0.5 * (Bm[0][2] - Bm[2][0]), 0.5 * (Bm[1][0] - Bm[0][1])};
+    // u = K^-1 p by the adjugate (K is symmetric positive definite away from the degenerate fits)
+    const double A00 = K[1][1] * K[2][2] - K[1][2] * K[2][1], A01 = K[0][2] * K[2][1] - K[0][1] * K[2][2], A02 = K[0][1] * K[1][2] - K[0][2] * K[1][1];
+    const double A10 = K[1][2] * K[2][0] - K[1][0] * K[2][2], A11 = K[0][0] * K[2][2] - K[0][2] * K[2][0], A12 = K[0][2] * K[1][0] - K[0][0] * K[1][2];
+    const double A20 = K[1][0] * K[2][1] - K[1][1] * K[2][0], A21 = K[0][1] * K[2][0] - K[0][0] * K[2][1], A22 = K[0][0] * K[1][1] - K[0][1] * K[1][0];
+    const double det = K[0][0] * A00 + K[0][1] * A10 + K[0][2] * A20;
+    const double u0 = (A00 * pv[0] + A01 * pv[1] + A02 * pv[2]) / det, u1 = (A10 * pv[0] + A11 * pv[1] + A12 * pv[2]) / det,
+                 u2 = (A20 * pv[0] + A21 * pv[1] + A22 * pv[2]) / det;
+    const double hat[3][3] = {{0, -u2, u1}, {u2, 0, -u0}, {-u1, u0, 0}};
+    double dW[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += R[k][a] * hat[k][c];
+            dW[a][c] = 2.0 * s;
+        }
+    float *dy = dy_all + (size_t)i * num * 3;
+    for (int p = 0; p < num; ++p)
+        for (int c = 0; c < 3; ++c) {
+            double s = gt[c] * inv;
+            for (int a = 0; a < 3; ++a) s += ((double)x[3 * p + a] - cx[a]) * dW[a][c];
+            dy[3 * p + c] = (float)s;
+        }
+}
+
 // pn2x_hand_frame: Kabsch on the palm keypoints + canonicalisation of the whole cloud, one workgroup per cloud.
 // Replaces ransac_rt + canonicalize (reference hand_network.py:100,118-119; hand_utils.py:30-31,42-66): the CPU
 // SVD hop, the cat/transpose and ~8 small torch kernels become one launch.
@@ -165,6 +233,15 @@ extern "C" int pn2x_kabsch(int b, int xb, int num, const float *x, const float *
     if (b == 0) return PN2_OK;
     if (!x || !y || !R || !t) return PN2_ENULL;
     hipLaunchKernelGGL(pn2::kabsch_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, b, xb, num, x, y, R, t);
+    return pn2::check_launch();
+}
+
+extern "C" int pn2x_kabsch_backward(int b, int xb, int num, const float *x, const float *y, const float *R, const float *grad_R,
+                                    const float *grad_t, float *grad_y, void *stream) {
+    if (b < 0 || num < 1 || !(xb == b || xb == 1)) return PN2_EINVAL;
+    if (b == 0) return PN2_OK;
+    if (!x || !y || !R || !grad_y) return PN2_ENULL;
+    hipLaunchKernelGGL(pn2::kabsch_bwd_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, b, xb, num, x, y, R, grad_R, grad_t, grad_y);
     return pn2::check_launch();
 }
 

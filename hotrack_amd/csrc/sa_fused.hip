@@ -116,6 +116,7 @@ struct SaArgs {
     int a1f_ld, cadd_ld;
     const int *idx;     // (B,S,K)
     const float *w2, *b2, *w3, *b3;
+    const float *w2e;   // (C2,3) weights of the three extra input columns of the first MFMA layer (MODE 5), or nullptr
     float *out;         // out[b*out_b + s*out_s + c*out_c]
     long out_b;
     int out_s, out_c;
@@ -132,14 +133,21 @@ struct SaArgs {
 // registers, 2 = half the accumulator / A-fragment registers).  MINW = waves per SIMD for __launch_bounds__.
 // K (neighbours per centroid) is a template parameter: the max-combine / store part is then straight-line code.
 // MODE fixes which layer-1 operands exist so the LOAD role is branch-free: 0 = xyz only (sa1), 1 = a1f + xyz,
-// 2 = a1f + xyz + cadd, 3 = any combination, tested at run time.
+// 2 = a1f + xyz + cadd, 3 = any combination, tested at run time, 4 = plain rows (two-layer MLP, no pooling).
 // The tile loop of one problem, run by workgroup `wg` of the `nwg` workgroups assigned to it (a whole launch, or one share
 // of a launch that serves two scales of a module at once -- sa_mlp_max_pair_kernel below).
 template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
 __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int nwg) {
     static_assert(K == 16 || K == 32 || K == 64, "K");
+    // MODE 4 ("rows"): no neighbourhoods at all -- H1 = the input rows a1f[r, :] as they are, and every row of the layer-3
+    // output is stored (no max-pool): a fused two-layer MLP over R = S*K plain rows (pn2x_mlp2_rows), same tile loop.
+    // MODE 5: rows whose first layer has three more input columns x[r, C1 .. C1+2] (coordinates next to the features: the
+    // [interpolated | xyz] rows of feature propagation): they travel in the padding floats of the LDS rows and their
+    // term W2e x_e is added on the VALU when the layer-2 accumulators are written out.
+    constexpr bool ROWS = MODE == 4 || MODE == 5, ROWS_EXTRA = MODE == 5;
+    static_assert(!ROWS_EXTRA || SA_PAD >= 4, "the extra input columns live in the LDS row padding");
     const bool has_a1f = MODE == 3 ? A.a1f != nullptr : MODE >= 1;
-    const bool has_xyz = MODE == 3 ? A.xyz != nullptr : true;
+    const bool has_xyz = MODE == 3 ? A.xyz != nullptr : !ROWS;
     const bool has_cadd = MODE == 3 ? A.cadd != nullptr : MODE == 2;
     constexpr int lgK = K == 16 ? 4 : K == 32 ? 5 : 6;
     const int N = A.N, S = A.S;
@@ -223,10 +231,16 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     const rsrc_t ra_all = make_rsrc(A.a1f, has_a1f ? (unsigned)A.B * a1f_cloud : 0u);
     const rsrc_t rx_all = make_rsrc(A.xyz, has_xyz ? (unsigned)A.B * xyz_cloud : 0u);
     struct HalfIdx { int jj[RPT], ss; };
-    struct HalfRows { float4 a[RPT], pj[RPT], c, cs; };  // pj / cs: (x, y, z, the following record's x -- unused)
+    struct HalfRows { float4 a[RPT], pj[RPT], c, cs, e; };  // pj / cs: (x, y, z, the following record's x -- unused); e: MODE 5
     auto load_idx = [&](const Cursor &cu, int h, HalfIdx &I) {
         const int b = cu.b < A.B ? cu.b : A.B - 1;
         const int pos0 = cu.t * TM + h * (TM / 2);
+        if constexpr (ROWS) {  // the "neighbour" of position p is row p
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) I.jj[r] = pos0 + row0 + r;
+            I.ss = 0;
+            return;
+        }
         const rsrc_t ri = make_rsrc(reinterpret_cast<const char *>(A.idx) + (size_t)b * idx_cloud, idx_cloud);
         if constexpr (RPT == 4) {
             const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)row0x4, 4 * pos0, 0));
@@ -242,9 +256,11 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     auto load_rows = [&](const Cursor &cu, const HalfIdx &I, HalfRows &D) {
         const int b = cu.b < A.B ? cu.b : A.B - 1;
         if (has_a1f) {
-            const int so = (int)((unsigned)b * a1f_cloud);
+            const int so = ROWS ? 0 : (int)((unsigned)b * a1f_cloud);
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) D.a[r] = ld_b128(ra_all, mad24(I.jj[r], a1f_ldb, c4x16), so);
+            for (int r = 0; r < RPT; ++r) D.a[r] = ld_b128(ra_all, mad24(I.jj[r], a1f_ldb, c4x16), so);  // rows past the end read 0
+            // MODE 5: the extra columns of the half tile's TM/2 rows, one row per thread of the first loader lanes
+            if (ROWS_EXTRA && lt < TM / 2) D.e = ld_b128(ra_all, mad24(I.jj[0] - row0 + lt, a1f_ldb, 4u * C1), so);
         }
         if (has_cadd) {
             const rsrc_t rd = make_rsrc(reinterpret_cast<const char *>(A.cadd) + (size_t)b * cadd_cloud, cadd_cloud);
@@ -266,6 +282,12 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
 #ifdef SA_FINISH_PRIO
         __builtin_amdgcn_s_setprio(SA_FINISH_PRIO);
 #endif
+        if constexpr (ROWS) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r) * LD1 + 4 * c4) = D.a[r];
+            if (ROWS_EXTRA && lt < TM / 2) *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + lt) * LD1 + C1) = D.e;
+            return;
+        }
         const f32x2 w0x = {wxr[0][0], wxr[1][0]}, w0y = {wxr[0][1], wxr[1][1]}, w0z = {wxr[0][2], wxr[1][2]};
         const f32x2 w1x = {wxr[2][0], wxr[3][0]}, w1y = {wxr[2][1], wxr[3][1]}, w1z = {wxr[2][2], wxr[3][2]};
         // the half tile's centroid: constant term b1 (+ cadd) and coordinates
@@ -299,7 +321,14 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     // ---- COMPUTE role: weights -> registers (B operand: lane holds W[out = tile*16 + li][in = 16*tq + 4*g + j])
     float w2r[NT2][C1 / 4], w3r[NT3][C2 / 4];
     float bias2[NT2], bias3[NT3];
+    float w2e[NT2][3] = {{0.f}};
     if (compute) {
+        if constexpr (ROWS_EXTRA) {
+#pragma unroll
+            for (int ct = 0; ct < NT2; ++ct)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) w2e[ct][k] = A.w2e[((wc * NT2 + ct) * 16 + li) * 3 + k];
+        }
 #pragma unroll
         for (int ct = 0; ct < NT2; ++ct) {
             const int oc = (wc * NT2 + ct) * 16 + li;
@@ -407,6 +436,7 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     // Max-pool + store of a tile (optionally deferred into the next tile's layer 2, see SA_DEFER_EPILOGUE; loop-carried then:
     // the row-tile maxima m, the tile's cloud and first position).  The stores go through a buffer descriptor whose bounds
     // check drops the lanes that have nothing to write (offset -1): no exec-mask branch around the store.
+    const rsrc_t ro_rows = make_rsrc(out, ROWS ? 4u * (unsigned)N * (unsigned)A.out_s : 0u);  // rows mode: the whole (R = N, ld) output
     float m[4][NT3];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -469,13 +499,23 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
             f32x4 acc[2][RTC][NT2];
             auto writeout2 = [&](int p) {  // relu -> H2 (D tile: row = g*4 + r, col = li)
 #pragma unroll
-                for (int rt = 0; rt < RTC; ++rt)
+                for (int rt = 0; rt < RTC; ++rt) {
+                    float4 e[4];
+                    if constexpr (ROWS_EXTRA) {  // the rows' extra input columns (wave-uniform per lane row: LDS broadcast reads)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) e[r] = *reinterpret_cast<const float4 *>(H1 + (wp * 64 + (p * RTC + rt) * 16 + g * 4 + r) * LD1 + C1);
+                    }
 #pragma unroll
                     for (int ct = 0; ct < NT2; ++ct) {
                         float *dst = H2 + (wp * 64 + (p * RTC + rt) * 16 + g * 4) * LD2 + (wc * NT2 + ct) * 16 + li;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[r * LD2] = fmaxf(acc[p & 1][rt][ct][r], 0.f);
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[p & 1][rt][ct][r];
+                            if constexpr (ROWS_EXTRA) v = __builtin_fmaf(w2e[ct][0], e[r].x, __builtin_fmaf(w2e[ct][1], e[r].y, __builtin_fmaf(w2e[ct][2], e[r].z, v)));
+                            dst[r * LD2] = fmaxf(v, 0.f);
+                        }
                     }
+                }
             };
             float4 an[RTC];
 #pragma unroll
@@ -506,7 +546,7 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
                                 acc[p & 1][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2r[ct][4 * tq + j], acc[p & 1][rt][ct], 0, 0, 0);
                         }
 #if SA_DEFER_EPILOGUE
-                    if (tq == 0 && p == 0) epilogue();  // the previous tile's max-pool + store (nothing is written when there was none)
+                    if (!ROWS && tq == 0 && p == 0) epilogue();  // the previous tile's max-pool + store (nothing is written when there was none)
 #endif
 #if SA_OVERLAP_WRITEOUT
                     if (tq == 0 && p > 0) writeout2(p - 1);
@@ -562,26 +602,41 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
                                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w3r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
                         }
                 }
+                if constexpr (ROWS) {  // relu -> out rows (D tile: row = g*4 + r, col = li); rows past the end are dropped by the bounds check
 #pragma unroll
-                for (int rt = 0; rt < RTC; ++rt)
+                    for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < NT3; ++ct)
-                        m[p * RTC + rt][ct] = fmax_raw(fmax3_raw(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2]), acc[rt][ct][3]);
+                        for (int ct = 0; ct < NT3; ++ct)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = cc.t * TM + wp * 64 + (p * RTC + rt) * 16 + g * 4 + r;
+                                const unsigned off = 4u * ((unsigned)row * (unsigned)A.out_s + (unsigned)((wc * NT3 + ct) * 16 + li));
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc[rt][ct][r], 0.f)), ro_rows, (int)off, 0, 0);
+                            }
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < RTC; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < NT3; ++ct)
+                            m[p * RTC + rt][ct] = fmax_raw(fmax3_raw(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2]), acc[rt][ct][3]);
+                }
             }
             stamp(it, 4);
-            e_b = cc.b;
-            e_pos0 = cc.t * TM;
-            e_pending = true;
+            if constexpr (!ROWS) {
+                e_b = cc.b;
+                e_pos0 = cc.t * TM;
+                e_pending = true;
 #if !SA_DEFER_EPILOGUE
-            epilogue();
+                epilogue();
 #endif
+            }
         }
         stamp(it, 5);
         __syncthreads();  // B2: H1[next] complete, H2 reusable
         stamp(it, 6);
     }
 #if SA_DEFER_EPILOGUE
-    epilogue();  // the last tile's (a workgroup without tiles writes nothing: e_pending is false)
+    if (!ROWS) epilogue();  // the last tile's (a workgroup without tiles writes nothing: e_pending is false)
 #endif
 }
 
@@ -727,7 +782,7 @@ extern "C" int pn2x_sa_mlp_max(int b, int n, int s, int k, int c1, int c2, int c
     SaArgs a;
     a.B = b; a.N = n; a.S = s; a.K = k; a.lgK = 0;
     a.a1f = a1f; a.a1f_ld = a1f_ld; a.cadd_ld = cadd_ld; a.xyz = xyz; a.cxyz = cxyz; a.wx = wx; a.b1 = b1; a.cadd = cadd; a.idx = idx;
-    a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.out = out; a.out_b = out_b; a.out_s = out_s; a.out_c = out_c;
+    a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.w2e = nullptr; a.out = out; a.out_b = out_b; a.out_s = out_s; a.out_c = out_c;
     a.num_tiles = 0; a.tiles_per_cloud = 0; a.trace = g_sa_trace;
     hipStream_t st = (hipStream_t)stream;
     if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64, 2, 4, 4, SA_NB1>(b, a, st);
@@ -747,7 +802,7 @@ static int fill_sa_args(int b, const pn2x_sa_problem &p, int c1, int c3, SaArgs 
     if (!sa_ranges_ok(b, p.n, p.s, p.k, p.a1f ? p.a1f_ld : 0, p.cadd ? p.cadd_ld : 0, c3, p.out_s, p.out_c)) return PN2_ERANGE;
     a.B = 0; a.N = p.n; a.S = p.s; a.K = p.k; a.lgK = 0;
     a.a1f = p.a1f; a.a1f_ld = p.a1f_ld; a.cadd_ld = p.cadd_ld; a.xyz = p.xyz; a.cxyz = p.cxyz; a.wx = p.wx; a.b1 = p.b1;
-    a.cadd = p.cadd; a.idx = p.idx; a.w2 = p.w2; a.b2 = p.b2; a.w3 = p.w3; a.b3 = p.b3; a.out = p.out; a.out_b = p.out_b;
+    a.cadd = p.cadd; a.idx = p.idx; a.w2 = p.w2; a.b2 = p.b2; a.w3 = p.w3; a.b3 = p.b3; a.w2e = nullptr; a.out = p.out; a.out_b = p.out_b;
     a.out_s = p.out_s; a.out_c = p.out_c; a.num_tiles = 0; a.tiles_per_cloud = 0; a.trace = nullptr;
     return PN2_OK;
 }
@@ -773,6 +828,29 @@ extern "C" int pn2x_sa_mlp_max_pair(int b, int c1, int c2, int c3, const pn2x_sa
     hipStream_t st = (hipStream_t)stream;
     if (fc0) return launch_sa_pair<128, 128, 192, 4, SA_RTC128, 2, SA_NB1, 16, 64, 2>(b, a0, a1, st);
     return launch_sa_pair<128, 128, 192, 4, SA_RTC128, 2, SA_NB1, 16, 64, 1>(b, a0, a1, st);
+}
+
+// ---- two-layer MLP over plain rows: out[r, :] = relu(W3 relu(W2 x[r, :] + b2) + b3) -----------------------------------------
+// The tile loop of the set-abstraction kernel without neighbourhoods (MODE 4): the intermediate activation never leaves the
+// chip.  Used for consecutive per-point layers whose two weight matrices fit the register file (feature propagation).
+extern "C" int pn2x_mlp2_rows_supported(int c1, int c2, int c3) { return (c1 == 128 && c2 == 128 && c3 == 128) ? 1 : 0; }
+
+extern "C" int pn2x_mlp2_rows(long rows, int c1, int c2, int c3, const float *x, int ldx, const float *w2, const float *w2e, const float *b2,
+                              const float *w3, const float *b3, float *out, int ldo, void *stream) {
+    using namespace pn2;
+    if (rows < 0 || ldx < c1 + (w2e ? 4 : 0) || ldo < c3 || ldx % 4 || ldo < 1) return PN2_EINVAL;
+    if (rows == 0) return PN2_OK;
+    if (!x || !w2 || !b2 || !w3 || !b3 || !out) return PN2_ENULL;
+    if (!pn2x_mlp2_rows_supported(c1, c2, c3)) return PN2_ERANGE;
+    if (((uintptr_t)x | (uintptr_t)w2 | (uintptr_t)w3) % 16 != 0) return PN2_EINVAL;
+    if (rows >= (1L << 24) - 64 || 4L * ldx >= (1L << 24) || 4L * rows * ldx > 0xffffffffL || 4L * rows * ldo > 0xffffffffL) return PN2_ERANGE;
+    SaArgs a;
+    a.B = 1; a.N = (int)rows; a.K = 16; a.S = (int)((rows + 15) / 16); a.lgK = 4;
+    a.a1f = x; a.a1f_ld = ldx; a.cadd_ld = 0; a.xyz = nullptr; a.cxyz = nullptr; a.wx = nullptr; a.b1 = nullptr; a.cadd = nullptr; a.idx = nullptr;
+    a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.w2e = w2e; a.out = out; a.out_b = 0; a.out_s = ldo; a.out_c = 1;
+    a.num_tiles = 0; a.tiles_per_cloud = 0; a.trace = nullptr;
+    if (w2e) return launch_sa_km<128, 128, 128, 4, 2, 2, SA_NB1, 16, 5>(1, a, (hipStream_t)stream);
+    return launch_sa_km<128, 128, 128, 4, 2, 2, SA_NB1, 16, 4>(1, a, (hipStream_t)stream);
 }
 
 extern "C" int pn2x_sa_mlp_max_supported(int k, int c1, int c2, int c3) {

@@ -32,6 +32,43 @@ def kabsch(x: torch.Tensor, y: torch.Tensor):
     return R, t
 
 
+_lib.pn2x_kabsch_backward.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_kabsch_backward.restype = _ci
+
+
+def kabsch_backward(x: torch.Tensor, y: torch.Tensor, R: torch.Tensor, grad_R, grad_t) -> torch.Tensor:
+    """dL/dy (B,num,3) through (R, t) = kabsch(x, y) given dL/dR (B,3,3) and dL/dt (B,3,1) (either may be None)."""
+    x = x.float().contiguous()
+    y = y.float().contiguous()
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    B, num, _ = y.shape
+    f32 = torch.float32
+    gR = None if grad_R is None else _native._ptr(grad_R.contiguous(), "grad_R", f32, B * 9)
+    gt = None if grad_t is None else _native._ptr(grad_t.contiguous(), "grad_t", f32, B * 3)
+    dy = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        _native._check(_lib.pn2x_kabsch_backward(B, x.shape[0], num, _native._ptr(x, "x", f32, x.shape[0] * num * 3),
+                                                 _native._ptr(y, "y", f32, B * num * 3), _native._ptr(R.contiguous(), "R", f32, B * 9),
+                                                 gR, gt, dy.data_ptr(), _native._stream(y)), "kabsch_backward")
+    return dy
+
+
+class KabschFit(torch.autograd.Function):
+    """(R, t) = kabsch(x, y), differentiable with respect to y: one launch forward (pn2x_kabsch), one backward."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        R, t = kabsch(x, y)
+        ctx.save_for_backward(x, y, R)
+        return R, t
+
+    @staticmethod
+    def backward(ctx, grad_R, grad_t):
+        x, y, R = ctx.saved_tensors
+        return None, kabsch_backward(x, y, R, grad_R, grad_t)
+
+
 _cl = ctypes.c_long
 _lib.pn2x_sa_mlp_max.argtypes = [_ci] * 7 + [_vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cl, _ci, _ci, _vp]
 _lib.pn2x_sa_mlp_max.restype = _ci
@@ -143,6 +180,41 @@ def sa_mlp_max_pair(p0: dict, p1: dict) -> None:
     with torch.cuda.device(a[0]["idx"].device):
         _native._check(_native._call(_lib.pn2x_sa_mlp_max_pair, "sa_mlp_max_pair_kernel", None, B, C1, C2, C3, ctypes.byref(q0),
                                      ctypes.byref(q1), _native._stream(a[0]["idx"])), "sa_mlp_max_pair")
+
+
+_lib.pn2x_mlp2_rows.argtypes = [_cl] + [_ci] * 3 + [_vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp]
+_lib.pn2x_mlp2_rows.restype = _ci
+_lib.pn2x_mlp2_rows_supported.argtypes = [_ci] * 3
+_lib.pn2x_mlp2_rows_supported.restype = _ci
+
+
+def mlp2_rows_supported(c1: int, c2: int, c3: int) -> bool:
+    return bool(_lib.pn2x_mlp2_rows_supported(c1, c2, c3))
+
+
+def mlp2_rows(x: torch.Tensor, w2, b2, w3, b3, out: torch.Tensor = None, w2e=None) -> torch.Tensor:
+    """relu(relu(x[:, :c1] W2^T + x[:, c1:c1+3] W2e^T + b2) W3^T + b3) over the rows of a 2-D float32 GPU tensor (last dim
+    contiguous, any row stride) in one launch (include/pn2_ext.h: pn2x_mlp2_rows).  `w2e` (c2, 3) or None; `out` may be a
+    column block of a wider buffer."""
+    if x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or x.stride(1) != 1:
+        raise TypeError("mlp2_rows: x must be a 2-D float32 GPU tensor with a contiguous last dimension")
+    R = x.shape[0]
+    C1, C2, C3 = w2.shape[1], w2.shape[0], w3.shape[0]
+    f32 = torch.float32
+    ldx = x.stride(0) if R > 1 else x.shape[1]
+    if x.shape[1] < C1 + (3 if w2e is not None else 0) or (w2e is not None and ldx < C1 + 4):
+        raise ValueError("mlp2_rows: x has too few columns")
+    if out is None:
+        out = torch.empty((R, C3), dtype=f32, device=x.device)
+    if out.dim() != 2 or out.shape[0] != R or out.shape[1] < C3 or out.stride(1) != 1 or out.dtype != f32 or out.device != x.device:
+        raise ValueError("mlp2_rows: out must be (rows, >= c3) float32 on the same device")
+    with torch.cuda.device(x.device):
+        _native._check(_native._call(_lib.pn2x_mlp2_rows, "mlp2_rows_kernel", None, R, C1, C2, C3, x.data_ptr(), ldx,
+                                     _native._ptr(w2, "w2", f32, C2 * C1), None if w2e is None else _native._ptr(w2e, "w2e", f32, C2 * 3),
+                                     _native._ptr(b2, "b2", f32, C2), _native._ptr(w3, "w3", f32, C3 * C2),
+                                     _native._ptr(b3, "b3", f32, C3), out.data_ptr(), out.stride(0) if R > 1 else out.shape[1], _native._stream(x)),
+                       "mlp2_rows")
+    return out
 
 
 def three_nn_weights(unknown: torch.Tensor, known: torch.Tensor):

@@ -24,6 +24,14 @@ extern "C" {
  * y: (b, num, 3);  R: (b, 3, 3) row-major;  t: (b, 3, 1).
  */
 int pn2x_kabsch(int b, int xb, int num, const float *x, const float *y, float *R, float *t, void *stream);
+/*
+ * Gradient of a loss with respect to y through the fit (R, t) = pn2x_kabsch(x, y), in closed form (no solver library, one
+ * launch; what autograd computes through torch.svd in the reference's training losses, hand_network.py:186-190 via
+ * hand_utils.py:42-66).  R (b,3,3) as returned by pn2x_kabsch; grad_R (b,3,3) / grad_t (b,3) may be NULL (= zero);
+ * grad_y (b,num,3) is written.  x carries no gradient (the palm template).
+ */
+int pn2x_kabsch_backward(int b, int xb, int num, const float *x, const float *y, const float *R, const float *grad_R,
+                         const float *grad_t, float *grad_y, void *stream);
 
 /*
  * Hand frame in one launch: Kabsch fit of the palm template to kp[:, palm_idx] (num <= 16 indices, device int32)
@@ -194,6 +202,18 @@ typedef struct pn2x_sa_problem {
     long out_b;
     int out_s, out_c;
 } pn2x_sa_problem;
+/*
+ * pn2x_mlp2_rows: out[r, :] = relu(W3 relu(W2 x[r, :c1] + W2e x[r, c1:c1+3] + b2) + b3) for `rows` point-major rows (x: ldx
+ * floats apart; out: ldo floats apart, c3 written; BatchNorm folded into W / b by the caller) -- two consecutive
+ * [Conv1d 1x1 + BN + ReLU] layers of a feature-propagation MLP (pointnet_utils.py:504-506) in ONE launch: the tile loop of
+ * pn2x_sa_mlp_max without neighbourhoods, both weight matrices register-resident, the intermediate activation never
+ * written to HBM.  w2 (c2, c1), w3 (c3, c2) row-major, 16-byte aligned.  w2e (c2, 3) or NULL: weights of three more input
+ * columns stored right behind the c1 features (the coordinates of an [interpolated | xyz] row; needs ldx >= c1 + 4).
+ * PN2_ERANGE unless pn2x_mlp2_rows_supported(c1, c2, c3).
+ */
+int pn2x_mlp2_rows_supported(int c1, int c2, int c3);
+int pn2x_mlp2_rows(long rows, int c1, int c2, int c3, const float *x, int ldx, const float *w2, const float *w2e, const float *b2,
+                   const float *w3, const float *b3, float *out, int ldo, void *stream);
 int pn2x_sa_mlp_max_pair_supported(int k0, int k1, int c1, int c2, int c3);
 int pn2x_sa_mlp_max_pair(int b, int c1, int c2, int c3, const pn2x_sa_problem *p0, const pn2x_sa_problem *p1, void *stream);
 

@@ -123,6 +123,14 @@ class FastEval:
         W = fp1[0][0]
         fp1[0] = (torch.cat([W[:, 3:], W[:, :3]], dim=1).contiguous(), fp1[0][1])  # -> [interp | xyz] (aligned block first)
         P["fp1"] = fp1
+        # Two consecutive per-point layers whose weights fit the register file run as ONE launch (the intermediate activation
+        # stays on chip; as separate skinny GEMMs over B*N rows they reach 0.36 of the MFMA peak): fp1 = [interp | xyz] -> c -> c
+        from hotrack_amd import ext
+        P["fp1_fused"] = None
+        c_in = fp1[0][0].shape[1] - 3
+        if len(fp1) == 2 and c_in == P["fp2"][-1][0].shape[0] and ext.mlp2_rows_supported(c_in, fp1[0][0].shape[0], fp1[1][0].shape[0]):
+            P["fp1_fused"] = dict(w2=fp1[0][0][:, :c_in].contiguous(), w2e=fp1[0][0][:, c_in:].contiguous(), b2=fp1[0][1],
+                                  w3=fp1[1][0].contiguous(), b3=fp1[1][1])
         P["conv1"] = fold(bh.conv1, bh.bn1)
         C = bh.out_dim
         wq, q = [], {}
@@ -278,9 +286,13 @@ class FastEval:
         assert c_i == l1_out.shape[2]
         w, i3 = ext.three_nn_weights(xyz2, l1_xyz)
         ext.three_interpolate_pm(l1_out, i3, w, fp1_in[:, :, :c_i])
-        x = fp1_in.view(B * N, c_i + 4)[:, :c_i + 3]
-        for W, b in P["fp1"]:
-            x = _lin_relu(x, W, b)
+        f = P["fp1_fused"]
+        if f is not None:  # both fp1 layers in one launch (pn2x_mlp2_rows): rows [interp | xyz | pad] -> 128 -> 128
+            x = ext.mlp2_rows(fp1_in.view(B * N, c_i + 4), f["w2"], f["b2"], f["w3"], f["b3"], w2e=f["w2e"])
+        else:
+            x = fp1_in.view(B * N, c_i + 4)[:, :c_i + 3]
+            for W, b in P["fp1"]:
+                x = _lin_relu(x, W, b)
         src2 = _lin_relu(x, *P["conv1"])  # (B*N, C) per-point backbone features
         C = src2.shape[1]
 

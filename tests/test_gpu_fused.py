@@ -316,3 +316,71 @@ def test_sa_mlp_max_pair_equals_two_launches(with_cadd, B, N, order):
     big = next(p for p in probs if p["idx"].shape[2] == 64)
     ext.sa_mlp_max_pair(dict(p32, out=b2_), dict(big, out=torch.empty(B, J, C3, device="cuda")))
     assert torch.equal(a, b2_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,ldx,ldo", [(1, 128, 128), (63, 128, 128), (64, 132, 128), (1000, 128, 136), (65536, 128, 128), (70001, 256, 128)])
+def test_mlp2_rows_matches_torch(rows, ldx, ldo):
+    """pn2x_mlp2_rows (two fused per-point layers, the fp1 tail of the inference path) vs torch fp32 / fp64."""
+    from hotrack_amd import ext
+    g = torch.Generator().manual_seed(rows)
+    C = 128
+    xb = torch.randn(rows, ldx, generator=g).cuda()
+    x = xb[:, :C]
+    w2, b2 = (torch.randn(C, C, generator=g) / C ** 0.5).cuda(), torch.randn(C, generator=g).cuda() * 0.1
+    w3, b3 = (torch.randn(C, C, generator=g) / C ** 0.5).cuda(), torch.randn(C, generator=g).cuda() * 0.1
+    ob = torch.full((rows, ldo), 7.0).cuda()
+    out = ext.mlp2_rows(x, w2, b2, w3, b3, out=ob[:, :C] if ldo != C else ob)
+    ref = torch.relu(torch.relu(x.double() @ w2.double().t() + b2.double()) @ w3.double().t() + b3.double()).float()
+    assert torch.allclose(out[:, :C], ref, atol=2e-5, rtol=1e-5), float((out[:, :C] - ref).abs().max())
+    if ldo != C:
+        assert float((ob[:, C:] - 7.0).abs().max()) == 0.0  # columns beyond c3 untouched
+    assert ext.mlp2_rows_supported(128, 128, 128) and not ext.mlp2_rows_supported(64, 64, 64)
+    if ldx >= C + 4:  # three more input columns behind the features (the [interpolated | xyz | pad] rows of fp1)
+        w2e = torch.randn(C, 3, generator=g).cuda()
+        out = ext.mlp2_rows(xb, w2, b2, w3, b3, w2e=w2e)
+        ref = torch.relu(torch.relu(x.double() @ w2.double().t() + xb[:, C:C + 3].double() @ w2e.double().t() + b2.double())
+                         @ w3.double().t() + b3.double()).float()
+        assert torch.allclose(out, ref, atol=3e-5, rtol=1e-5), float((out - ref).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,num,shared", [(1, 6, True), (32, 6, True), (70, 14, False)])
+def test_kabsch_fit_gradient_matches_svd_autograd(B, num, shared):
+    """ext.KabschFit (pn2x_kabsch / pn2x_kabsch_backward: one launch per direction) against autograd through an fp64 SVD
+    of the same fit, for a loss that uses both the rotation and the translation."""
+    from hotrack_amd import ext
+    g = torch.Generator().manual_seed(B + num)
+    x = torch.randn(1 if shared else B, num, 3, generator=g)
+    Rt = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+    Rt = Rt * torch.sign(torch.det(Rt))[:, None, None]
+    y = (torch.bmm(x.expand(B, -1, -1), Rt.transpose(1, 2)) + 0.3 * torch.randn(B, 1, 3, generator=g) + 0.05 * torch.randn(B, num, 3, generator=g))
+    cR, ct = torch.randn(B, 3, 3, generator=g), torch.randn(B, 3, 1, generator=g)
+
+    def ref(y64):
+        x64 = x.double().expand(B, -1, -1)
+        cx, cy = x64.mean(1, keepdim=True), y64.mean(1, keepdim=True)
+        w = torch.bmm((x64 - cx).transpose(1, 2), y64 - cy)
+        u, _, vh = torch.linalg.svd(w)
+        v = vh.transpose(1, 2)
+        fix = torch.eye(3, dtype=torch.float64).repeat(B, 1, 1)
+        fix[:, 2, 2] = torch.det(torch.bmm(v, u.transpose(1, 2)))
+        R = torch.bmm(torch.bmm(v, fix), u.transpose(1, 2))
+        t = (cy - torch.bmm(cx, R.transpose(1, 2))).transpose(1, 2)
+        return R, t
+
+    y64 = y.double().requires_grad_(True)
+    R64, t64 = ref(y64)
+    ((R64 * cR.double()).sum() + (t64 * ct.double()).sum()).backward()
+    yg = y.cuda().requires_grad_(True)
+    R, t = ext.KabschFit.apply(x.cuda(), yg)
+    ((R * cR.cuda()).sum() + (t * ct.cuda()).sum()).backward()
+    assert torch.allclose(R.cpu().double(), R64.detach(), atol=1e-5) and torch.allclose(t.cpu().double(), t64.detach(), atol=1e-5)
+    scale = float(y64.grad.abs().max())
+    assert float((yg.grad.cpu().double() - y64.grad).abs().max()) < 2e-5 * max(1.0, scale)
+    # rotation-only / translation-only losses (the other gradient arrives as None or zeros)
+    yg2 = y.cuda().requires_grad_(True)
+    (ext.KabschFit.apply(x.cuda(), yg2)[1] * ct.cuda()).sum().backward()
+    y64b = y.double().requires_grad_(True)
+    (ref(y64b)[1] * ct.double()).sum().backward()
+    assert float((yg2.grad.cpu().double() - y64b.grad).abs().max()) < 2e-5 * max(1.0, float(y64b.grad.abs().max()))
