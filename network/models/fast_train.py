@@ -25,6 +25,34 @@ def _w2d(conv):
     return conv.weight.view(conv.weight.shape[0], -1)
 
 
+class _SplitCols(torch.autograd.Function):
+    """Column blocks of a first-layer weight [feature | xyz | centre-feature] as views, with ONE concatenation as backward.
+    Plain slicing costs, per block and step, a zero-fill of the full weight, a copy of the block's gradient into it and an
+    accumulation (34 launches of a few microseconds each over the five split weights of the network)."""
+
+    @staticmethod
+    def forward(ctx, w, *sizes):
+        ctx.sizes = sizes
+        ctx.meta = (w.shape[0], w.dtype, w.device)
+        return tuple(p for p in w.split(list(sizes), dim=1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        rows, dtype, dev = ctx.meta
+        parts = [g if g is not None else torch.zeros((rows, n), dtype=dtype, device=dev) for g, n in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, dim=1),) + (None,) * len(ctx.sizes)
+
+
+def _split_first_layer(w, D, has_center):
+    """w (C1, D + 3 [+ Dc]) -> (feature block | None, xyz block, centre block | None)."""
+    sizes = ([D] if D else []) + [3] + ([w.shape[1] - D - 3] if has_center else [])
+    parts = list(_SplitCols.apply(w, *sizes))
+    wf = parts.pop(0) if D else None
+    wx = parts.pop(0)
+    wc = parts.pop(0) if has_center else None
+    return wf, wx, wc
+
+
 class FastTrain:
     def __init__(self, net):
         self.net = net
@@ -60,15 +88,15 @@ class FastTrain:
         B, N, _ = xyz.shape
         S = cxyz.shape[1]
         D = 0 if feat2d is None else feat2d.shape[1]
-        w1 = [_w2d(convs[0]) for convs in mod.conv_blocks]
+        w1 = [_split_first_layer(_w2d(convs[0]), D, center2d is not None) for convs in mod.conv_blocks]
         a1f = cadd = None
         if D:
-            wf = w1[0][:, :D] if len(w1) == 1 else torch.cat([w[:, :D] for w in w1], dim=0)
+            wf = w1[0][0] if len(w1) == 1 else torch.cat([w[0] for w in w1], dim=0)
             a1f = F.linear(feat2d, wf).view(B, N, -1)
         if center2d is not None:
-            wc = w1[0][:, D + 3:] if len(w1) == 1 else torch.cat([w[:, D + 3:] for w in w1], dim=0)
+            wc = w1[0][2] if len(w1) == 1 else torch.cat([w[2] for w in w1], dim=0)
             cadd = F.linear(center2d, wc).view(B, S, -1)
-        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[:, D:D + 3] for w in w1])
+        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1])
         outs = []
         for i, y1 in enumerate(y1s):
             K = idxs[i].shape[2]
@@ -141,5 +169,9 @@ class FastTrain:
     def _rearrange(mod, tok):
         """rearrange_module on token-major features tok (B,J,C) -> (B*J, C) (blocks.py: fast formula)."""
         B, J, C = tok.shape
-        g = tok[:, mod._perm.t()]  # (B, J, re, C)
-        return F.linear(g.reshape(B * J, mod.re * C), mod.linear.weight.squeeze(-1), mod.linear.bias)
+        flat = getattr(mod, "_perm_flat", None)  # (J*re,) token indices, cached: a 2-D advanced index recomputes its
+        if flat is None or flat.device != tok.device:  # linearised offsets every step and scatters its gradient with index_put
+            flat = mod._perm.t().reshape(-1).to(tok.device).contiguous()
+            mod._perm_flat = flat
+        g = tok.index_select(1, flat)  # (B, J*re, C)
+        return F.linear(g.view(B * J, mod.re * C), mod.linear.weight.squeeze(-1), mod.linear.bias)
