@@ -384,3 +384,31 @@ def test_kabsch_fit_gradient_matches_svd_autograd(B, num, shared):
     y64b = y.double().requires_grad_(True)
     (ref(y64b)[1] * ct.double()).sum().backward()
     assert float((yg2.grad.cpu().double() - y64b.grad).abs().max()) < 2e-5 * max(1.0, float(y64b.grad.abs().max()))
+
+
+@pytest.mark.gpu
+def test_fast_path_with_fused_fp1_pair_matches_default(monkeypatch):
+    """HOTRACK_MLP2=1 routes fp1's two layers through pn2x_mlp2_rows (opt-in, fast_eval.py): same outputs as the GEMM pair."""
+    from hotrack_amd import fused, pointnet2_utils
+    from models import pointnet_utils
+    from models.hand_network import HandTrackNet
+    pointnet_utils.set_operator_backend(pointnet2_utils)
+    torch.manual_seed(0)
+    model = HandTrackNet(make_cfg("cuda"))
+    deterministic_init(model)
+    model = model.cuda().eval()
+    d = synthetic_frames(21, 3, 1024)
+    d = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in d.items()}
+    flags = {"track_flag": False, "test_flag": True, "save_flag": False, "IKNet_flag": False}
+    try:
+        pointnet_utils.set_fused_backend(fused)
+        with torch.no_grad():
+            a = model(d, dict(flags))
+            assert model._fast.P["fp1_fused"] is None
+            monkeypatch.setenv("HOTRACK_MLP2", "1")
+            model._fast.prepare(force=True)
+            assert model._fast.P["fp1_fused"] is not None
+            b = model(d, dict(flags))
+    finally:
+        pointnet_utils.set_fused_backend(None)
+    assert torch.allclose(a["pred_kp"], b["pred_kp"], atol=2e-5), float((a["pred_kp"] - b["pred_kp"]).abs().max())
