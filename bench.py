@@ -219,6 +219,10 @@ def main():
     ap.add_argument("--no-elide", action="store_true", help="also compute the attention the reference discards")
     ap.add_argument("--no-fused", action="store_true", help="disable the fused SA kernels (unfused torch MLPs)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--sa-cus", type=int, default=0, help="with more than one batch in flight: CUs the persistent SA grids occupy "
+                    "(pn2x_sa_set_compute_units; a workgroup of that kernel fills its CU, the rest stay available to the other stream); "
+                    "0 = all (default: 240 gives +0.7 %% frames/s with two batches in flight, but the SA launches themselves then run 8 "
+                    "rounds of tiles instead of 7, i.e. the dominant kernel's own roofline fraction drops from 0.70 to 0.63)")
     ap.add_argument("--inflight", type=int, default=2, help="number of batches in flight: step i is replayed on HIP stream "
                     "i %% inflight (each stream has its own captured graph and buffers), so one batch's FPS / small "
                     "kernels overlap another batch's GEMMs")
@@ -285,14 +289,24 @@ def main():
                 model(pool[i % POOL][0], dict(FLAGS))
             torch.cuda.synchronize()
             eager_ms = (time.perf_counter() - t0) / 5 * 1e3
+            from hotrack_amd import ext
             gstreams = [torch.cuda.Stream() for _ in range(ninf)]
             slots = [_flatten(pool[0][0], dev) for _ in range(ninf)]  # static inputs of each stream's graph
             graphs = []
+            sa_cus = args.sa_cus if (ninf > 1 and fused_on and "PN2_SA_CUS" not in os.environ) else 0
+            ext.sa_set_compute_units(sa_cus)  # grid sizes are baked into the graphs at capture
             for i in range(ninf):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     outs[i] = model(slots[i][0], dict(FLAGS))
                 graphs.append(g)
+            g_single = None
+            if ninf > 1:  # the single-stream reference point replays a graph captured with every CU available to the SA grids
+                ext.sa_set_compute_units(0)
+                g_single = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_single):
+                    out_single = model(slots[0][0], dict(FLAGS))
+                ext.sa_set_compute_units(sa_cus)
 
         def make_step(n, src):
             counter = [0]
@@ -310,7 +324,7 @@ def main():
                     # the serving loop's hand-over: this step's batch goes into the graph's static inputs (one device-to-device
                     # copy of the batch's flat buffer), on the graph's stream
                     slots[i][1].copy_(src[s % POOL][1], non_blocking=True)
-                    graphs[i].replay()
+                    (g_single if (n == 1 and g_single is not None) else graphs[i]).replay()
             return step
 
         def timed_region(step):
@@ -409,6 +423,7 @@ def main():
                                       "runs its real pass for that cloud (value_tied_inputs, %d regions)" % len(tied_regions),
                        "dead_attention_elided": not args.no_elide, "fused_sa_kernels": fused_on,
                        "launch": "hipGraph replay" if use_graph else "eager", "batches_in_flight": ninf,
+                       "sa_compute_units": (sa_cus or 256) if use_graph else 256,
                        "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4),
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),
                        "weights": "deterministic random init (no checkpoint available offline)"},

@@ -17,6 +17,8 @@
 //
 // Tile geometry: 4 waves = WC channel groups x WP position groups (WC*WP = 4); a position
 // group owns 64 consecutive (s,k) positions = 64/K centroids (K in {16,32,64}).
+#include <stdlib.h>
+
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
@@ -661,6 +663,20 @@ sa_mlp_max_pair_kernel(const SaArgs A0, const SaArgs A1, const int n0, const int
         sa_body<C1, C2, C3, WC, RTC, MINW, NB1, K1, MODE>(A1, wg - n0, n1);
 }
 
+// CUs a persistent SA grid may occupy.  A workgroup of this kernel fills a CU (8 waves x 256 VGPRs, ~135 KB LDS): nothing of
+// a concurrent stream can share it, so a serving loop that keeps several batches in flight does better when the SA grids
+// leave a few CUs to the other stream's latency-bound kernels (measured, two batches in flight: 256 CUs 0.824 ms/step,
+// 240 CUs 0.815, 224 CUs 0.822; single stream 1.030 / 1.058 / 1.067).  pn2x_sa_set_compute_units(n) / PN2_SA_CUS=n; 0 = all.
+static int g_sa_cus = -1;
+static int sa_compute_units() {
+    if (g_sa_cus < 0) {
+        const char *e = getenv("PN2_SA_CUS");
+        g_sa_cus = e ? atoi(e) : 0;
+    }
+    const int all = num_compute_units();
+    return (g_sa_cus > 0 && g_sa_cus < all) ? g_sa_cus : all;
+}
+
 template <int C1, int C2, int C3, int WC, int RTC, int MINW, int NB1, int K, int MODE>
 static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
     constexpr int WP = 4 / WC, TM = WP * 64;
@@ -679,7 +695,7 @@ static int launch_sa_km(int b, SaArgs a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // persistent workgroups: weights are loaded into registers once per workgroup
     const int wg_per_cu = (int)((160 * 1024) / lds) < MINW / 2 ? (int)((160 * 1024) / lds) : MINW / 2;
-    const int max_wg = num_compute_units() * (wg_per_cu < 1 ? 1 : wg_per_cu);
+    const int max_wg = sa_compute_units() * (wg_per_cu < 1 ? 1 : wg_per_cu);
     // Balanced persistent grid: every workgroup runs the same number of tiles (ceil(tiles / rounds)), so the launch
     // takes `rounds` tile-times either way but leaves the CUs a ragged last round would idle to concurrent streams
     // (1344 tiles: 224 workgroups x 6 instead of 256 of which 64 run 6 and 192 run 5).
@@ -711,7 +727,7 @@ static int launch_sa_pair(int b, SaArgs a0, SaArgs a1, hipStream_t st) {
     if (lds > 64 * 1024 && raised.first_use())
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int wg_per_cu = (int)((160 * 1024) / lds) < MINW / 2 ? (int)((160 * 1024) / lds) : MINW / 2;
-    const int max_wg = num_compute_units() * (wg_per_cu < 1 ? 1 : wg_per_cu);
+    const int max_wg = sa_compute_units() * (wg_per_cu < 1 ? 1 : wg_per_cu);
     // same number of rounds for both shares (a tile costs the same in either: 64 positions through the same layers)
     const int total = a0.num_tiles + a1.num_tiles;
     int rounds = (total + max_wg - 1) / max_wg;
@@ -761,6 +777,12 @@ static bool sa_ranges_ok(long b, long n, long s, long k, long a1f_ld, long cadd_
            4 * b * n * (a1f_ld > 3 ? a1f_ld : 3) <= lim && 4 * s * (cadd_ld > 3 ? cadd_ld : 3) <= lim && 4 * s * k <= lim;
 }
 }  // namespace pn2
+
+extern "C" int pn2x_sa_set_compute_units(int n) {
+    if (n < 0) return PN2_EINVAL;
+    pn2::g_sa_cus = n;
+    return PN2_OK;
+}
 
 extern "C" void pn2x_debug_set_sa_trace(void *device_buffer_2x8x8_int64) { pn2::g_sa_trace = (long long *)device_buffer_2x8x8_int64; }
 

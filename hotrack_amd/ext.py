@@ -188,6 +188,16 @@ _lib.pn2x_mlp2_rows_supported.argtypes = [_ci] * 3
 _lib.pn2x_mlp2_rows_supported.restype = _ci
 
 
+_lib.pn2x_sa_set_compute_units.argtypes = [_ci]
+_lib.pn2x_sa_set_compute_units.restype = _ci
+
+
+def sa_set_compute_units(n: int) -> None:
+    """CUs the persistent SA grids may occupy (0 = all): a serving loop with several batches in flight leaves a few to the
+    other stream (include/pn2_ext.h: pn2x_sa_set_compute_units)."""
+    _native._check(_lib.pn2x_sa_set_compute_units(int(n)), "sa_set_compute_units")
+
+
 def mlp2_rows_supported(c1: int, c2: int, c3: int) -> bool:
     return bool(_lib.pn2x_mlp2_rows_supported(c1, c2, c3))
 

@@ -211,6 +211,12 @@ typedef struct pn2x_sa_problem {
  * columns stored right behind the c1 features (the coordinates of an [interpolated | xyz] row; needs ldx >= c1 + 4).
  * PN2_ERANGE unless pn2x_mlp2_rows_supported(c1, c2, c3).
  */
+/*
+ * Number of compute units the persistent grids of pn2x_sa_mlp_max / _pair / pn2x_mlp2_rows may occupy (0 = all, the default;
+ * also PN2_SA_CUS in the environment).  A workgroup of these kernels fills its CU, so a caller that keeps several batches in
+ * flight on different streams gains by leaving a few CUs to the other stream (bench.py: 240 of 256 with two in flight).
+ */
+int pn2x_sa_set_compute_units(int n);
 int pn2x_mlp2_rows_supported(int c1, int c2, int c3);
 int pn2x_mlp2_rows(long rows, int c1, int c2, int c3, const float *x, int ldx, const float *w2, const float *w2e, const float *b2,
                    const float *w3, const float *b3, float *out, int ldo, void *stream);
