@@ -412,3 +412,26 @@ def test_fast_path_with_fused_fp1_pair_matches_default(monkeypatch):
     finally:
         pointnet_utils.set_fused_backend(None)
     assert torch.allclose(a["pred_kp"], b["pred_kp"], atol=2e-5), float((a["pred_kp"] - b["pred_kp"]).abs().max())
+
+
+@pytest.mark.gpu
+def test_sa_compute_unit_cap_changes_nothing_but_the_grid():
+    """pn2x_sa_set_compute_units: fewer workgroups walk the same tiles -- bit-identical output."""
+    from hotrack_amd import ext
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, N, S, K, C1, C2, C3 = 9, 300, 21, 64, 128, 128, 192
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    args = dict(a1f=r(B, N, C1), xyz=torch.rand(B, N, 3, device="cuda", generator=g), cxyz=torch.rand(B, S, 3, device="cuda", generator=g),
+                wx=r(C1, 3), b1=r(C1) * 0.1)
+    idx = torch.randint(0, N, (B, S, K), device="cuda", generator=g, dtype=torch.int32)
+    w2, b2, w3, b3 = r(C2, C1) * 0.1, r(C2) * 0.1, r(C3, C2) * 0.1, r(C3) * 0.1
+    try:
+        outs = []
+        for cus in (0, 7, 100):
+            ext.sa_set_compute_units(cus)
+            outs.append(ext.sa_mlp_max(idx, w2, b2, w3, b3, point_major=True, **args))
+    finally:
+        ext.sa_set_compute_units(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    with pytest.raises(ext._native.Pn2Error):
+        ext.sa_set_compute_units(-1)
