@@ -52,12 +52,69 @@ group_fwd_kernel(int c, int n, int ps, int c_per_block, const float *__restrict_
     }
 }
 
+// Large clouds: when the (cloud, channel) rows being gathered from no longer stay in L2 (a row is n floats, thousands of
+// workgroups work on different rows at once), every 4-byte gather pulls a 128-byte line from HBM: 0.15 of the HBM roofline
+// at n = 8192.  Here a workgroup stages CC channel rows of one cloud in LDS (coalesced, read once), then streams its share of
+// the positions: 16-byte index loads, LDS gathers, 16-byte coalesced stores -- what is left is the output write.
+constexpr int kGgBig = 1024;
+__global__ void __launch_bounds__(kGgBig)
+group_fwd_lds_kernel(int c, int n, int ps, int cc, int e_per_block, const float *__restrict__ points_all,
+                     const int *__restrict__ idx_all, float *__restrict__ out_all) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];  // [cc][n]
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * cc;
+    const int nc = (c - c0) < cc ? (c - c0) : cc;
+    const float *__restrict__ src = points_all + ((size_t)b * c + c0) * n;
+    const int total = nc * n;
+    if ((((uintptr_t)src) % 16 == 0) && (total % 4 == 0)) {
+        for (int i = threadIdx.x * 4; i < total; i += kGgBig * 4) *reinterpret_cast<float4 *>(slab + i) = *reinterpret_cast<const float4 *>(src + i);
+    } else {
+        for (int i = threadIdx.x; i < total; i += kGgBig) slab[i] = src[i];
+    }
+    __syncthreads();
+    const int e_begin = blockIdx.x * e_per_block;
+    const int e_end = (e_begin + e_per_block) < ps ? (e_begin + e_per_block) : ps;
+    const int *__restrict__ idx = idx_all + (size_t)b * ps;
+    float *__restrict__ dst0 = out_all + ((size_t)b * c + c0) * ps;
+    for (int e0 = e_begin + threadIdx.x * 4; e0 < e_end; e0 += kGgBig * 4) {  // ps % 4 == 0 and e_per_block % 4 == 0
+        const int4 id = *reinterpret_cast<const int4 *>(idx + e0);
+        const float *row = slab;
+        float *dst = dst0 + e0;
+#pragma unroll 4
+        for (int ch = 0; ch < nc; ++ch) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(row[id.x], row[id.y], row[id.z], row[id.w]);
+            row += n;
+            dst += ps;
+        }
+    }
+}
+
 int group_fwd_dispatch(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,
                        float *out, hipStream_t st) {
     const long ps_l = (long)npoints * nsample;
     if (b == 0 || c == 0 || ps_l == 0) return PN2_OK;  // C == 0: HandTrackNet sa1 groups zero-channel features
     const int ps = (int)ps_l;
     const bool vec4 = (ps % 4 == 0) && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
+    // LDS-staged variant: rows too many / too long for L2 (see above) and every staged element gathered often enough
+    const long lds_cap = 128 * 1024;
+    if (vec4 && (long)n * 4 <= lds_cap && (long)b * c * n * 4 >= (8L << 20) && ps_l >= 8L * n) {
+        int cc = (int)(lds_cap / ((long)n * 4));
+        if (cc > c) cc = c;
+        if (cc > 16) cc = 16;
+        const int ych = (c + cc - 1) / cc;
+        int xb = (int)((1024 + (long)ych * b - 1) / ((long)ych * b));  // >= ~1024 workgroups, but a workgroup's output stays
+        const int xb_max = (int)(ps_l / (8L * n));                                       // >= 8x the elements it stages (>= 1 here)
+        if (xb > xb_max) xb = xb_max;
+        if (xb < 1) xb = 1;
+        int e_per_block = (int)(((ps_l + xb - 1) / xb + 3) / 4 * 4);
+        xb = (int)((ps_l + e_per_block - 1) / e_per_block);
+        const size_t lds = (size_t)cc * n * sizeof(float);
+        static PerDeviceOnce raised;
+        if (lds > 64 * 1024 && raised.first_use())
+            (void)hipFuncSetAttribute((const void *)group_fwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+        hipLaunchKernelGGL(group_fwd_lds_kernel, dim3(xb, ych, b), dim3(kGgBig), lds, st, c, n, ps, cc, e_per_block, points, idx, out);
+        return check_launch();
+    }
     const int per_block = kGgThreads * (vec4 ? 4 : 1);
     const int xb = (ps + per_block - 1) / per_block;
     // split channels so the launch reaches >= ~2048 workgroups when the problem allows it
@@ -79,19 +136,19 @@ int group_fwd_dispatch(int b, int c, int n, int npoints, int nsample, const floa
 // together (a thread walking the channels one load at a time sat on one HBM round trip per element: 0.02-0.14 of the
 // HBM roofline), then the LDS adds follow; consecutive threads take consecutive positions -> coalesced rows of grad_out.
 constexpr int kGgU = 8;
-__global__ void __launch_bounds__(kGgThreads)
+__global__ void __launch_bounds__(kGgBig)
 group_bwd_lds_kernel(int c, int n, int ps, int cc, const float *__restrict__ grad_out_all,
                      const int *__restrict__ idx_all, float *__restrict__ grad_points_all) {
     extern __shared__ __attribute__((aligned(16))) float acc[];  // [cc][n]
     const int b = blockIdx.y;
     const int c0 = blockIdx.x * cc;
     const int nc = (c - c0) < cc ? (c - c0) : cc;
-    for (int i = threadIdx.x; i < nc * n; i += kGgThreads) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < nc * n; i += (int)blockDim.x) acc[i] = 0.f;
     __syncthreads();
     const int *__restrict__ idx = idx_all + (size_t)b * ps;
     const float *__restrict__ g = grad_out_all + ((size_t)b * c + c0) * ps;
     const int chunks = (nc + kGgU - 1) / kGgU;
-    for (int item = threadIdx.x; item < ps * chunks; item += kGgThreads) {
+    for (int item = threadIdx.x; item < ps * chunks; item += (int)blockDim.x) {
         const int chunk = item / ps, e = item - chunk * ps;
         const int ch0 = chunk * kGgU;
         const int id = idx[e];
@@ -106,14 +163,14 @@ group_bwd_lds_kernel(int c, int n, int ps, int cc, const float *__restrict__ gra
     float *__restrict__ dst = grad_points_all + ((size_t)b * c + c0) * n;
     const int total = nc * n;
     int i = threadIdx.x;
-    for (; i + 3 * kGgThreads < total; i += 4 * kGgThreads) {  // four independent read-modify-writes in flight
-        const float d0 = dst[i], d1 = dst[i + kGgThreads], d2 = dst[i + 2 * kGgThreads], d3 = dst[i + 3 * kGgThreads];
+    for (; i + 3 * (int)blockDim.x < total; i += 4 * (int)blockDim.x) {  // four independent read-modify-writes in flight
+        const float d0 = dst[i], d1 = dst[i + (int)blockDim.x], d2 = dst[i + 2 * (int)blockDim.x], d3 = dst[i + 3 * (int)blockDim.x];
         dst[i] = d0 + acc[i];
-        dst[i + kGgThreads] = d1 + acc[i + kGgThreads];
-        dst[i + 2 * kGgThreads] = d2 + acc[i + 2 * kGgThreads];
-        dst[i + 3 * kGgThreads] = d3 + acc[i + 3 * kGgThreads];
+        dst[i + (int)blockDim.x] = d1 + acc[i + (int)blockDim.x];
+        dst[i + 2 * (int)blockDim.x] = d2 + acc[i + 2 * (int)blockDim.x];
+        dst[i + 3 * (int)blockDim.x] = d3 + acc[i + 3 * (int)blockDim.x];
     }
-    for (; i < total; i += kGgThreads) dst[i] += acc[i];
+    for (; i < total; i += (int)blockDim.x) dst[i] += acc[i];
 }
 
 __global__ void __launch_bounds__(kGgThreads)
@@ -142,7 +199,9 @@ int group_bwd_dispatch(int b, int c, int n, int npoints, int nsample, const floa
         // keep enough workgroups in flight: shrink the channel slab while the grid is small
         while (cc > 1 && (long)b * ((c + cc - 1) / cc) < 1024) cc = (cc + 1) / 2;
         dim3 grid((c + cc - 1) / cc, b);
-        hipLaunchKernelGGL(group_bwd_lds_kernel, grid, dim3(kGgThreads), (size_t)cc * n * sizeof(float), st, c, n, ps, cc,
+        // a slab of >= 16 KB leaves room for few workgroups per CU: 1024 threads each keep its gradient loads in flight
+        const int threads = (size_t)cc * n * sizeof(float) >= 16 * 1024 ? kGgBig : kGgThreads;
+        hipLaunchKernelGGL(group_bwd_lds_kernel, grid, dim3(threads), (size_t)cc * n * sizeof(float), st, c, n, ps, cc,
                            grad_out, idx, grad_points);
     } else {
         dim3 grid((ps + kGgThreads - 1) / kGgThreads, c, b);

@@ -130,7 +130,8 @@ def test_knn(ops, oracle, B, n, m, k, kind):
 
 
 GROUP_CASES = [(4, 3, 1024, 256, 32), (4, 0, 1024, 256, 32), (4, 64, 256, 128, 32), (2, 384, 1024, 21, 16),
-               (2, 384, 1024, 21, 64), (2, 5, 100, 7, 3), (1, 67, 8192, 2048, 64), (2, 1, 1, 1, 1), (2, 130, 333, 10, 5)]
+               (2, 384, 1024, 21, 64), (2, 5, 100, 7, 3), (1, 67, 8192, 2048, 64), (2, 1, 1, 1, 1), (2, 130, 333, 10, 5),
+               (8, 33, 8192, 1024, 64), (5, 30, 16384, 2048, 64)]  # the last two take the LDS-staged forward (rows beyond L2)
 
 
 @pytest.mark.parametrize("B,C,N,P,S", GROUP_CASES)
