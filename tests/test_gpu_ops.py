@@ -165,7 +165,7 @@ def test_gather_forward_backward(ops, oracle, B, C, N, M):
 
 
 @pytest.mark.parametrize("B,C,M,n", [(4, 256, 128, 256), (4, 128, 256, 1024), (2, 5, 3, 10), (2, 33, 700, 999),
-                                     (1, 16, 20000, 300)])
+                                     (1, 16, 20000, 300), (3, 70, 64, 1000), (1, 9, 100, 4096)])  # last two: LDS-staged forward, ragged channel chunk / several query chunks
 def test_three_interpolate_forward_backward(ops, oracle, B, C, M, n):
     rng = np.random.default_rng(M + n)
     feat = rng.normal(size=(B, C, M)).astype(np.float32)
