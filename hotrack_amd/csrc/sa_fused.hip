@@ -5,9 +5,10 @@
 // (pointnet_utils.py:389-403, :566-581).  On MI355X that is pure HBM traffic over tensors that
 // exist only to be reduced.  Here one kernel consumes the neighbour indices directly:
 //
-//   layer 1 is linear in [feat_j | xyz_j - c_s | centre_feat_s], so it splits into a per-POINT
-//   term A1[b,j,:] and a per-CENTROID term c1[b,s,:] (two small dense GEMMs done by the caller);
-//   in the kernel layer 1 is   h1 = relu(A1[idx] + c1)   -- a coalesced row gather into LDS;
+//   layer 1 is linear in [feat_j | xyz_j - c_s | centre_feat_s], so its per-POINT half A1[b,j,:] is a dense GEMM over
+//   the N points done by the caller (library GEMM); in the kernel layer 1 is
+//       h1 = relu(A1[idx] + Wx (xyz[idx] - c_s) + b1 + cadd_s)
+//   -- a coalesced row gather + a few packed FMAs, written to LDS by the LOAD role;
 //   layers 2 and 3 run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, 157 TF
 //   peak) with the BN-folded weights held in REGISTERS as the B operand for the whole kernel
 //   (the workgroup is persistent over position tiles), activations staged through LDS as the
@@ -15,8 +16,14 @@
 //   the max over the K neighbours is taken on the accumulator registers (rows of the MFMA
 //   D tile are positions) + two cross-lane steps, so (B, C, S, K) never exists.
 //
-// Tile geometry: 4 waves = WC channel groups x WP position groups (WC*WP = 4); a position
-// group owns 64 consecutive (s,k) positions = 64/K centroids (K in {16,32,64}).
+// Tile geometry: 4 COMPUTE waves = WC channel groups x WP position groups (WC*WP = 4); a position
+// group owns 64 consecutive (s,k) positions = 64/K centroids (K in {16,32,64}); 4 LOAD waves prepare the next tile.
+//
+// What bounds it (profiles/r02_misc_measurements.md): on this part the fp32 matrix rate equals the packed-fp32 vector
+// rate, and next to a wave that streams fp32 MFMAs the SIMD issues almost nothing else -- VALU work does not hide under
+// the MFMAs, wherever it is placed and whatever the wave priorities.  A tile costs its 640 MFMAs x 32 cycles plus about
+// four cycles per non-MFMA instruction of either role plus the barrier / LDS latencies, so both roles are written for
+// instruction count: buffer-descriptor gathers, no per-row clamps or divisions, packed FMAs, one store per centroid.
 #include <stdlib.h>
 
 #include "pn2_common.h"
@@ -128,8 +135,9 @@ struct SaArgs {
 
 // Workgroup = 8 waves with fixed roles (wave specialisation):
 //   waves 0-3  COMPUTE: layers 2 and 3 on the matrix cores, weights register-resident, max over K, store;
-//   waves 4-7  LOAD:    gather + layer-1 epilogue of the NEXT tile into the other half of a double-buffered
-//                       LDS tile, so the matrix cores never wait for the row gather.
+//   waves 4-7  LOAD:    gather + layer-1 arithmetic of the NEXT tile into the other slot of a double-buffered
+//                       LDS tile (software-pipelined: indices two half tiles ahead, rows one), so the matrix
+//                       cores never wait for a memory round trip.
 // Two s_barriers per tile keep the roles in step (H1[next] complete / H2 reusable).
 // RTC = row tiles (of 16 positions) whose accumulators are live at once (4 = fewest passes over the weight
 // registers, 2 = half the accumulator / A-fragment registers).  MINW = waves per SIMD for __launch_bounds__.
