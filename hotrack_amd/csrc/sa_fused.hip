@@ -44,6 +44,9 @@
 #ifndef SA_OVERLAP_WRITEOUT
 #define SA_OVERLAP_WRITEOUT 1  /* layer 2: ReLU -> H2 write-out of pass p after the first k-step of pass p+1 (second accumulator set) */
 #endif
+#ifndef SA_SCALAR_L1
+#define SA_SCALAR_L1 0  /* layer-1 arithmetic of the LOAD role with scalar fp32 ops instead of packed ones (A/B: scripts/probes/sa_sweep_kernel.sh) */
+#endif
 #ifndef SA_LOADER_PRIO
 #define SA_LOADER_PRIO 0
 #endif
@@ -300,6 +303,25 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
         }
         const f32x2 w0x = {wxr[0][0], wxr[1][0]}, w0y = {wxr[0][1], wxr[1][1]}, w0z = {wxr[0][2], wxr[1][2]};
         const f32x2 w1x = {wxr[2][0], wxr[3][0]}, w1y = {wxr[2][1], wxr[3][1]}, w1z = {wxr[2][2], wxr[3][2]};
+#if SA_SCALAR_L1
+        // scalar fp32 form: beside a streaming fp32-MFMA wave a packed fp32 VALU op costs more than the two scalar ops it
+        // replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); same IEEE operations, same results
+        float t[4] = {b1r.x, b1r.y, b1r.z, b1r.w};
+        if (has_cadd) { t[0] += D.c.x; t[1] += D.c.y; t[2] += D.c.z; t[3] += D.c.w; }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            float v[4] = {t[0], t[1], t[2], t[3]};
+            if (has_a1f) { v[0] += D.a[r].x; v[1] += D.a[r].y; v[2] += D.a[r].z; v[3] += D.a[r].w; }
+            if (has_xyz) {
+                const float dx = D.pj[r].x - D.cs.x, dy = D.pj[r].y - D.cs.y, dz = D.pj[r].z - D.cs.z;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[i] = __builtin_fmaf(wxr[i][0], dx, __builtin_fmaf(wxr[i][1], dy, __builtin_fmaf(wxr[i][2], dz, v[i])));
+            }
+            *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r) * LD1 + 4 * c4) =
+                make_float4(fmax_raw(v[0], 0.f), fmax_raw(v[1], 0.f), fmax_raw(v[2], 0.f), fmax_raw(v[3], 0.f));
+        }
+#else
         // the half tile's centroid: constant term b1 (+ cadd) and coordinates
         f32x2 t0 = {b1r.x, b1r.y}, t1 = {b1r.z, b1r.w};
         if (has_cadd) { t0 += (f32x2){D.c.x, D.c.y}; t1 += (f32x2){D.c.z, D.c.w}; }
@@ -316,6 +338,7 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
             *reinterpret_cast<float4 *>(H1 + (h * (TM / 2) + row0 + r) * LD1 + 4 * c4) =
                 make_float4(fmax_raw(v0.x, 0.f), fmax_raw(v0.y, 0.f), fmax_raw(v1.x, 0.f), fmax_raw(v1.y, 0.f));
         }
+#endif
 #ifdef SA_FINISH_PRIO
         __builtin_amdgcn_s_setprio(SA_LOADER_PRIO);
 #endif

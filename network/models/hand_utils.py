@@ -72,7 +72,9 @@ def _inv3(K):
 
 class _KabschRotation(torch.autograd.Function):
     """R(w) of the Kabsch fit as a differentiable function of the 3x3 cross-covariance w = (x-cx)^T (y-cy), with the
-    value supplied by the caller (device kernel) and the gradient in closed form.
+    value supplied by the caller and the gradient in closed form.  This is the element-wise statement of the formula
+    (checked against autograd through an fp64 SVD on the CPU, tests/test_network.py); on the GPU the training losses use
+    hotrack_amd.ext.KabschFit, the same derivative as one kernel per direction (pn2x_kabsch / pn2x_kabsch_backward).
 
     R = V diag(1,1,d) U^T (w = U S V^T) makes  R w = Sym  symmetric, i.e. w = Q Sym with Q = R^T the polar factor of
     w.  Differentiating  w = Q Sym :  Q^T dw - dw^T Q = X Sym + Sym X  with X = Q^T dQ skew; in axial vectors
