@@ -34,6 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "network"))
 
+# The serving loop keeps several batches in flight, one HIP stream + captured graph each.  The HIP runtime multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with the process's other streams): with the default, two to
+# four of our streams end up behind each other on one queue and the chip sees at most two of them at a time
+# (78 k frames/s whether 2 or 4 are in flight); with 8 queues every stream has its own (4 in flight: 87 k).  Must be set
+# before the runtime initialises; a deployment sets it in the service's environment.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -164,7 +171,7 @@ def cpu_baseline(npoints, budget_s=20.0, max_frames=200):
     }
 
 
-POOL = 4  # distinct resident batches rotated through the graphs' static input buffers
+POOL = 5  # distinct resident batches rotated through the graphs' static input buffers (coprime with the streams in flight: every stream sees every batch)
 
 
 def _leaves(d):
@@ -223,7 +230,7 @@ def main():
                     "(pn2x_sa_set_compute_units; a workgroup of that kernel fills its CU, the rest stay available to the other stream); "
                     "0 = all (default: 240 gives +0.7 %% frames/s with two batches in flight, but the SA launches themselves then run 8 "
                     "rounds of tiles instead of 7, i.e. the dominant kernel's own roofline fraction drops from 0.70 to 0.63)")
-    ap.add_argument("--inflight", type=int, default=2, help="number of batches in flight: step i is replayed on HIP stream "
+    ap.add_argument("--inflight", type=int, default=4, help="number of batches in flight: step i is replayed on HIP stream "
                     "i %% inflight (each stream has its own captured graph and buffers), so one batch's FPS / small "
                     "kernels overlap another batch's GEMMs")
     args = ap.parse_args()
@@ -423,6 +430,7 @@ def main():
                                       "runs its real pass for that cloud (value_tied_inputs, %d regions)" % len(tied_regions),
                        "dead_attention_elided": not args.no_elide, "fused_sa_kernels": fused_on,
                        "launch": "hipGraph replay" if use_graph else "eager", "batches_in_flight": ninf,
+                       "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "sa_compute_units": (sa_cus or 256) if use_graph else 256,
                        "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4),
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),
