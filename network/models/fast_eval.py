@@ -123,15 +123,16 @@ class FastEval:
         W = fp1[0][0]
         fp1[0] = (torch.cat([W[:, 3:], W[:, :3]], dim=1).contiguous(), fp1[0][1])  # -> [interp | xyz] (aligned block first)
         P["fp1"] = fp1
-        # Two consecutive per-point layers whose weights fit the register file can run as ONE launch (pn2x_mlp2_rows: the
-        # intermediate activation stays on chip): fp1 = [interp | xyz] -> c -> c.  Opt-in (HOTRACK_MLP2=1): measured on MI355X it
-        # wins single-stream (1.031 -> 1.022 ms per 64-cloud step) but loses with two batches in flight (0.819 -> 0.825 ms):
-        # the persistent kernel occupies every CU's LDS for its whole run, the library GEMMs leave room for the other stream.
+        # Two consecutive per-point layers whose weights fit the register file run as ONE launch (pn2x_mlp2_rows: the
+        # intermediate activation stays on chip): fp1 = [interp | xyz] -> c -> c.  Measured on MI355X against the two tuned library
+        # GEMMs: 64-cloud step 1.031 -> 1.022 ms single-stream, 0.735 -> 0.733 ms with four batches in flight (with only two
+        # streams sharing the chip it lost 0.7 %: the persistent kernel holds every CU's LDS for its whole run).  HOTRACK_MLP2=0
+        # restores the GEMM pair.
         import os
         from hotrack_amd import ext
         P["fp1_fused"] = None
         c_in = fp1[0][0].shape[1] - 3
-        if os.environ.get("HOTRACK_MLP2") == "1" and len(fp1) == 2 and c_in == P["fp2"][-1][0].shape[0] and ext.mlp2_rows_supported(c_in, fp1[0][0].shape[0], fp1[1][0].shape[0]):
+        if os.environ.get("HOTRACK_MLP2", "1") != "0" and len(fp1) == 2 and c_in == P["fp2"][-1][0].shape[0] and ext.mlp2_rows_supported(c_in, fp1[0][0].shape[0], fp1[1][0].shape[0]):
             P["fp1_fused"] = dict(w2=fp1[0][0][:, :c_in].contiguous(), w2e=fp1[0][0][:, c_in:].contiguous(), b2=fp1[0][1],
                                   w3=fp1[1][0].contiguous(), b3=fp1[1][1])
         P["conv1"] = fold(bh.conv1, bh.bn1)

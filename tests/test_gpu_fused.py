@@ -388,7 +388,7 @@ def test_kabsch_fit_gradient_matches_svd_autograd(B, num, shared):
 
 @pytest.mark.gpu
 def test_fast_path_with_fused_fp1_pair_matches_default(monkeypatch):
-    """HOTRACK_MLP2=1 routes fp1's two layers through pn2x_mlp2_rows (opt-in, fast_eval.py): same outputs as the GEMM pair."""
+    """fp1's two layers through pn2x_mlp2_rows (the default, fast_eval.py) against the library GEMM pair (HOTRACK_MLP2=0)."""
     from hotrack_amd import fused, pointnet2_utils
     from models import pointnet_utils
     from models.hand_network import HandTrackNet
@@ -403,9 +403,10 @@ def test_fast_path_with_fused_fp1_pair_matches_default(monkeypatch):
     try:
         pointnet_utils.set_fused_backend(fused)
         with torch.no_grad():
+            monkeypatch.setenv("HOTRACK_MLP2", "0")
             a = model(d, dict(flags))
             assert model._fast.P["fp1_fused"] is None
-            monkeypatch.setenv("HOTRACK_MLP2", "1")
+            monkeypatch.delenv("HOTRACK_MLP2")
             model._fast.prepare(force=True)
             assert model._fast.P["fp1_fused"] is not None
             b = model(d, dict(flags))
