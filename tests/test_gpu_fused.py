@@ -436,3 +436,53 @@ def test_sa_compute_unit_cap_changes_nothing_but_the_grid():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     with pytest.raises(ext._native.Pn2Error):
         ext.sa_set_compute_units(-1)
+
+
+@pytest.mark.gpu
+def test_serving_loop_several_graphs_in_flight_equals_eager():
+    """bench.py's serving loop in miniature: three captured graphs on three streams, five batches rotated through their static
+    inputs with no synchronisation between steps -- every replay must reproduce the eager forward of the batch it was given
+    (no state shared between streams: folded weights, index caches, scratch, GEMM workspaces)."""
+    from hotrack_amd import fused, pointnet2_utils
+    from models import pointnet_utils
+    from models.hand_network import HandTrackNet
+    pointnet_utils.set_operator_backend(pointnet2_utils)
+    torch.manual_seed(0)
+    model = HandTrackNet(make_cfg("cuda"))
+    deterministic_init(model)
+    model = model.cuda().eval()
+    flags = {"track_flag": False, "test_flag": True, "save_flag": False, "IKNet_flag": False}
+    B, NB, NS = 6, 5, 3
+
+    def to_dev(d):
+        return {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in d.items()}
+
+    batches = [to_dev(synthetic_frames(100 + i, B, 1024)) for i in range(NB)]
+    keys = ("jittered_hand_kp", "hand_points")
+    try:
+        pointnet_utils.set_fused_backend(fused)
+        with torch.no_grad():
+            eager = [model(b, dict(flags))["pred_kp"].clone() for b in batches]
+            streams = [torch.cuda.Stream() for _ in range(NS)]
+            slots = [to_dev(synthetic_frames(100, B, 1024)) for _ in range(NS)]
+            graphs, outs = [], []
+            torch.cuda.synchronize()
+            for i in range(NS):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    outs.append(model(slots[i], dict(flags))["pred_kp"])
+                graphs.append(g)
+            got = [None] * (4 * NB)
+            for s in range(4 * NB):  # no sync between steps; a slot is re-used only after its stream finished the previous replay
+                i = s % NS
+                with torch.cuda.stream(streams[i]):
+                    for k in keys:
+                        slots[i][k].copy_(batches[s % NB][k], non_blocking=True)
+                    slots[i]["gt_hand_pose"]["palm_template"].copy_(batches[s % NB]["gt_hand_pose"]["palm_template"], non_blocking=True)
+                    graphs[i].replay()
+                    got[s] = outs[i].clone()
+            torch.cuda.synchronize()
+    finally:
+        pointnet_utils.set_fused_backend(None)
+    for s, g_ in enumerate(got):
+        assert torch.allclose(g_, eager[s % NB], atol=1e-5), (s, float((g_ - eager[s % NB]).abs().max()))
