@@ -56,6 +56,22 @@ def test_argument_validation_without_gpu(hip_lib_path):
     lib.pn2s_trilinear.argtypes = [ci, vp, vp, ci, ci, cf, cf, cf, cf, vp, vp]
     assert lib.pn2s_trilinear(8, None, None, 1, 201, -0.2, 0.0, -0.05, 0.05, None, None) == -1           # stride <= 0
     assert lib.pn2s_trilinear(0, None, None, 1, 201, -0.2, 0.002, -0.05, 0.05, None, None) == 0          # empty is a no-op
+    cl = ctypes.c_long
+    lib.pn2x_mlp2_rows.argtypes = [cl, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]
+    assert lib.pn2x_mlp2_rows(-1, 128, 128, 128, None, 128, None, None, None, None, None, None, 128, None) == -1  # rows < 0
+    assert lib.pn2x_mlp2_rows(8, 128, 128, 128, None, 126, None, None, None, None, None, None, 128, None) == -1   # ldx < c1
+    assert lib.pn2x_mlp2_rows(0, 128, 128, 128, None, 128, None, None, None, None, None, None, 128, None) == 0    # no rows: no-op
+    assert lib.pn2x_mlp2_rows(8, 128, 128, 128, None, 128, None, None, None, None, None, None, 128, None) == -2   # NULL pointers
+    assert lib.pn2x_mlp2_rows_supported(128, 128, 128) == 1 and lib.pn2x_mlp2_rows_supported(96, 96, 96) == 0
+    lib.pn2x_kabsch_backward.argtypes = [ci, ci, ci] + [vp] * 7
+    assert lib.pn2x_kabsch_backward(4, 2, 6, None, None, None, None, None, None, None) == -1   # x batch neither 1 nor b
+    assert lib.pn2x_kabsch_backward(4, 1, 6, None, None, None, None, None, None, None) == -2   # NULL pointers
+    assert lib.pn2x_kabsch_backward(0, 1, 6, None, None, None, None, None, None, None) == 0    # empty batch
+    assert lib.pn2x_sa_set_compute_units(-3) == -1 and lib.pn2x_sa_set_compute_units(0) == 0
+    lib.pn2x_sa_mlp_max.argtypes = [ci] * 7 + [vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cl, ci, ci, vp]
+    # a row stride whose byte offsets would not fit the 24-bit address multiplier of the gathers is refused, not mis-addressed
+    one = ctypes.c_void_p(16)
+    assert lib.pn2x_sa_mlp_max(1, 64, 4, 16, 128, 128, 192, one, 1 << 23, one, one, one, one, None, 0, one, one, one, one, one, one, 768, 192, 1, None) == -3
 
 
 def test_python_boundary_exports_reference_names():
