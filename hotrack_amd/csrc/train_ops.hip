@@ -348,7 +348,7 @@ interp_pm_bwd_kernel(int m, int n, int Q, const float *__restrict__ dOut, int ld
 // relative coordinates rel (b, s*k, 3) the backward needs for d(wx).
 __global__ void __launch_bounds__(kTT)
 sa_layer1_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int a1f_ld, const float *__restrict__ xyz,
-                 const float *__restrict__ cxyz, const float *__restrict__ wx, const float *__restrict__ cadd, int cadd_ld,
+                 const float *__restrict__ cxyz, const float *__restrict__ wx, int wx_ld, const float *__restrict__ cadd, int cadd_ld,
                  const int *__restrict__ idx, float *__restrict__ out, float *__restrict__ rel_out) {
     const int b = blockIdx.y;
     const long e = (long)blockIdx.x * kTT + threadIdx.x;
@@ -362,11 +362,11 @@ sa_layer1_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int 
     if (xyz) {
         const float *p = xyz + ((size_t)b * n + j) * 3, *c = cxyz + ((size_t)b * S + s) * 3;
         const float rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
-        const float *w = wx + (size_t)q * 12;
-        acc.x += w[0] * rx + w[1] * ry + w[2] * rz;
-        acc.y += w[3] * rx + w[4] * ry + w[5] * rz;
-        acc.z += w[6] * rx + w[7] * ry + w[8] * rz;
-        acc.w += w[9] * rx + w[10] * ry + w[11] * rz;
+        const float *w0 = wx + (size_t)(4 * q) * wx_ld, *w1 = w0 + wx_ld, *w2 = w1 + wx_ld, *w3 = w2 + wx_ld;  // rows of a (C1, 3) block, wx_ld apart
+        acc.x += w0[0] * rx + w0[1] * ry + w0[2] * rz;
+        acc.y += w1[0] * rx + w1[1] * ry + w1[2] * rz;
+        acc.z += w2[0] * rx + w2[1] * ry + w2[2] * rz;
+        acc.w += w3[0] * rx + w3[1] * ry + w3[2] * rz;
         if (rel_out && q == 0) {
             float *o = rel_out + ((size_t)b * sk + r) * 3;
             o[0] = rx; o[1] = ry; o[2] = rz;
@@ -631,8 +631,14 @@ extern "C" int pn2x_three_interpolate_pm_grad(int b, int c, int m, int n, const 
 extern "C" int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
                               const float *wx, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
                               void *stream) {
+    return pn2x_sa_layer1_ld(b, n, s, k, c1, a1f, a1f_ld, xyz, cxyz, wx, 3, cadd, cadd_ld, idx, out, rel_out, stream);
+}
+
+extern "C" int pn2x_sa_layer1_ld(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
+                                 const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
+                                 void *stream) {
     using namespace pn2;
-    if (b < 0 || n < 1 || s < 0 || k < 1 || c1 < 4 || c1 % 4) return PN2_EINVAL;
+    if (b < 0 || n < 1 || s < 0 || k < 1 || c1 < 4 || c1 % 4 || (xyz && wx_ld < 3)) return PN2_EINVAL;
     if (b == 0 || s == 0) return PN2_OK;
     if (!idx || !out || (!a1f && !xyz)) return PN2_ENULL;
     if (xyz && (!cxyz || !wx)) return PN2_ENULL;
@@ -641,7 +647,7 @@ extern "C" int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a
     const int Q = c1 / 4;
     const long total = (long)s * k * Q;
     hipLaunchKernelGGL(sa_layer1_kernel, dim3((unsigned)((total + kTT - 1) / kTT), b), dim3(kTT), 0, (hipStream_t)stream, n, s, k, Q, a1f,
-                       a1f_ld, xyz, cxyz, wx, cadd, cadd_ld, idx, out, rel_out);
+                       a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out);
     return check_launch();
 }
 

@@ -26,6 +26,8 @@ _lib.pn2x_bn_relu_bwd.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _
 _lib.pn2x_scatter_add_rows.argtypes = [_ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _ci, _vp]
 _lib.pn2x_three_interpolate_pm_grad.argtypes = [_ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp]
 _lib.pn2x_sa_layer1.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
+_lib.pn2x_sa_layer1_ld.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp]
+_lib.pn2x_sa_layer1_ld.restype = _ci
 for _n in ("pn2x_bn_stats", "pn2x_bn_relu_apply", "pn2x_bn_relu_bwd", "pn2x_scatter_add_rows", "pn2x_three_interpolate_pm_grad",
            "pn2x_sa_layer1"):
     getattr(_lib, _n).restype = _ci
@@ -216,11 +218,13 @@ class _SaLayer1(torch.autograd.Function):
             K, C1 = idx.shape[2], wx.shape[0]
             out = torch.empty((B, S * K, C1), dtype=_f32, device=xyz.device)
             rel = torch.empty((B, S * K, 3), dtype=_f32, device=xyz.device)
-            wxc = wx.contiguous()
-            with torch.cuda.device(xyz.device):
-                _native._check(_lib.pn2x_sa_layer1(
+            if wx.dim() != 2 or wx.shape[1] != 3 or wx.stride(1) != 1 or wx.dtype != _f32:
+                wx = wx.contiguous().float()
+            with torch.cuda.device(xyz.device):  # the (C1, 3) block is read in place (a column block of the layer's weight)
+                _native._check(_lib.pn2x_sa_layer1_ld(
                     B, N, S, K, C1, None if a1f is None else a1f.data_ptr() + 4 * col, 0 if a1f is None else a1f.stride(1),
-                    xyz.data_ptr(), cxyz.data_ptr(), wxc.data_ptr(), None if cadd is None else cadd.data_ptr() + 4 * col,
+                    xyz.data_ptr(), cxyz.data_ptr(), wx.data_ptr(), wx.stride(0) if C1 > 1 else 3,
+                    None if cadd is None else cadd.data_ptr() + 4 * col,
                     0 if cadd is None else cadd.stride(1), _native._ptr(idx, "idx", torch.int32, B * S * K), out.data_ptr(),
                     rel.data_ptr(), st), "sa_layer1")
             outs.append(out)

@@ -263,6 +263,11 @@ int pn2x_bn_relu_bwd(long rows, int c, const float *dh, int ldd, const float *y,
  */
 int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
                    const float *wx, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out, void *stream);
+/* the same with the (c1, 3) weight block taken in place from a wider matrix: rows wx_ld floats apart (a column block of the
+ * layer's [feature | xyz | centre] weight; no contiguous copy per step) */
+int pn2x_sa_layer1_ld(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
+                      const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
+                      void *stream);
 /*
  * Transpose of pn2x_gather_rows (group_points_grad on point-major rows, reference group_points_gpu.cu:8-25):
  *   din[b, idx[b,j], :] += dout[b, j, :]      dout (b, m, ldo), idx (b, m) int32, din (b, n, ldi) accumulated into.
