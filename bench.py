@@ -127,8 +127,22 @@ def roofline_of(key, sec, per_step):
             "note": "bound by its M-step dependency chain, not by HBM (SURVEY.md section 7, hard part 2)"}
 
 
-def cpu_baseline(npoints, budget_s=20.0, max_frames=200):
-    """Reference CPU path (port) on the host: B=1 frames through the same network, no dead-work elision."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(npoints, budget_s=24.0, max_frames=200):
+    """Reference CPU path (port) on the host, SURVEY.md 8(d) protocol: B=1 frames through the same network with NO dead-work
+    elision, warm-up then up to 200 timed frames per setting, per-frame median / p10 / p90, at 1 thread (what the
+    reference's test.py:26 sets) and at all cores (torch.set_num_threads(nproc)); 16 threads is timed too because torch's
+    intra-op pool stops scaling far below this host's core count on per-frame tensors.  Bounded to ~budget_s of CPU work:
+    the frames actually timed are stated in `sample`."""
     from netinit import synthetic_frames
     from models import pointnet_utils
     from oracle import cpu_reference
@@ -139,35 +153,45 @@ def cpu_baseline(npoints, budget_s=20.0, max_frames=200):
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         frames = [synthetic_frames(1000 + i, 1, npoints) for i in range(4)]
         out = {}
-        # torch's intra-op pool stops scaling (and can collapse) far below the host's core count on these
-        # small per-frame tensors, so the port is timed at several pool sizes and the BEST one is reported.
-        cands = sorted({1, min(8, avail), min(16, avail), min(32, avail)})
+        cands = sorted({1, min(16, avail), avail})
         per = budget_s / len(cands)
         for threads in cands:
             torch.set_num_threads(threads)
             with torch.no_grad():
                 t0 = time.perf_counter()
-                model(frames[0], dict(FLAGS))  # warm-up, also a guard against a collapsing thread pool
-                if time.perf_counter() - t0 > per / 2:
+                model(frames[0], dict(FLAGS))  # first warm-up frame, also a guard against a collapsing thread pool
+                first = time.perf_counter() - t0
+                if first > per / 2:
+                    out[threads] = {"frames": 1, "median_ms": round(first * 1e3, 2), "p10_ms": None, "p90_ms": None,
+                                    "frames_per_s": round(1.0 / first, 3), "note": "thread pool collapses at this size: one frame only"}
                     continue
-                model(frames[1], dict(FLAGS))
-                t0 = time.perf_counter()
-                n = 0
-                while n < max_frames and time.perf_counter() - t0 < per:
-                    model(frames[n % 4], dict(FLAGS))
-                    n += 1
-                dt = time.perf_counter() - t0
-            out[threads] = (n / dt, n)
+                t_w = time.perf_counter()
+                nw = 1
+                while nw < 20 and time.perf_counter() - t_w < per * 0.15:  # up to 20 warm-up frames
+                    model(frames[nw % 4], dict(FLAGS))
+                    nw += 1
+                ts = []
+                t_all = time.perf_counter()
+                while len(ts) < max_frames and time.perf_counter() - t_all < per * 0.8:
+                    t0 = time.perf_counter()
+                    model(frames[len(ts) % 4], dict(FLAGS))
+                    ts.append(time.perf_counter() - t0)
+            ts.sort()
+            q = lambda f: ts[min(len(ts) - 1, int(f * len(ts)))]
+            out[threads] = {"frames": len(ts), "warmup_frames": nw, "median_ms": round(q(0.5) * 1e3, 2), "p10_ms": round(q(0.1) * 1e3, 2),
+                            "p90_ms": round(q(0.9) * 1e3, 2), "frames_per_s": round(1.0 / q(0.5), 3)}
         torch.set_num_threads(min(avail, 32))
     finally:
         pointnet_utils.set_operator_backend(saved)
-    best = max(out, key=lambda t: out[t][0])
+    best = max(out, key=lambda t: out[t]["frames_per_s"])
     return {
-        "value": round(out[best][0], 3), "unit": "frames/s", "cores": best, "kind": "port",
-        "sample": f"{out[best][1]} frames, B=1, N={npoints}, eval forward, reference fallback algorithms "
-                  f"(oracle/cpu_reference.py), attention not elided, torch CPU intra-op threads={best} "
+        "value": out[best]["frames_per_s"], "unit": "frames/s", "cores": best, "kind": "port",
+        "sample": f"{out[best]['frames']} frames (median of per-frame times), B=1, N={npoints}, eval forward, reference fallback "
+                  f"algorithms (oracle/cpu_reference.py), attention not elided, torch CPU intra-op threads={best} "
                   f"(best of {sorted(out)}; host exposes {avail} cores)",
-        "by_threads": {str(t): round(v[0], 3) for t, v in sorted(out.items())},
+        "cpu_model": _cpu_model(), "host_cores": avail,
+        "one_thread": out.get(1), "all_cores": out.get(avail),
+        "by_threads": {str(t): v for t, v in sorted(out.items())},
     }
 
 
@@ -221,7 +245,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="clouds per GPU per step (BASELINE configs[1])")
     ap.add_argument("--npoints", type=int, default=1024)
-    ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step timed region until this many seconds are timed")
+    ap.add_argument("--min-time", type=float, default=6.0, help="repeat the K-step timed region until this many seconds are timed "
+                    "(default 6 s: longer than the 5-s tick of an external GPU-busy sampler)")
+    ap.add_argument("--train-steps", type=int, default=20, help="WORLD_SIZE > 1 only: steps of the data-parallel training leg "
+                    "(configs[2] per GPU, flat-gradient RCCL all-reduce) appended after the headline regions; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-elide", action="store_true", help="also compute the attention the reference discards")
     ap.add_argument("--no-fused", action="store_true", help="disable the fused SA kernels (unfused torch MLPs)")
@@ -334,11 +361,15 @@ def main():
                     (g_single if (n == 1 and g_single is not None) else graphs[i]).replay()
             return step
 
+        local_regions = []  # this rank's own wall time of every headline region (per-rank frames/s spread at N > 1)
+
         def timed_region(step):
             sync_all()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 step()
+            torch.cuda.synchronize()
+            local_regions.append(time.perf_counter() - t0)
             sync_all()
             return max_over_ranks(time.perf_counter() - t0)
 
@@ -359,7 +390,9 @@ def main():
             for _ in range(3):
                 one()
             single_ms = timed_region(one) / args.steps * 1e3
+        local_regions.clear()
         regions = repeat_regions(step, args.min_time)   # ---- THE timed regions: K steps each, barrier + sync on both sides
+        headline_local = sorted(local_regions)[len(local_regions) // 2]
         tied_step = make_step(ninf, tied_pool)
         sync_all()
         for _ in range(3):
@@ -373,7 +406,39 @@ def main():
             model(pool[i % POOL][0], dict(FLAGS))
         torch.cuda.synchronize()
         timer.stop()
+        # ---- what the replays computed: every resident batch through every stream's graph against the eager forward of that
+        # batch, at the headline size (a wrong-but-finite replay must not print a headline)
+        replay_check = None
+        if use_graph:
+            eager_kp = [model(pool[r][0], dict(FLAGS))["pred_kp"].clone() for r in range(POOL)]
+            worst = 0.0
+            for i in range(ninf):
+                for r in range(POOL):
+                    with torch.cuda.stream(gstreams[i]):
+                        slots[i][1].copy_(pool[r][1], non_blocking=True)
+                        graphs[i].replay()
+                    gstreams[i].synchronize()
+                    worst = max(worst, float((outs[i]["pred_kp"] - eager_kp[r]).abs().max()))
+            assert worst <= 1e-5, f"graph replay differs from the eager forward of the same batch by {worst}"
+            replay_check = {"max_abs_diff_pred_kp": worst, "batches": POOL, "streams": ninf, "tolerance": 1e-5}
     assert all(torch.isfinite(o["pred_kp"]).all() for o in outs if o is not None)
+
+    # ---- WORLD_SIZE > 1: per-rank spread of the headline, and a data-parallel TRAINING leg (outside the headline) so that a
+    # multi-GPU record shows RCCL carrying the gradient all-reduce: configs[2] per GPU (32 x 1024), whole step in HIP graphs,
+    # one flat all-reduce per step (network/trainer.py dp=flat)
+    per_rank = train_leg = None
+    if world > 1:
+        t = torch.tensor([args.batch * args.steps / headline_local], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [round(float(g), 1) for g in gathered]
+        if args.train_steps > 0:
+            if use_graph:
+                del graphs, slots, g_single
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from bench_train import run_training_leg
+            train_leg = run_training_leg(args.train_steps, 5, 32, True, rank, world)
 
     if rank == 0:
         med = sorted(regions)[len(regions) // 2]
@@ -439,7 +504,15 @@ def main():
             "frame_hbm_frac": None if alg_bytes is None else round(alg_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 6),
             "roofline": roof,
             "kernels": other,
+            "replay_check": replay_check,
         }
+        from hotrack_amd import gemm_tuning
+        res["gemm_table"] = gemm_tuning.status()["gemm_table"]
+        res["config"]["gemm_table_detail"] = gemm_tuning.status()["detail"]
+        if per_rank is not None:
+            res["per_rank_frames_per_s"] = {"min": min(per_rank), "max": max(per_rank), "ranks": per_rank}
+        if train_leg is not None:
+            res["train"] = train_leg
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.npoints)
             res["speedup_vs_cpu_baseline"] = round(fps / res["cpu_baseline"]["value"], 1)

@@ -77,7 +77,8 @@ group_fwd_lds_kernel(int c, int n, int ps, int cc, int e_per_block, const float 
     const int *__restrict__ idx = idx_all + (size_t)b * ps;
     float *__restrict__ dst0 = out_all + ((size_t)b * c + c0) * ps;
     for (int e0 = e_begin + threadIdx.x * 4; e0 < e_end; e0 += kGgBig * 4) {  // ps % 4 == 0 and e_per_block % 4 == 0
-        const int4 id = *reinterpret_cast<const int4 *>(idx + e0);
+        int4 id = *reinterpret_cast<const int4 *>(idx + e0);
+        id.x = lds_index(id.x, n); id.y = lds_index(id.y, n); id.z = lds_index(id.z, n); id.w = lds_index(id.w, n);
         const float *row = slab;
         float *dst = dst0 + e0;
 #pragma unroll 4
@@ -151,7 +152,7 @@ group_bwd_lds_kernel(int c, int n, int ps, int cc, const float *__restrict__ gra
     for (int item = threadIdx.x; item < ps * chunks; item += (int)blockDim.x) {
         const int chunk = item / ps, e = item - chunk * ps;
         const int ch0 = chunk * kGgU;
-        const int id = idx[e];
+        const int id = lds_index(idx[e], n);
         float v[kGgU];
 #pragma unroll
         for (int u = 0; u < kGgU; ++u) v[u] = (ch0 + u < nc) ? g[(size_t)(ch0 + u) * ps + e] : 0.f;
@@ -190,7 +191,7 @@ int group_bwd_dispatch(int b, int c, int n, int npoints, int nsample, const floa
     const int ps = (int)ps_l;
     // inverted index + LDS-staged segment sums (scatter_cm.hip); shapes it does not cover (very long position lists, a
     // scratch that would have to grow during graph capture) take the LDS-atomic slab kernel below
-    if (scatter_cm_dispatch(1, b, c, n, ps, grad_out, idx, nullptr, grad_points, st) == PN2_OK) return PN2_OK;
+    if (const int rc = scatter_cm_dispatch(1, b, c, n, ps, grad_out, idx, nullptr, grad_points, st); rc != PN2_ERANGE) return rc;  // only "shape not covered" falls through
     const int lds_budget = 64 * 1024;
     int cc = lds_budget / (int)(sizeof(float) * (size_t)n);
     if (cc >= 1) {

@@ -53,7 +53,10 @@ interp_fwd_lds_kernel(int c, int m, int n, int cc, int j_per_block, const float 
     for (int j0 = j_begin + threadIdx.x * 4; j0 < j_end; j0 += kIpThreads * 4) {  // n % 4 == 0, j_per_block % 4 == 0
         const int4 *ip = reinterpret_cast<const int4 *>(idx_all + ((size_t)b * n + j0) * 3);
         const float4 *wp = reinterpret_cast<const float4 *>(weight_all + ((size_t)b * n + j0) * 3);
-        const int4 ia = ip[0], ib = ip[1], ic = ip[2];          // (i0 i1 i2 | i0) (i1 i2 | i0 i1) (i2 | i0 i1 i2) of queries j0 .. j0+3
+        int4 ia = ip[0], ib = ip[1], ic = ip[2];          // (i0 i1 i2 | i0) (i1 i2 | i0 i1) (i2 | i0 i1 i2) of queries j0 .. j0+3
+        ia.x = lds_index(ia.x, m); ia.y = lds_index(ia.y, m); ia.z = lds_index(ia.z, m); ia.w = lds_index(ia.w, m);
+        ib.x = lds_index(ib.x, m); ib.y = lds_index(ib.y, m); ib.z = lds_index(ib.z, m); ib.w = lds_index(ib.w, m);
+        ic.x = lds_index(ic.x, m); ic.y = lds_index(ic.y, m); ic.z = lds_index(ic.z, m); ic.w = lds_index(ic.w, m);
         const float4 wa = wp[0], wb = wp[1], wc = wp[2];
         const float *r = rows;
         float *dst = out_all + ((size_t)b * c + c0) * n + j0;
@@ -123,7 +126,7 @@ interp_bwd_lds_kernel(int c, int n, int m, int cc, const float *__restrict__ gra
         const int ch0 = chunk * kIpU;
         const int *__restrict__ id = idx_all + ((size_t)b * n + j) * 3;
         const float *__restrict__ w = weight_all + ((size_t)b * n + j) * 3;
-        const int i0 = id[0], i1 = id[1], i2 = id[2];
+        const int i0 = lds_index(id[0], m), i1 = lds_index(id[1], m), i2 = lds_index(id[2], m);
         const float w0 = w[0], w1 = w[1], w2 = w[2];
         float v[kIpU];
 #pragma unroll
@@ -171,7 +174,7 @@ interp_bwd_atomic_kernel(int c, int n, int m, const float *__restrict__ grad_out
 int interp_bwd_dispatch(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
                         float *grad_points, hipStream_t st) {
     if (b == 0 || c == 0 || n == 0) return PN2_OK;
-    if (scatter_cm_dispatch(3, b, c, m, n, grad_out, idx, weight, grad_points, st) == PN2_OK) return PN2_OK;  // see scatter_cm.hip
+    if (const int rc = scatter_cm_dispatch(3, b, c, m, n, grad_out, idx, weight, grad_points, st); rc != PN2_ERANGE) return rc;  // see scatter_cm.hip; only "shape not covered" falls through
     int cc = (64 * 1024) / (int)(sizeof(float) * (size_t)m);
     if (cc >= 1) {
         if (cc > 16) cc = 16;

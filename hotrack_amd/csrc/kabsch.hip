@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256)
 hand_frame_kernel(int xb, int num, int n, int j, const float *__restrict__ tmpl_all, const float *__restrict__ kp_all,
                   const int *__restrict__ palm_idx, const float *__restrict__ pts_all, float scale,
                   float *__restrict__ R_all, float *__restrict__ t_all, float *__restrict__ xyz2_all,
-                  float *__restrict__ xyz1_all, float *__restrict__ xyz2_copy, int copy_ld) {
+                  float *__restrict__ xyz1_all, float *__restrict__ xyz2_copy, int copy_ld, int *__restrict__ nonfinite) {
     __shared__ float sR[9], st[3];
     __shared__ float sy[16 * 3];
     const int b = blockIdx.x;
@@ -210,6 +210,7 @@ hand_frame_kernel(int xb, int num, int n, int j, const float *__restrict__ tmpl_
     const float *pts = pts_all + (size_t)b * n * 3;
     float *o2 = xyz2_all + (size_t)b * n * 3;
     float *o1 = xyz1_all + (size_t)b * j * 3;
+    int bad = 0;
     for (int i = threadIdx.x; i < n + j; i += 256) {
         const float *p = i < n ? pts + 3 * i : kp + 3 * (i - n);
         float *o = i < n ? o2 + 3 * i : o1 + 3 * (i - n);
@@ -219,10 +220,15 @@ hand_frame_kernel(int xb, int num, int n, int j, const float *__restrict__ tmpl_
         const float v1 = (d0 * r01 + d1 * r11 + d2 * r21) / scale;
         const float v2 = (d0 * r02 + d1 * r12 + d2 * r22) / scale;
         o[0] = v0; o[1] = v1; o[2] = v2;
+        bad |= !(fabsf(v0 + v1 + v2) < __builtin_inff());  // NaN / Inf in the cloud, the keypoints or the fit
         if (xyz2_copy && i < n) {  // second copy straight into a consumer's row buffer (three columns of a wider row)
             float *c = xyz2_copy + ((size_t)b * n + i) * copy_ld;
             c[0] = v0; c[1] = v1; c[2] = v2;
         }
+    }
+    if (nonfinite) {  // per-cloud flag for pn2x_pose_head2: a frame with a non-finite input yields NaN keypoints (as the
+        bad = __syncthreads_or(bad);  // reference, where the NaN spreads through sampling / grouping / the global max-pool)
+        if (threadIdx.x == 0) nonfinite[b] = bad;
     }
 }
 
@@ -245,6 +251,9 @@ extern "C" int pn2x_kabsch_backward(int b, int xb, int num, const float *x, cons
     return pn2::check_launch();
 }
 
+extern "C" int pn2x_hand_frame3(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
+                                const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
+                                float *xyz1, float *xyz2_copy, int copy_ld, int *nonfinite, void *stream);
 extern "C" int pn2x_hand_frame2(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
                                 const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
                                 float *xyz1, float *xyz2_copy, int copy_ld, void *stream);
@@ -258,11 +267,17 @@ extern "C" int pn2x_hand_frame(int b, int xb, int num, int n, int j, const float
 extern "C" int pn2x_hand_frame2(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
                                 const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
                                 float *xyz1, float *xyz2_copy, int copy_ld, void *stream) {
+    return pn2x_hand_frame3(b, xb, num, n, j, palm_template, kp, palm_idx, points, scale, R, t, xyz2, xyz1, xyz2_copy, copy_ld, nullptr, stream);
+}
+
+extern "C" int pn2x_hand_frame3(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
+                                const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
+                                float *xyz1, float *xyz2_copy, int copy_ld, int *nonfinite, void *stream) {
     if (xyz2_copy && copy_ld < 3) return PN2_EINVAL;
     if (b < 0 || num < 1 || num > 16 || n < 0 || j < 1 || !(xb == b || xb == 1) || !(scale > 0.f)) return PN2_EINVAL;
     if (b == 0) return PN2_OK;
     if (!palm_template || !kp || !palm_idx || !points || !R || !t || !xyz2 || !xyz1) return PN2_ENULL;
     hipLaunchKernelGGL(pn2::hand_frame_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, xb, num, n, j, palm_template, kp,
-                       palm_idx, points, scale, R, t, xyz2, xyz1, xyz2_copy, copy_ld);
+                       palm_idx, points, scale, R, t, xyz2, xyz1, xyz2_copy, copy_ld, nonfinite);
     return pn2::check_launch();
 }

@@ -81,6 +81,13 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 }
 
 // fminf without the v_max canonicalisation hipcc inserts in IEEE mode (operands are never sNaN here).
+// index into an LDS-staged array of n entries: a corrupt index (negative or >= n) must not read or update another array's
+// LDS (the global-memory kernels of the reference do not check either, but there a bad index cannot corrupt a neighbour's sums)
+__device__ __forceinline__ int lds_index(int i, int n) {
+    const unsigned u = (unsigned)i, hi = (unsigned)(n - 1);
+    return (int)(u < hi ? u : hi);
+}
+
 __device__ __forceinline__ float fmin_raw(float a, float b) {
     float r;
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

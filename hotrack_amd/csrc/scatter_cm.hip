@@ -23,13 +23,16 @@ int *stream_scratch_ints(size_t count, hipStream_t st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
-    Buf &b = bufs[((unsigned long long)dev << 48) ^ (unsigned long long)(uintptr_t)st];
-    if (b.n >= count) return b.p;
+    // Never hand out library-owned scratch to a capturing stream, even when the cached buffer is large enough: its pointer
+    // would be baked into the graph, and a later, larger eager call on this stream frees it (replays would then run on freed
+    // memory).  Captured callers take the scratch-free kernels (or pass their own scratch: pn2x_scatter_cm).
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
-        return nullptr;  // cannot allocate inside a capture
+        return nullptr;
     }
+    Buf &b = bufs[((unsigned long long)dev << 48) ^ (unsigned long long)(uintptr_t)st];
+    if (b.n >= count) return b.p;
     // the old buffer may still be in use by work already enqueued on this stream: free it in stream order
     if (b.p) (void)hipFreeAsync(b.p, st);
     const size_t want = count + count / 2;

@@ -75,7 +75,7 @@ add_layernorm_kernel(long rows, int c, const float *__restrict__ x, const float 
 __global__ void __launch_bounds__(256)
 pose_head_kernel(int tokens, int j, int c, const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ bias,
                  const float *__restrict__ xyz1, const float *__restrict__ R, const float *__restrict__ t, float scale,
-                 float *__restrict__ kp_hand, float *__restrict__ kp_cam) {
+                 float *__restrict__ kp_hand, float *__restrict__ kp_cam, const int *__restrict__ nonfinite) {
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= tokens) return;
     const int lane = threadIdx.x & 63;
@@ -89,7 +89,8 @@ pose_head_kernel(int tokens, int j, int c, const float *__restrict__ h, const fl
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
     if (lane == 0) {
         const int b = tok / j;
-        const float px = a0 + bias[0] + xyz1[3 * tok], py = a1 + bias[1] + xyz1[3 * tok + 1], pz = a2 + bias[2] + xyz1[3 * tok + 2];
+        float px = a0 + bias[0] + xyz1[3 * tok], py = a1 + bias[1] + xyz1[3 * tok + 1], pz = a2 + bias[2] + xyz1[3 * tok + 2];
+        if (nonfinite && nonfinite[b]) px = py = pz = __builtin_nanf("");  // flagged by pn2x_hand_frame3: non-finite input frame
         kp_hand[3 * tok] = px; kp_hand[3 * tok + 1] = py; kp_hand[3 * tok + 2] = pz;
         const float *Rb = R + 9 * b, *tb = t + 3 * b;
         // row vector times R^T: out_i = sum_k p_k R[i][k]
@@ -122,11 +123,17 @@ extern "C" int pn2x_add_layernorm(long rows, int c, const float *x, const float 
 
 extern "C" int pn2x_pose_head(int b, int j, int c, const float *h, const float *w, const float *bias, const float *xyz1,
                               const float *R, const float *t, float scale, float *kp_hand, float *kp_cam, void *stream) {
+    return pn2x_pose_head2(b, j, c, h, w, bias, xyz1, R, t, scale, kp_hand, kp_cam, nullptr, stream);
+}
+
+extern "C" int pn2x_pose_head2(int b, int j, int c, const float *h, const float *w, const float *bias, const float *xyz1,
+                               const float *R, const float *t, float scale, float *kp_hand, float *kp_cam, const int *nonfinite,
+                               void *stream) {
     if (b < 0 || j < 1 || c < 1) return PN2_EINVAL;
     if (b == 0) return PN2_OK;
     if (!h || !w || !bias || !xyz1 || !R || !t || !kp_hand || !kp_cam) return PN2_ENULL;
     const int tokens = b * j;
     hipLaunchKernelGGL(pose_head_kernel, dim3((tokens + 3) / 4), dim3(256), 0, (hipStream_t)stream, tokens, j, c, h, w, bias, xyz1,
-                       R, t, scale, kp_hand, kp_cam);
+                       R, t, scale, kp_hand, kp_cam, nonfinite);
     return check_launch();
 }

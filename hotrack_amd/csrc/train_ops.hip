@@ -48,6 +48,9 @@ __device__ __forceinline__ void bn_consts(BnCh &k, int C, int c0, long rows, con
     }
 }
 
+// ReLU that propagates NaN like torch's (fmaxf(NaN, 0) is 0): a diverged step must show up in the loss, not vanish in a max
+__device__ __forceinline__ float relu_nan(float h) { return !(h <= 0.f) ? h : 0.f; }
+
 __device__ __forceinline__ float bn_act(float y, const BnCh &k, int i) {
     return ((y - k.mean[i]) * k.invstd[i]) * k.g[i] + k.b[i];  // torch's evaluation order
 }
@@ -139,7 +142,7 @@ bn_relu_apply_kernel(long rows, int C, const float *__restrict__ Y, int ldy, con
         const float4 v = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
         float4 h;
         h.x = bn_act(v.x, k, 0); h.y = bn_act(v.y, k, 1); h.z = bn_act(v.z, k, 2); h.w = bn_act(v.w, k, 3);
-        if (relu) { h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f); }
+        if (relu) { h.x = relu_nan(h.x); h.y = relu_nan(h.y); h.z = relu_nan(h.z); h.w = relu_nan(h.w); }
         *reinterpret_cast<float4 *>(H + r * ldh + 4 * q) = h;
     }
 }
@@ -192,9 +195,9 @@ bn_relu_max_kernel(long groups, int K, int C, const float *__restrict__ Y, int l
         const float h[4] = {bn_act(v.x, k, 0), bn_act(v.y, k, 1), bn_act(v.z, k, 2), bn_act(v.w, k, 3)};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (h[i] > m[i]) { m[i] = h[i]; am[i] = kk; }
+            if (h[i] > m[i] || h[i] != h[i]) { m[i] = h[i]; am[i] = kk; }  // a NaN sticks (h > NaN is false afterwards), as torch's max
     }
-    *reinterpret_cast<float4 *>(out + grp * C + 4 * q) = make_float4(fmaxf(m[0], 0.f), fmaxf(m[1], 0.f), fmaxf(m[2], 0.f), fmaxf(m[3], 0.f));
+    *reinterpret_cast<float4 *>(out + grp * C + 4 * q) = make_float4(relu_nan(m[0]), relu_nan(m[1]), relu_nan(m[2]), relu_nan(m[3]));
     *reinterpret_cast<int4 *>(arg + grp * C + 4 * q) = make_int4(am[0], am[1], am[2], am[3]);
 }
 
@@ -401,12 +404,12 @@ scatter_rows_lds_kernel(int n_dst, int m_src, int C, int cc, const float *__rest
             const float *w = weight + ((size_t)b * m_src + j) * 3;
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                float *dst = slab + id[t] * cc + 4 * q;
+                float *dst = slab + lds_index(id[t], n_dst) * cc + 4 * q;
                 const float wt = w[t];
                 atomicAdd(dst + 0, wt * v.x); atomicAdd(dst + 1, wt * v.y); atomicAdd(dst + 2, wt * v.z); atomicAdd(dst + 3, wt * v.w);
             }
         } else {
-            float *dst = slab + idx[(size_t)b * m_src + j] * cc + 4 * q;
+            float *dst = slab + lds_index(idx[(size_t)b * m_src + j], n_dst) * cc + 4 * q;
             atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
         }
     }

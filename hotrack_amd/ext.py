@@ -308,6 +308,8 @@ _lib.pn2x_hand_frame.argtypes = [_ci] * 5 + [_vp] * 4 + [ctypes.c_float] + [_vp]
 _lib.pn2x_hand_frame.restype = _ci
 _lib.pn2x_hand_frame2.argtypes = [_ci] * 5 + [_vp] * 4 + [ctypes.c_float] + [_vp] * 5 + [_ci, _vp]
 _lib.pn2x_hand_frame2.restype = _ci
+_lib.pn2x_hand_frame3.argtypes = [_ci] * 5 + [_vp] * 4 + [ctypes.c_float] + [_vp] * 5 + [_ci, _vp, _vp]
+_lib.pn2x_hand_frame3.restype = _ci
 
 
 def _xyz_cols(t: torch.Tensor, name: str, B: int, R: int):
@@ -319,10 +321,10 @@ def _xyz_cols(t: torch.Tensor, name: str, B: int, R: int):
 
 
 def hand_frame(palm_template: torch.Tensor, kp: torch.Tensor, palm_idx: torch.Tensor, points: torch.Tensor, scale: float,
-               xyz2_copy: torch.Tensor = None):
+               xyz2_copy: torch.Tensor = None, nonfinite: torch.Tensor = None):
     """Kabsch(palm_template -> kp[:, palm_idx]) + canonicalisation in one launch.
     Returns R (B,3,3), t (B,3,1), xyz2 (B,N,3), xyz1 (B,J,3).  xyz2_copy: a (B,N,3) column block of a consumer's row
-    buffer that receives a second copy of xyz2."""
+    buffer that receives a second copy of xyz2.  nonfinite: (B,) int32 that receives 1 for frames with a NaN / Inf input."""
     if palm_template.dim() == 2:
         palm_template = palm_template.unsqueeze(0)
     palm_template, kp, points = palm_template.float().contiguous(), kp.float().contiguous(), points.float().contiguous()
@@ -336,18 +338,20 @@ def hand_frame(palm_template: torch.Tensor, kp: torch.Tensor, palm_idx: torch.Te
     xyz1 = torch.empty((B, J, 3), dtype=f32, device=points.device)
     pc, ldc = (None, 0) if xyz2_copy is None else _xyz_cols(xyz2_copy, "xyz2_copy", B, N)
     with torch.cuda.device(points.device):
-        _native._check(_lib.pn2x_hand_frame2(B, xb, num, N, J, _native._ptr(palm_template, "palm_template", f32, xb * num * 3),
+        _native._check(_lib.pn2x_hand_frame3(B, xb, num, N, J, _native._ptr(palm_template, "palm_template", f32, xb * num * 3),
                                              _native._ptr(kp, "kp", f32, B * J * 3), _native._ptr(palm_idx, "palm_idx", torch.int32, num),
                                              _native._ptr(points, "points", f32, B * N * 3), float(scale), R.data_ptr(), t.data_ptr(),
-                                             xyz2.data_ptr(), xyz1.data_ptr(), pc, ldc, _native._stream(points)), "hand_frame")
+                                             xyz2.data_ptr(), xyz1.data_ptr(), pc, ldc,
+                                             None if nonfinite is None else _native._ptr(nonfinite, "nonfinite", torch.int32, B),
+                                             _native._stream(points)), "hand_frame")
     return R, t, xyz2, xyz1
 
 
 _cf = ctypes.c_float
 _lib.pn2x_add_layernorm.argtypes = [_cl, _ci, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _cf, _vp, _vp]
 _lib.pn2x_add_layernorm.restype = _ci
-_lib.pn2x_pose_head.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp]
-_lib.pn2x_pose_head.restype = _ci
+_lib.pn2x_pose_head2.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp]
+_lib.pn2x_pose_head2.restype = _ci
 
 
 def add_layernorm(x: torch.Tensor, ln1, y: torch.Tensor = None, bias: torch.Tensor = None, ln2=None) -> torch.Tensor:
@@ -373,7 +377,8 @@ def add_layernorm(x: torch.Tensor, ln1, y: torch.Tensor = None, bias: torch.Tens
     return out
 
 
-def pose_head(h: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xyz1: torch.Tensor, R: torch.Tensor, t: torch.Tensor, scale: float):
+def pose_head(h: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xyz1: torch.Tensor, R: torch.Tensor, t: torch.Tensor, scale: float,
+              nonfinite: torch.Tensor = None):
     """h (B*J, C), w (3, C), bias (3,), xyz1 (B,J,3), R (B,3,3), t (B,3,1) -> (kp_hand (B,J,3), kp_cam (B,J,3)):
     kp_hand = h w^T + bias + xyz1;  kp_cam = (kp_hand R^T) * scale + t  (include/pn2_ext.h: pn2x_pose_head)."""
     B, J, _ = xyz1.shape
@@ -384,8 +389,9 @@ def pose_head(h: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xyz1: torch.
     kp_hand = torch.empty((B, J, 3), dtype=f32, device=h.device)
     kp_cam = torch.empty((B, J, 3), dtype=f32, device=h.device)
     with torch.cuda.device(h.device):
-        _native._check(_lib.pn2x_pose_head(B, J, C, *ptrs, float(scale), kp_hand.data_ptr(), kp_cam.data_ptr(), _native._stream(h)),
-                       "pose_head")
+        _native._check(_lib.pn2x_pose_head2(B, J, C, *ptrs, float(scale), kp_hand.data_ptr(), kp_cam.data_ptr(),
+                                            None if nonfinite is None else _native._ptr(nonfinite, "nonfinite", torch.int32, B),
+                                            _native._stream(h)), "pose_head")
     return kp_hand, kp_cam
 
 

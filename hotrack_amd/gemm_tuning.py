@@ -12,8 +12,79 @@ from __future__ import annotations
 
 import os
 
-RESULTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
-_state = {"done": False, "on": False}
+RESULTS = os.environ.get("PN2_TUNED_GEMMS_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+_state = {"done": False, "on": False, "status": "off", "detail": None}
+
+# Sentinel shapes of the start-up self-test (rows, in, out): the largest GEMM of a 64-cloud forward and the batch-1 layer-1
+# GEMM of the keypoint branches, whose default-heuristic solution was 10x slower than the recorded one.
+SENTINELS = ((65536, 384, 256), (1024, 384, 512))
+
+
+def recorded_on() -> dict:
+    """The library versions the shipped table was recorded on (its TunableOp validator rows)."""
+    out = {}
+    try:
+        for line in open(RESULTS):
+            f = line.strip().split(",")
+            if len(f) >= 3 and f[0] == "Validator":
+                out[f[1]] = ",".join(f[2:])
+    except OSError:
+        pass
+    return out
+
+
+def _time_linear(x, w, scoped: bool) -> float:
+    import torch
+    import torch.nn.functional as F
+    import torch.cuda.tunable as tunable
+    was = tunable.is_enabled()
+    tunable.enable(bool(scoped))
+    try:
+        for _ in range(3):
+            F.linear(x, w)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            F.linear(x, w)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / 10.0
+    finally:
+        tunable.enable(was)
+
+
+def _self_test(loaded: bool):
+    """Does the table do what it was shipped for ON THIS INSTALLATION?  Solution indices are only valid for the hipBLASLt /
+    rocBLAS build they were recorded on; TunableOp's validators reject a table from another build (`loaded` False), and a
+    table that loads but loses on the sentinel shapes is switched off.  Logged once; bench.py reports `gemm_table`."""
+    import sys
+    import torch
+    if not loaded:
+        _state["status"], _state["detail"] = "stale", {"reason": "TunableOp rejected the table (validators: recorded on %s)" % recorded_on()}
+    elif torch.cuda.is_current_stream_capturing():
+        _state["status"], _state["detail"] = "applied", {"reason": "first use inside a stream capture: sentinel timing skipped"}
+        return
+    else:
+        detail, lost = {}, False
+        for rows, cin, cout in SENTINELS:
+            x = torch.randn(rows, cin, device="cuda")
+            w = torch.randn(cout, cin, device="cuda")
+            t_tab, t_def = _time_linear(x, w, True), _time_linear(x, w, False)
+            detail["%dx%d->%d" % (rows, cin, cout)] = {"table_ms": round(t_tab, 4), "default_ms": round(t_def, 4)}
+            lost |= t_tab > 1.25 * t_def
+        _state["detail"] = detail
+        _state["status"] = "stale" if lost else "applied"
+        if lost:
+            _state["on"] = False
+    if _state["status"] == "stale":
+        print("hotrack_amd.gemm_tuning: the shipped GEMM solution table does not apply to this installation (%s); the library's "
+              "default heuristic is used -- re-record it with scripts/tune_gemms.py" % (_state["detail"],), file=sys.stderr, flush=True)
+
+
+def status() -> dict:
+    """{"gemm_table": "applied" | "stale" | "off", "detail": ...} after the first enable()."""
+    enable()
+    return {"gemm_table": _state["status"], "detail": _state["detail"]}
 
 
 def enable() -> bool:
@@ -35,6 +106,7 @@ def enable() -> bool:
     tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "pn2_tunableop_%d.csv" % os.getpid()))
     _state["on"] = bool(tunable.read_file(RESULTS))
     tunable.enable(False)  # the table stays loaded; `scope()` switches it on around the inference path only
+    _self_test(_state["on"])
     return _state["on"]
 
 

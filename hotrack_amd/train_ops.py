@@ -59,15 +59,30 @@ def _rows2d(t: torch.Tensor, name: str):
 
 class Workspace:
     """Zeroed fp64 accumulators for the BatchNorm reductions of one training step: reset() = one fill launch, take(n)
-    hands out consecutive slices.  The capacity grows on demand outside graph capture."""
+    hands out consecutive slices (fixed capacity: take() raises when it is exhausted).
+
+    A slice handed out for a BACKWARD reduction is only valid for the first backward of the forward that took it, and only
+    while no later forward has reset the workspace: `generation` counts the resets, `backward_slice()` returns the slice when
+    it is still this forward's and has not been used, and a freshly zeroed tensor otherwise (gradient accumulation over two
+    forwards, retain_graph / a second autograd.grad through the same graph) -- never sums into stale or already-used
+    accumulators."""
 
     def __init__(self, device, capacity: int = 1 << 19):
         self.buf = torch.zeros(capacity, dtype=torch.float64, device=device)
         self.used = 0
+        self.generation = 0
 
     def reset(self):
         self.buf.zero_()
         self.used = 0
+        self.generation += 1
+
+    def backward_slice(self, ctx) -> torch.Tensor:
+        """The zeroed accumulator of ctx's backward (ctx.ws, ctx.ws_b, ctx.ws_gen set in forward)."""
+        if ctx.ws_gen == self.generation and not getattr(ctx, "ws_used", False):
+            ctx.ws_used = True
+            return ctx.ws_b
+        return torch.zeros(ctx.ws_b.numel(), dtype=torch.float64, device=ctx.ws_b.device)
 
     def take(self, n: int) -> torch.Tensor:
         if self.used + n > self.buf.numel():
@@ -79,7 +94,7 @@ class Workspace:
 
 class _BnRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, conv_bias, running_mean, running_var, nbt, eps, momentum, relu, ws_f, ws_b):
+    def forward(ctx, y, gamma, beta, conv_bias, running_mean, running_var, nbt, eps, momentum, relu, ws_f, ws_b, ws):
         py, ldy = _rows2d(y, "y")
         R, C = y.shape
         h = torch.empty((R, C), dtype=_f32, device=y.device)
@@ -93,6 +108,7 @@ class _BnRelu(torch.autograd.Function):
                            "bn_relu_apply")
         ctx.save_for_backward(y, gamma, beta, saved)
         ctx.ws_b, ctx.relu, ctx.has_bias = ws_b, relu, conv_bias is not None
+        ctx.ws, ctx.ws_gen = ws, ws.generation
         return h
 
     @staticmethod
@@ -102,11 +118,12 @@ class _BnRelu(torch.autograd.Function):
         R, C = y.shape
         dy = torch.empty((R, C), dtype=_f32, device=y.device)
         dpar = torch.empty((3, C), dtype=_f32, device=y.device)
+        sums = ctx.ws.backward_slice(ctx)
         with torch.cuda.device(y.device):
             _native._check(_lib.pn2x_bn_relu_bwd(R, C, dh.data_ptr(), C, y.data_ptr(), y.stride(0), saved[0].data_ptr(), saved[1].data_ptr(),
-                                                 gamma.data_ptr(), beta.data_ptr(), 1 if ctx.relu else 0, ctx.ws_b.data_ptr(), dy.data_ptr(), C,
+                                                 gamma.data_ptr(), beta.data_ptr(), 1 if ctx.relu else 0, sums.data_ptr(), dy.data_ptr(), C,
                                                  dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(), _native._stream(y)), "bn_relu_bwd")
-        return dy, dpar[0], dpar[1], (dpar[2] if ctx.has_bias else None), None, None, None, None, None, None, None, None
+        return dy, dpar[0], dpar[1], (dpar[2] if ctx.has_bias else None), None, None, None, None, None, None, None, None, None
 
 
 def bn_relu(y: torch.Tensor, bn: torch.nn.Module, ws: Workspace, conv_bias: torch.Tensor = None, relu: bool = True) -> torch.Tensor:
@@ -117,12 +134,12 @@ def bn_relu(y: torch.Tensor, bn: torch.nn.Module, ws: Workspace, conv_bias: torc
     track = bn.track_running_stats and bn.running_mean is not None
     return _BnRelu.apply(y, bn.weight, bn.bias, conv_bias, bn.running_mean if track else None, bn.running_var if track else None,
                          bn.num_batches_tracked if track else None, bn.eps, bn.momentum if bn.momentum is not None else 0.1, relu,
-                         ws.take(_lib.pn2x_bn_sums_doubles(C)), ws.take(_lib.pn2x_bn_sums_doubles(C)))
+                         ws.take(_lib.pn2x_bn_sums_doubles(C)), ws.take(_lib.pn2x_bn_sums_doubles(C)), ws)
 
 
 class _BnReluMax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, K, gamma, beta, conv_bias, running_mean, running_var, nbt, eps, momentum, ws_f, ws_b):
+    def forward(ctx, y, K, gamma, beta, conv_bias, running_mean, running_var, nbt, eps, momentum, ws_f, ws_b, ws):
         py, ldy = _rows2d(y, "y")
         R, C = y.shape
         G = R // K
@@ -137,6 +154,7 @@ class _BnReluMax(torch.autograd.Function):
                                                  saved[1].data_ptr(), out.data_ptr(), arg.data_ptr(), st), "bn_relu_max")
         ctx.save_for_backward(y, gamma, beta, saved, arg)
         ctx.ws_b, ctx.K, ctx.has_bias = ws_b, K, conv_bias is not None
+        ctx.ws, ctx.ws_gen = ws, ws.generation
         return out
 
     @staticmethod
@@ -146,12 +164,13 @@ class _BnReluMax(torch.autograd.Function):
         R, C = y.shape
         dy = torch.empty((R, C), dtype=_f32, device=y.device)
         dpar = torch.empty((3, C), dtype=_f32, device=y.device)
+        sums = ctx.ws.backward_slice(ctx)
         with torch.cuda.device(y.device):
             _native._check(_lib.pn2x_bn_relu_max_bwd(R // ctx.K, ctx.K, C, dout.data_ptr(), arg.data_ptr(), y.data_ptr(), y.stride(0),
                                                      saved[0].data_ptr(), saved[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                     ctx.ws_b.data_ptr(), dy.data_ptr(), C, dpar[0].data_ptr(), dpar[1].data_ptr(),
+                                                     sums.data_ptr(), dy.data_ptr(), C, dpar[0].data_ptr(), dpar[1].data_ptr(),
                                                      dpar[2].data_ptr(), _native._stream(y)), "bn_relu_max_bwd")
-        return dy, None, dpar[0], dpar[1], (dpar[2] if ctx.has_bias else None), None, None, None, None, None, None, None
+        return dy, None, dpar[0], dpar[1], (dpar[2] if ctx.has_bias else None), None, None, None, None, None, None, None, None
 
 
 def bn_relu_max(y: torch.Tensor, K: int, bn: torch.nn.Module, ws: Workspace, conv_bias: torch.Tensor = None) -> torch.Tensor:
@@ -165,7 +184,7 @@ def bn_relu_max(y: torch.Tensor, K: int, bn: torch.nn.Module, ws: Workspace, con
     n = _lib.pn2x_bn_sums_doubles(C)
     return _BnReluMax.apply(y, K, bn.weight, bn.bias, conv_bias, bn.running_mean if track else None, bn.running_var if track else None,
                             bn.num_batches_tracked if track else None, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-                            ws.take(n), ws.take(n))
+                            ws.take(n), ws.take(n), ws)
 
 
 def inverse_index(idx: torch.Tensor, n_dst: int):

@@ -48,6 +48,13 @@ int pn2x_hand_frame(int b, int xb, int num, int n, int j, const float *palm_temp
 int pn2x_hand_frame2(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
                      const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
                      float *xyz1, float *xyz2_copy, int copy_ld, void *stream);
+/* ... and a per-cloud flag nonfinite[b] (device int32, b entries, or NULL): 1 when the cloud, the keypoints or the fit of
+ * cloud b contain a NaN / Inf.  Handed to pn2x_pose_head2, it turns that frame's predicted keypoints into NaN: the
+ * fused inference kernels drop NaNs in their ReLU / max-pool maxima (built -fno-honor-nans), whereas in the reference a
+ * non-finite input point spreads through sampling, grouping and the global max-pool to every output of its frame. */
+int pn2x_hand_frame3(int b, int xb, int num, int n, int j, const float *palm_template, const float *kp,
+                     const int *palm_idx, const float *points, float scale, float *R, float *t, float *xyz2,
+                     float *xyz1, float *xyz2_copy, int copy_ld, int *nonfinite, void *stream);
 
 /*
  * Fused grouped MLP + max of one set-abstraction scale, eval mode (BatchNorm folded into the
@@ -182,6 +189,10 @@ int pn2x_add_layernorm(long rows, int c, const float *x, const float *y, const f
  */
 int pn2x_pose_head(int b, int j, int c, const float *h, const float *w, const float *bias, const float *xyz1,
                    const float *R, const float *t, float scale, float *kp_hand, float *kp_cam, void *stream);
+/* ... with the per-cloud flags of pn2x_hand_frame3 (or NULL): flagged frames get NaN keypoints in both frames. */
+int pn2x_pose_head2(int b, int j, int c, const float *h, const float *w, const float *bias, const float *xyz1,
+                    const float *R, const float *t, float scale, float *kp_hand, float *kp_cam, const int *nonfinite,
+                    void *stream);
 
 /*
  * Both scales of a keypoint-query module (reference PointNetSetAbstractionMsg_GivenCenterPoints, pointnet_utils.py:536-590:

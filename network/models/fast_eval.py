@@ -97,6 +97,16 @@ class FastEval:
         key = self._versions()
         if not force and self._key == key:
             return self.P
+        # NaN contract of this path (tests/test_gpu_fused.py::test_fast_path_nan_contract): the fused kernels drop NaNs in
+        # their ReLU / max-pool maxima, so (a) non-finite WEIGHTS (a diverged checkpoint) are detected here, once per weight
+        # change, and the network then runs the module path, which propagates them like torch / the reference;
+        # (b) non-finite INPUT frames are flagged on the device by the hand-frame kernel and get NaN keypoints from the head.
+        with torch.no_grad():
+            ts = [t for t in list(self.net.parameters()) + list(self.net.buffers()) if t.is_floating_point()]
+            self.finite_weights = bool(torch.stack([torch.isfinite(t).all() for t in ts]).all().item()) if ts else True
+        if not self.finite_weights:
+            self.P, self._key = None, key
+            return None
         from hotrack_amd import gemm_tuning
         from hotrack_amd.fused import fold_conv_bn as fold
         gemm_tuning.enable()  # load the gfx950 solution table for the library GEMMs (no-op if absent / disabled)
@@ -205,6 +215,8 @@ class FastEval:
         from hotrack_amd import pointnet2_utils as ops
         net = self.net
         P = self.prepare()
+        if P is None:
+            return None
         dev = net.device
         if flag_dict["track_flag"]:
             palm = input["pred_palm_template"]
@@ -227,8 +239,9 @@ class FastEval:
         # fp1's input rows [interp(l1 -> l0) | xyz | pad] exist from the start: the hand-frame kernel drops its xyz copy there
         c_i = P["fp2"][-1][0].shape[0]
         fp1_in = torch.empty((B, N, c_i + 4), **f32)
+        nonfinite = torch.empty(B, dtype=torch.int32, device=pts.device)  # per-frame NaN / Inf flag (see prepare())
         R, t, xyz2, xyz1 = ext.hand_frame(palm.contiguous(), kp.contiguous(), palm_idx, pts.contiguous(), 0.2,
-                                          xyz2_copy=fp1_in[:, :, c_i:c_i + 3])
+                                          xyz2_copy=fp1_in[:, :, c_i:c_i + 3], nonfinite=nonfinite)
         scale = self._scale(pts.device)
         canon = {"scale": scale, "rotation": R, "translation": t}
         tt = t.transpose(1, 2)
@@ -340,7 +353,7 @@ class FastEval:
             x = ext.add_layernorm(x, blk.norm2, y=F.linear(hdn, blk.linear2.weight), bias=blk.linear2.bias, ln2=nxt)
         hdn = _lin_relu(x, net.final_mlp[0].weight.squeeze(-1), net.final_mlp[0].bias)
         # head: last 1x1 conv + residual on the initial keypoints + back to the camera frame, one launch
-        pred_hf, pred_kp = ext.pose_head(hdn, P["head_w"], net.final_mlp[2].bias, xyz1, R, t, 0.2)
+        pred_hf, pred_kp = ext.pose_head(hdn, P["head_w"], net.final_mlp[2].bias, xyz1, R, t, 0.2, nonfinite=nonfinite)
 
         ret = {"canon_pose": canon}
         ret["pred_kp_handframe"] = pred_hf.transpose(1, 2)

@@ -106,7 +106,17 @@ class HandTrackNet(nn.Module):
             # configurations / sizes the point-major path does not cover use the module path below (same results)
             if (self._fast is not False and input["jittered_hand_kp"].shape[1] == 21
                     and input["hand_points"].shape[1] <= self._fast.MAX_POINTS):
-                return self._fast.forward(input, flag_dict)
+                out = self._fast.forward(input, flag_dict)
+                if out is not None:
+                    return out
+                # None: non-finite weights (diverged checkpoint).  The fused kernels drop NaNs in their maxima, so this forward
+                # runs the unfused module path, which propagates them like torch / the reference.
+                saved = pointnet_utils.fused_backend()
+                pointnet_utils.set_fused_backend(None)
+                try:
+                    return self.forward(input, flag_dict)
+                finally:
+                    pointnet_utils.set_fused_backend(saved)
         dev = self.device
         if flag_dict["track_flag"]:
             palm_template = input["pred_palm_template"]

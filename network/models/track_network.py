@@ -26,7 +26,8 @@ class HandTrackModel(nn.Module):
     # A captured graph bakes in the pointers of the BN-folded weights FastEval built at capture time: anything that can
     # change the weights (checkpoint load, fine-tuning, .to()/.float()) drops the captured graphs.
     def train(self, mode: bool = True):
-        self._graphs.clear()
+        if mode or mode != self.training:  # eval() on a model already in eval mode (Trainer.test per sequence) keeps the graphs
+            self._graphs.clear()
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):

@@ -229,9 +229,12 @@ class Trainer(nn.Module):
     # ---- "flat" data parallelism: one all-reduce of all gradients -----------------------------------------------------
     def _allreduce_flat(self):
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        if not grads:
+            return  # nothing received a gradient on this rank (and, by the layout check below, on no rank)
         n = sum(g.numel() for g in grads)
         if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
             self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+            self._check_flat_layout(n, len(grads))
         self._flat_grads = grads
         torch.cat([g.reshape(-1) for g in grads], out=self._flat)
         if dist.get_backend() == "nccl":
@@ -240,7 +243,30 @@ class Trainer(nn.Module):
             dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
             self._flat.div_(self.world)
 
+    def _check_flat_layout(self, numel, count):
+        """The flat exchange assumes every rank holds the same set of non-None gradients (same code path, same shapes: a
+        DistributedSampler with drop_last).  Checked whenever the layout is (re)built -- on every rank at the same step if the
+        assumption holds; a mismatch raises on all ranks instead of silently misaligning gradients."""
+        t = torch.tensor([numel, -numel, count, -count], dtype=torch.int64,
+                         device=self._flat.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mx_n, mn_n, mx_c, mn_c = int(t[0]), -int(t[1]), int(t[2]), -int(t[3])
+        if mx_n != mn_n or mx_c != mn_c:
+            raise RuntimeError(f"dp=flat: gradient layouts differ across ranks (numel {mn_n}..{mx_n}, tensors {mn_c}..{mx_c}): "
+                               "a data-dependent branch produced different parameter uses; use dp=ddp for such models")
+
+    def _agree(self, ok: bool) -> bool:
+        """Collective AND over ranks (capture / fallback decisions must be taken by all ranks together: a rank that falls
+        back to eager alone would issue a different number of collectives)."""
+        if self.world == 1 or self.dp_mode != "flat":
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+
     def _scatter_flat(self):
+        if not self._flat_grads:
+            return
         views, off = [], 0
         for g in self._flat_grads:
             views.append(self._flat[off:off + g.numel()].view_as(g))
@@ -251,12 +277,21 @@ class Trainer(nn.Module):
         self.model.train()
         loss_dict = None
         if getattr(self, "graph_step", False) and self.ddp is None and torch.cuda.is_available():  # ("ddp" mode stays eager)
-            try:
-                loss_dict = dict(self._graphed_step(data))
-            except RuntimeError as exc:  # an op of this configuration cannot be captured: stay eager from now on
-                self.log_string(f"graph_step disabled ({exc})")
-                self.graph_step, self._graph = False, None
-                torch.cuda.synchronize()
+            sig = tuple((path, tuple(t.shape), t.dtype) for path, t in self._leaves(data))
+            if self._graph is None or sig != self._graph_sig:
+                # (re)capture: ranks see same-shaped batches, so all of them are here together; whether the capture worked
+                # is agreed collectively, so either every rank replays graphs from now on or every rank stays eager
+                err = None
+                try:
+                    self._capture(data, sig)
+                except RuntimeError as exc:  # an op of this configuration cannot be captured
+                    err = exc
+                    torch.cuda.synchronize()
+                if not self._agree(err is None):
+                    self.log_string(f"graph_step disabled ({err or 'capture failed on another rank'})")
+                    self.graph_step, self._graph, self._opt_graph = False, None, None
+            if self.graph_step:
+                loss_dict = dict(self._graphed_step(data, sig))
         if loss_dict is None:
             loss_dict = self._step(data)
         self.iteration += 1
@@ -273,8 +308,9 @@ class Trainer(nn.Module):
             elif torch.is_tensor(v):
                 yield prefix + (k,), v
 
-    def _graphed_step(self, data):
-        sig = tuple((path, tuple(t.shape), t.dtype) for path, t in self._leaves(data))
+    def _graphed_step(self, data, sig=None):
+        if sig is None:
+            sig = tuple((path, tuple(t.shape), t.dtype) for path, t in self._leaves(data))
         if self._graph is None or sig != self._graph_sig:
             self._capture(data, sig)
         for (_, dst), (_, src) in zip(self._leaves(self._static), self._leaves(data)):

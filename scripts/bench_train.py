@@ -13,6 +13,68 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
+def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce=True):
+    """configs[2] per GPU on an already initialised process group (or a single process): returns the result dict (every
+    rank; times are max over ranks).  Used by main() below and by bench.py's `train` leg when WORLD_SIZE > 1."""
+    os.environ.setdefault("HOTRACK_DATA_ROOT", "/tmp/hotrack_bench_data")
+    from configs.config import get_config
+    from datasets.synthetic import make_frame
+    from parse_args import add_args
+    from trainer import Trainer
+    args = add_args(argparse.ArgumentParser()).parse_args(["--config", "handtracknet_train_SimGrasp.yml"])
+    args.num_points, args.batch_size = 1024, batch
+    cfg = get_config(args, save=False)
+    cfg["graph_step"] = graph  # data parallel: forward+backward graph | eager flat all-reduce | Adam graph
+    torch.manual_seed(0)
+    tr = Trainer(cfg)
+    tr.step_epoch()
+    batches = [torch.utils.data.default_collate([make_frame(1000 * rank + 64 * j + i, 1024, 0.02) for i in range(batch)]) for j in range(4)]
+    batches = [{k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in b.items()} for b in batches]
+    on_dev = world > 1 and dist.get_backend() == "nccl"
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def reduce_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], device="cuda" if on_dev else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+    for i in range(warmup):
+        loss = tr.update(batches[i % 4])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = tr.update(batches[i % 4])
+    sync()
+    local = time.perf_counter() - t0
+    dt = reduce_max(local)
+    res = {"metric": "HandTrackNet training frames/sec (N=1024)", "value": round(batch * world * steps / dt, 1),
+           "unit": "frames/s", "n_gpus": world, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "per_gpu_batch": batch,
+           "scaling": "weak", "graph_step": bool(getattr(tr, "graph_step", False)), "dp_mode": tr.dp_mode,
+           "loss": float(loss["total_loss"]), "dtype": "f32", "data": "synthetic"}
+    if world > 1:
+        res["backend"] = dist.get_backend()  # "nccl" = RCCL on ROCm
+        res["world_size_seen_by_backend"] = dist.get_world_size()
+        if measure_allreduce and tr.dp_mode == "flat" and tr._flat is not None:
+            # the gradient exchange alone: the same flat buffer the step all-reduces, K times back to back
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                tr._allreduce_flat()
+            sync()
+            res["allreduce_us"] = round(reduce_max(time.perf_counter() - t0) / 20 * 1e6, 1)
+            res["bytes"] = int(tr._flat.numel() * tr._flat.element_size())
+            # ring all-reduce moves 2 (N-1)/N of the buffer per rank
+            res["allreduce_busbw_GBs"] = round(2 * (world - 1) / world * res["bytes"] / (res["allreduce_us"] * 1e-6) / 1e9, 2)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
@@ -25,42 +87,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("PN2_DIST_BACKEND", "nccl"))  # gloo: several ranks on one GPU (self-test)
-    os.environ.setdefault("HOTRACK_DATA_ROOT", "/tmp/hotrack_bench_data")
-    from configs.config import get_config
-    from datasets.synthetic import make_frame
-    from parse_args import add_args
-    from trainer import Trainer
-    args = add_args(argparse.ArgumentParser()).parse_args(["--config", "handtracknet_train_SimGrasp.yml"])
-    args.num_points, args.batch_size = 1024, a.batch
-    cfg = get_config(args, save=False)
-    cfg["graph_step"] = a.graph  # data parallel: forward+backward graph | eager flat all-reduce | Adam graph
-    torch.manual_seed(0)
-    tr = Trainer(cfg)
-    tr.step_epoch()
-    batches = [torch.utils.data.default_collate([make_frame(1000 * rank + 64 * j + i, 1024, 0.02) for i in range(a.batch)]) for j in range(4)]
-    batches = [{k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in b.items()} for b in batches]
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-    for i in range(a.warmup):
-        loss = tr.update(batches[i % 4])
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss = tr.update(batches[i % 4])
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    res = run_training_leg(a.steps, a.warmup, a.batch, a.graph, rank, world)
     if rank == 0:
-        print(json.dumps({"metric": "HandTrackNet training frames/sec (N=1024)", "value": round(a.batch * world * a.steps / dt, 1),
-                          "unit": "frames/s", "n_gpus": world, "ms_per_step": round(dt / a.steps * 1e3, 2), "per_gpu_batch": a.batch,
-                          "scaling": "weak", "graph_step": bool(getattr(tr, "graph_step", False)), "dp_mode": tr.dp_mode, "loss": float(loss["total_loss"]), "dtype": "f32", "data": "synthetic"}))
+        print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 

@@ -13,13 +13,19 @@ one=$(python bench.py --gpus 1 --steps 5 --warmup 2 --min-time 0.2 --no-cpu-base
 for N in $Ns; do
   port=$((29600 + N))
   line=$(PN2_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
-         --master-port $port bench.py --gpus $N --steps 5 --warmup 2 --min-time 0.2 --no-cpu-baseline | grep '^{')
+         --master-port $port bench.py --gpus $N --steps 5 --warmup 2 --min-time 0.2 --train-steps 5 --no-cpu-baseline | grep '^{')
   python - "$N" "$line" "$one" <<'PY'
 import json, sys
 n, d, one = int(sys.argv[1]), json.loads(sys.argv[2]), json.loads(sys.argv[3])
 assert d["n_gpus"] == n and d["config"]["world_size"] == n, d
 assert d["config"]["global_batch"] == n * d["config"]["per_gpu_batch"] and d["scaling"] == "weak"
 assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
+# the multi-GPU extras: per-rank spread of the headline and the data-parallel training leg that shows the gradient all-reduce
+pr, tr = d["per_rank_frames_per_s"], d["train"]
+assert len(pr["ranks"]) == n and pr["min"] <= pr["max"]
+assert tr["n_gpus"] == n and tr["world_size_seen_by_backend"] == n and tr["dp_mode"] == "flat" and tr["graph_step"] is True, tr
+assert tr["backend"] == "gloo" and tr["bytes"] > 16e6 and tr["allreduce_us"] > 0 and tr["ms_per_step"] > 0, tr
+assert d["replay_check"]["max_abs_diff_pred_kp"] <= 1e-5 and d["gemm_table"] in ("applied", "stale", "off")
 # N ranks time-share one GPU here, so the aggregate stays near the 1-rank number (it must NOT be N times smaller or larger)
 print(f"bench --gpus {n}: ok  n_gpus={d['n_gpus']} world_size={d['config']['world_size']} value={d['value']:.0f} frames/s "
       f"(1 rank on the same GPU: {one['value']:.0f})")

@@ -115,5 +115,8 @@ def test_tuned_gemm_table_is_well_formed():
     assert any(r[0] == "Validator" and r[1] == "GCN_ARCH_NAME" and r[2].startswith("gfx950") for r in rows)
     ops = [r for r in rows if r[0] != "Validator"]
     assert len(ops) > 50 and all(len(r) >= 3 and r[0].startswith("Gemm") for r in ops)
+    rec = gemm_tuning.recorded_on()  # the library build the solution indices are valid for travels with the table
+    assert rec.get("HIPBLASLT_VERSION") and rec.get("ROCBLAS_VERSION") and rec.get("PT_VERSION")
     if not torch.cuda.is_available():
         assert gemm_tuning.enable() is False  # no GPU: nothing is touched
+        assert gemm_tuning.status()["gemm_table"] == "off"

@@ -253,10 +253,10 @@ def test_tail_kernels_match_torch():
     assert torch.equal(ext.knn_indices(64, q, xyz), ops.knn(64, q, xyz)[1])
 
 
-@pytest.mark.parametrize("B,N,dup", [(33, 1024, False), (3, 512, False), (2, 2048, False), (2, 1024, True), (2, 4096, False), (1, 6000, False)])
+@pytest.mark.parametrize("B,N,dup", [(64, 1024, False), (33, 1024, False), (3, 512, False), (2, 2048, False), (2, 1024, True), (2, 4096, False), (1, 6000, False)])
 def test_fast_path_other_shapes_match_module_path(B, N, dup):
-    """Fast path vs module path beyond the default shape: the gathered-row layer-1 branch (B*N >= 32768), other point
-    counts, and clouds with duplicated points (tied FPS arg-maxima -> the second sampling level really runs)."""
+    """Fast path vs module path at BASELINE configs[1]'s exact size (64 x 1024, the bench.py headline shape) and beyond the
+    default shape: the gathered-row layer-1 branch (B*N >= 32768), other point counts, and clouds with duplicated points (tied FPS arg-maxima -> the second sampling level really runs)."""
     from hotrack_amd import fused, pointnet2_utils
     from models import pointnet_utils
     from models.hand_network import HandTrackNet
@@ -486,3 +486,53 @@ def test_serving_loop_several_graphs_in_flight_equals_eager():
         pointnet_utils.set_fused_backend(None)
     for s, g_ in enumerate(got):
         assert torch.allclose(g_, eager[s % NB], atol=1e-5), (s, float((g_ - eager[s % NB]).abs().max()))
+
+
+@pytest.mark.gpu
+def test_fast_path_nan_contract():
+    """NaN behaviour of the fused inference path, pinned against torch (the module path = the reference's composition).
+    The fused kernels drop NaNs in their ReLU / max-pool maxima (sa_fused.hip is built -fno-honor-nans), so the path
+    (a) flags a frame with a non-finite input point / keypoint on the device and returns NaN keypoints for THAT frame -- what
+        the reference yields, where the NaN spreads through sampling, grouping and the global max-pool -- while the other
+        frames of the batch are unaffected;
+    (b) detects non-finite WEIGHTS once per weight change and runs the unfused module path, which propagates them."""
+    from hotrack_amd import fused, pointnet2_utils
+    from models import pointnet_utils
+    from models.hand_network import HandTrackNet
+    pointnet_utils.set_operator_backend(pointnet2_utils)
+    torch.manual_seed(0)
+    model = HandTrackNet(make_cfg("cuda"))
+    deterministic_init(model)
+    model = model.cuda().eval()
+    flags = {"track_flag": False, "test_flag": True, "save_flag": False, "IKNet_flag": False}
+    to_dev = lambda d: {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in d.items()}
+    clean = to_dev(synthetic_frames(77, 4, 1024))
+    bad = to_dev(synthetic_frames(77, 4, 1024))
+    bad["hand_points"][1, 500, 1] = float("nan")     # a NaN depth sample in frame 1
+    bad["jittered_hand_kp"][3, 5, 0] = float("inf")  # a non-finite initial palm keypoint in frame 3
+    try:
+        with torch.no_grad():
+            pointnet_utils.set_fused_backend(None)
+            ref = model(bad, dict(flags))["pred_kp"]
+            pointnet_utils.set_fused_backend(fused)
+            good = model(clean, dict(flags))["pred_kp"]
+            got = model(bad, dict(flags))["pred_kp"]
+            assert model._fast is not None and model._fast.finite_weights
+            # (a) torch / module path: frames 1 and 3 are entirely non-finite, frames 0 and 2 finite
+            for b in (1, 3):
+                assert not torch.isfinite(ref[b]).any(), "module path: a non-finite input frame yields non-finite keypoints"
+                assert torch.isnan(got[b]).all(), "fast path: flagged frame must be NaN, not a finite guess"
+            for b in (0, 2):
+                assert torch.isfinite(ref[b]).all() and torch.equal(got[b], good[b])  # neighbours in the batch untouched
+            # (b) non-finite weights: detected at fold time -> module path -> NaN everywhere, as torch
+            w = model.bhand.sa1.conv_blocks[0][1].weight
+            keep = w.detach().clone()
+            w[3, 5] = float("nan")  # in place under no_grad: bumps the parameter's version counter
+            out = model(clean, dict(flags))["pred_kp"]
+            assert model._fast.finite_weights is False and model._fast.P is None
+            assert torch.isnan(out).all()
+            w.copy_(keep)
+            again = model(clean, dict(flags))["pred_kp"]
+            assert model._fast.finite_weights and torch.equal(again, good)
+    finally:
+        pointnet_utils.set_fused_backend(None)
