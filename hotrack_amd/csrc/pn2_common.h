@@ -9,6 +9,9 @@
 namespace pn2 {
 
 constexpr int kWave = 64;
+// fp64 BatchNorm accumulators exist kBnRep times (workgroup b adds into copy b % kBnRep): 8x less same-address contention
+// (train_ops.hip, train_gemm.hip; pn2x_bn_sums_doubles reports the resulting size)
+constexpr int kBnRep = 8;
 
 // Squared distance in the one fixed contraction order used by oracle and kernels alike:
 // fma(dz,dz, fma(dx,dx, dy*dy)).  (reference expression: sampling_gpu.cu:133,
@@ -154,8 +157,8 @@ struct PerDeviceOnce {
 // train_ops.hip: counting-sort inversion of an index list (offsets (b, n_dst+1), order (b, l)); PN2_ERANGE if n_dst does not fit LDS
 int inverse_index_launch(int b, int n_dst, int l, const int *idx, int *offsets, int *order, hipStream_t st);
 // Library-owned device scratch for kernels whose C ABI (the reference's signatures) has no scratch argument: one buffer per
-// (device, stream), grown on demand.  Returns nullptr when it would have to grow while the stream is being captured into a
-// graph (allocation is illegal there): callers then take their scratch-free path.
+// (device, stream), grown on demand.  Returns nullptr whenever the stream is being captured into a graph (the pointer would be
+// baked into the graph and a later growth would free it): callers then take their scratch-free path.
 int *stream_scratch_ints(size_t count, hipStream_t st);
 // Atomics-free backward of group / gather / three_interpolate on the channel-major operator layout (scatter_cm.hip):
 // t = 1: grad_points[b,c,idx[b,e]] += grad_out[b,c,e];  t = 3: grad_points[b,c,idx[b,j,k]] += w[b,j,k] * grad_out[b,c,j].

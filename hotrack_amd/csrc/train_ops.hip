@@ -22,7 +22,7 @@
 namespace pn2 {
 
 constexpr int kTT = 256;
-constexpr int kRep = 8;  // the fp64 accumulators exist kRep times (workgroup b adds into copy b % kRep): 8x less same-address contention
+constexpr int kRep = kBnRep;  // the fp64 accumulators exist kRep times (pn2_common.h)
 
 struct BnCh {  // per-thread constants of its 4 channels
     float mean[4], invstd[4], g[4], b[4];
@@ -558,6 +558,35 @@ extern "C" int pn2x_bn_relu_bwd(long rows, int c, const float *dh, int ldd, cons
                        beta, rpb, relu, sums, (const int *)nullptr, 1);
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, grid, dim3(kTT), 0, (hipStream_t)stream, rows, c, dh, ldd, y, ldy, mean, invstd, gamma,
                        beta, sums, rpb, relu, dy, ldo, dgamma, dbeta, dbias, (const int *)nullptr, 1);
+    return check_launch();
+}
+
+// The two halves of pn2x_bn_relu_bwd / pn2x_bn_relu_max_bwd as separate entries, for the fused training stacks
+// (train_gemm.hip): the top layer of a stack needs only the reduction (its dY is computed on load by the fused GEMMs),
+// the first layer only the apply step (its pre-masked gradient and sums come from the dgrad epilogue of layer 2).
+extern "C" int pn2x_bn_bwd_reduce(long rows, int c, const float *dh, int ldd, const int *arg, int k, const float *y, int ldy,
+                                  const float *mean, const float *invstd, const float *gamma, const float *beta, int relu, double *sums,
+                                  void *stream) {
+    using namespace pn2;
+    if (rows < 1 || bad_c(c) || ldy < c || ldy % 4 || ldd < c || ldd % 4 || (arg && (k < 1 || rows % k))) return PN2_EINVAL;
+    if (!dh || !y || !mean || !invstd || !gamma || !beta || !sums) return PN2_ENULL;
+    if (((uintptr_t)y | (uintptr_t)dh | (uintptr_t)arg) % 16) return PN2_EINVAL;
+    const int rpb = rows_per_block_for(rows, c);
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kTT), 0, (hipStream_t)stream, rows, c, dh,
+                       ldd, y, ldy, mean, invstd, gamma, beta, rpb, arg ? 1 : relu, sums, arg, arg ? k : 1);
+    return check_launch();
+}
+
+extern "C" int pn2x_bn_bwd_apply(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean,
+                                 const float *invstd, const float *gamma, const float *beta, int relu, const double *sums, float *dy,
+                                 int ldo, float *dgamma, float *dbeta, float *dbias, void *stream) {
+    using namespace pn2;
+    if (rows < 1 || bad_c(c) || ldy < c || ldy % 4 || ldg < c || ldg % 4 || ldo < c || ldo % 4) return PN2_EINVAL;
+    if (!g || !y || !mean || !invstd || !gamma || !beta || !sums || !dy || !dgamma || !dbeta) return PN2_ENULL;
+    if (((uintptr_t)y | (uintptr_t)g | (uintptr_t)dy) % 16) return PN2_EINVAL;
+    const int rpb = rows_per_block_for(rows, c);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kTT), 0, (hipStream_t)stream, rows, c, g, ldg,
+                       y, ldy, mean, invstd, gamma, beta, sums, rpb, relu, dy, ldo, dgamma, dbeta, dbias, (const int *)nullptr, 1);
     return check_launch();
 }
 

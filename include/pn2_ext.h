@@ -334,6 +334,55 @@ int pn2x_bn_relu_max_bwd(long groups, int k, int c, const float *dout, const int
                          const float *invstd, const float *gamma, const float *beta, double *sums, float *dy, int ldo, float *dgamma,
                          float *dbeta, float *dbias, void *stream);
 
+/*
+ * The two launches of pn2x_bn_relu_bwd / pn2x_bn_relu_max_bwd as separate entries (used by the fused training stacks below).
+ * pn2x_bn_bwd_reduce: sums += [sum_r g, sum_r g xhat] with g = dh . [relu(bn(y)) > 0] (relu != 0) -- or, with arg != NULL,
+ *   dh = d(max over k consecutive rows) (rows / k x c, row stride ldd, arg (rows / k, c) with the same row stride c) routed
+ *   to the recorded arg-max row and ReLU-masked.
+ * pn2x_bn_bwd_apply: dy = gamma invstd (g' - sum(g)/R - xhat sum(g xhat)/R) with g' = g . mask when relu != 0, g as given
+ *   (already masked) when relu == 0; also writes dgamma, dbeta (and zeros to dbias) from the sums.
+ */
+int pn2x_bn_bwd_reduce(long rows, int c, const float *dh, int ldd, const int *arg, int k, const float *y, int ldy, const float *mean,
+                       const float *invstd, const float *gamma, const float *beta, int relu, double *sums, void *stream);
+int pn2x_bn_bwd_apply(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean, const float *invstd,
+                      const float *gamma, const float *beta, int relu, const double *sums, float *dy, int ldo, float *dgamma,
+                      float *dbeta, float *dbias, void *stream);
+
+/*
+ * Train-mode [Conv 1x1 + BatchNorm + ReLU] layers with the BatchNorm folded into fp32-MFMA GEMMs (csrc/train_gemm.hip;
+ * reference composition: pointnet_utils.py:399-403, :460-462, :504-506, :577-581 as Conv2d/Conv1d + BatchNorm + ReLU modules).
+ * Layer i >= 2 of a stack, point-major rows; `p` = layer i-1, `i` = layer i; sums_* = pn2x_bn_sums_doubles(c) fp64
+ * accumulators (forward: [sum y | sum y^2], backward: [sum g | sum g xhat]) zeroed by the caller.
+ *
+ * pn2x_tg_fwd    y_i (rows x n) = relu(BN_p(x)) w^T with x = y_p (rows x k) and w (n x k); BN_p's batch statistics come from
+ *                sums_in (filled by the producer of x); workgroup 0 writes save_mean / save_invstd of layer p and its
+ *                running-statistics update (semantics of pn2x_bn_relu_apply); sums_out (or NULL) receives the statistics of y_i.
+ * pn2x_tg_dgrad  g_p (rows x n) = (dY_i w) . [relu(BN_p(y_p)) > 0] and sums_bwd_p, where dY_i (rows x kd) =
+ *                gamma_i invstd_i (g - sum(g)/R - xhat_i sum(g xhat_i)/R) is computed on load from
+ *                  gmode 0: g = the stored, already masked g_i (rows x kd, row stride ldg);
+ *                  gmode 1: g = dh_i . [relu(BN_i(y_i)) > 0] with dh_i stored (rows x kd);
+ *                  gmode 2: dh = d(max over kmax consecutive rows) (rows / kmax x kd, row stride ldg; arg likewise) routed to
+ *                           the arg-max row and masked;
+ *                and sums_bwd_i (complete: from pn2x_bn_bwd_reduce for the top layer, from the dgrad of layer i+1 otherwise).
+ * pn2x_tg_wgrad  dw (n x k) = dY_i^T relu(BN_p(y_p)) (both operands computed on load), reduced over row splits through
+ *                `partial` (>= pn2x_tg_wgrad_partial_floats(rows, n, k) floats); also dgamma_i, dbeta_i (and zeros to dbias_i).
+ * pn2x_tg_supported(c_in, c_out): c_in % 4 == 0, c_in <= 512, c_out a multiple of 32 (for wgrad also c_in % 32 == 0).
+ */
+int pn2x_tg_supported(int c_in, int c_out);
+int pn2x_tg_fwd(long rows, int k, int n, const float *x, int ldx, const float *w, int ldw, float *y, int ldy, const double *sums_in,
+                const float *gamma, const float *beta, const float *conv_bias, float eps, float momentum, float *running_mean,
+                float *running_var, long long *num_batches_tracked, float *save_mean, float *save_invstd, double *sums_out,
+                void *stream);
+int pn2x_tg_dgrad(long rows, int kd, int n, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi, int ldyi,
+                  const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i, const double *sums_bwd_i,
+                  const float *w, int ldw, const float *yp, int ldyp, const float *mean_p, const float *invstd_p,
+                  const float *gamma_p, const float *beta_p, float *gp, int ldgp, double *sums_bwd_p, void *stream);
+long pn2x_tg_wgrad_partial_floats(long rows, int n, int k);
+int pn2x_tg_wgrad(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi, int ldyi,
+                  const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i, const double *sums_bwd_i,
+                  const float *yp, int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p,
+                  float *partial, long partial_floats, float *dw, float *dgamma, float *dbeta, float *dbias, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

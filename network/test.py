@@ -9,6 +9,9 @@ import os
 import sys
 import time
 
+# (bench.py raises GPU_MAX_HW_QUEUES to 8 because its serving loop keeps four batches in flight on four HIP streams; this entry
+# point tracks one sequence at batch 1 on ONE stream, where the runtime's default queue mapping changes nothing.  A service
+# that runs several of these loops in one process sets GPU_MAX_HW_QUEUES >= its stream count in its environment.)
 import torch
 
 base_dir = os.path.dirname(os.path.abspath(__file__))
