@@ -167,6 +167,10 @@ int *stream_scratch_ints(size_t count, hipStream_t st);
 int scatter_cm_dispatch(int t, int b, int c, int n_dst, int m_src, const float *grad_out, const int *idx, const float *weight,
                         float *grad_points, hipStream_t st, int *scratch = nullptr, size_t scratch_ints = 0);
 
+// ball_query_grid.hip: PN2_ERANGE when the shape is not covered (n < 2048, radius <= 0, no scratch): the caller scans
+int ball_query_grid_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                             unsigned *scratch, size_t scratch_words, hipStream_t st);
+
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -129,37 +129,38 @@ tg_fwd_kernel(FwdArgs a) {
     __syncthreads();
 
     const long T = (a.R + BM - 1) / BM;
-    const int nchunks = (a.K + KC - 1) / KC;
+    const int nchunks = a.K / KC;  // K % KC == 0 (launcher)
     const int kq = tid & 7, rb = tid >> 3;
     float4 pa[4], pb[NT / 32];
-    const long ptile = blockIdx.x;
+    // loads are unconditional (rows clamped to the last valid one): no exec-mask branches between them, all in flight together
     auto prefetch = [&](long tile, int chunk, bool with_b) {
         const int k = chunk * KC + 4 * kq;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long row = tile * BM + rb + 32 * i;
-            pa[i] = (row < a.R && k < a.K) ? *reinterpret_cast<const float4 *>(a.X + row * a.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            long row = tile * BM + rb + 32 * i;
+            row = row < a.R ? row : a.R - 1;
+            pa[i] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + k);
         }
         if (with_b) {
 #pragma unroll
-            for (int i = 0; i < NT / 32; ++i)
-                pb[i] = (k < a.K) ? *reinterpret_cast<const float4 *>(a.W + (size_t)(n0 + rb + 32 * i) * a.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < NT / 32; ++i) pb[i] = *reinterpret_cast<const float4 *>(a.W + (size_t)(n0 + rb + 32 * i) * a.ldw + k);
         }
     };
     auto commit = [&](long tile, int chunk, bool with_b) {
         const int k = chunk * KC + 4 * kq;
-        const bool kv = k < a.K;
         float4 c[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c[e] = kv ? *reinterpret_cast<const float4 *>(cst + 4 * (k + e)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = 0; e < 4; ++e) c[e] = *reinterpret_cast<const float4 *>(cst + 4 * (k + e));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long row = tile * BM + rb + 32 * i;
-            const bool v = kv && row < a.R;  // rows / channels beyond the problem contribute exact zeros
+            const bool v = tile * BM + rb + 32 * i < a.R;  // rows beyond the problem contribute exact zeros
             const float x[4] = {pa[i].x, pa[i].y, pa[i].z, pa[i].w};
             float *dst = As + (rb + 32 * i) * LDK + 4 * kq;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[e] = v ? relu_nan(((x[e] - c[e].x) * c[e].y) * c[e].z + c[e].w) : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const float h = relu_nan(((x[e] - c[e].x) * c[e].y) * c[e].z + c[e].w);
+                dst[e] = v ? h : 0.f;
+            }
         }
         if (with_b) {
 #pragma unroll
@@ -176,9 +177,9 @@ tg_fwd_kernel(FwdArgs a) {
     for (int nb = 0; nb < NT / 32; ++nb) cs[nb] = cq[nb] = 0.f;
     const int m = wave * 32 + (lane & 31), kh = lane >> 5;
     bool b_resident = false;  // a single-chunk reduction keeps the weight tile in LDS for every row tile
-    if (ptile < T) prefetch(ptile, 0, true);
-    long tile = ptile;
+    long tile = blockIdx.x;
     int chunk = 0;
+    if (tile < T) prefetch(tile, 0, true);
     while (tile < T) {
         const bool wb = !b_resident;
         commit(tile, chunk, wb);
@@ -205,15 +206,24 @@ tg_fwd_kernel(FwdArgs a) {
         }
         if (chunk == nchunks - 1) {
             const long row0 = tile * BM + wave * 32 + 4 * kh;
+            const bool full = tile * BM + BM <= a.R;  // workgroup-uniform: only the last tile stores under a row guard
 #pragma unroll
             for (int nb = 0; nb < NT / 32; ++nb) {
                 float s = 0.f, q = 0.f;
                 float *dst = a.Y + n0 + nb * 32 + (lane & 31);
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[(row0 + (r & 3) + 8 * (r >> 2)) * a.ldy] = acc[nb][r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long row = row0 + (r & 3) + 8 * (r >> 2);
+                        if (row < a.R) dst[row * a.ldy] = acc[nb][r];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long row = row0 + (r & 3) + 8 * (r >> 2);
                     const float v = acc[nb][r];
-                    if (row < a.R) dst[row * a.ldy] = v;
                     s += v;
                     q += v * v;
                 }
@@ -234,7 +244,8 @@ tg_fwd_kernel(FwdArgs a) {
 // GMODE 2: G holds d(max over Kmax consecutive rows) (R / Kmax rows): routed to the recorded arg-max row, ReLU-masked
 struct DySrc {
     const float *G; int ldg;
-    const int *arg; int Kmax;
+    const int *arg; int Kmax;  // GMODE 2; Kmax a power of two is divided by shift (kshift >= 0)
+    int kshift;
     const float *Y; int ldy;
     const float *mean, *invstd, *gamma, *beta;
     const double *sums_bwd;  // layer i: sum(g), sum(g xhat)
@@ -255,30 +266,13 @@ __device__ __forceinline__ void dy_constants(const DySrc &d, int C, int c0, int 
     }
 }
 
-struct DyRegs {  // what one thread fetches for one float4 of dY
-    float4 g, y;
-    int4 a;
-};
+// one float4 of dY from the fetched registers (g: gradient source, y: pre-activation, ar: arg-max rows (GMODE 2)); kk = row
+// within its max group (GMODE 2); cst points at the constants of the first of the four channels
 template <int GMODE>
-__device__ __forceinline__ void dy_fetch(const DySrc &d, long row, int c, bool valid, DyRegs &r) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    r.y = valid ? *reinterpret_cast<const float4 *>(d.Y + row * d.ldy + c) : z;
-    if constexpr (GMODE == 2) {
-        const long grp = (int)row / d.Kmax;  // rows < 2^31 (checked by the launcher)
-        r.g = valid ? *reinterpret_cast<const float4 *>(d.G + grp * d.ldg + c) : z;
-        r.a = valid ? *reinterpret_cast<const int4 *>(d.arg + grp * d.ldg + c) : make_int4(-1, -1, -1, -1);
-    } else {
-        r.g = valid ? *reinterpret_cast<const float4 *>(d.G + row * d.ldg + c) : z;
-    }
-}
-// cst points at the constants of the first of the four channels
-template <int GMODE>
-__device__ __forceinline__ float4 dy_value(const DySrc &d, long row, bool valid, const DyRegs &r, const float *cst) {
-    const float g[4] = {r.g.x, r.g.y, r.g.z, r.g.w}, y[4] = {r.y.x, r.y.y, r.y.z, r.y.w};
-    const int ar[4] = {r.a.x, r.a.y, r.a.z, r.a.w};
+__device__ __forceinline__ float4 dy_value(float4 gv, float4 yv, int4 av, int kk, bool valid, const float *cst) {
+    const float g[4] = {gv.x, gv.y, gv.z, gv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
+    const int ar[4] = {av.x, av.y, av.z, av.w};
     float o[4];
-    int kk = 0;
-    if constexpr (GMODE == 2) kk = (int)row % d.Kmax;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float4 c0 = *reinterpret_cast<const float4 *>(cst + 8 * e);
@@ -287,7 +281,8 @@ __device__ __forceinline__ float4 dy_value(const DySrc &d, long row, bool valid,
         float gg = g[e];
         if constexpr (GMODE == 2) gg = ar[e] == kk ? gg : 0.f;
         if constexpr (GMODE != 0) gg = (xhat * c1.y + c1.z > 0.f) ? gg : 0.f;  // [relu(BN(y)) > 0], torch's evaluation order
-        o[e] = valid ? c0.z * (gg - c0.w - xhat * c1.x) : 0.f;
+        const float d = c0.z * (gg - c0.w - xhat * c1.x);
+        o[e] = valid ? d : 0.f;
     }
     return make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -323,26 +318,33 @@ tg_dgrad_kernel(DgradArgs a) {
     __syncthreads();
 
     const long T = (a.R + BM - 1) / BM;
-    const int nchunks = (a.Kd + KC - 1) / KC;
+    const int nchunks = a.Kd / KC;  // Kd % KC == 0 (launcher)
     const int kq = tid & 7, rb = tid >> 3;
     constexpr int BQ = NT / 4;        // float4 per weight row
     constexpr int BI = NT / 32;       // weight float4 per thread and chunk
     const int jq = tid % BQ, kr0 = tid / BQ;
-    DyRegs pa[4];
-    float4 pb[BI];
+    float4 pg[4], py[4], pb[BI];
+    int4 par[4];
+    const DySrc &d = a.dy;
     auto prefetch = [&](long tile, int chunk, bool with_b) {
         const int k = chunk * KC + 4 * kq;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long row = tile * BM + rb + 32 * i;
-            dy_fetch<GMODE>(a.dy, row, k, row < a.R && k < a.Kd, pa[i]);
+            long row = tile * BM + rb + 32 * i;
+            row = row < a.R ? row : a.R - 1;  // unconditional loads: the commit zeroes what lies beyond the problem
+            py[i] = *reinterpret_cast<const float4 *>(d.Y + row * d.ldy + k);
+            if constexpr (GMODE == 2) {
+                const long grp = d.kshift >= 0 ? ((int)row >> d.kshift) : ((int)row / d.Kmax);
+                pg[i] = *reinterpret_cast<const float4 *>(d.G + grp * d.ldg + k);
+                par[i] = *reinterpret_cast<const int4 *>(d.arg + grp * d.ldg + k);
+            } else {
+                pg[i] = *reinterpret_cast<const float4 *>(d.G + row * d.ldg + k);
+            }
         }
         if (with_b) {
 #pragma unroll
-            for (int i = 0; i < BI; ++i) {
-                const int kr = chunk * KC + kr0 + (kT / BQ) * i;
-                pb[i] = kr < a.Kd ? *reinterpret_cast<const float4 *>(a.W + (size_t)kr * a.ldw + n0 + 4 * jq) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int i = 0; i < BI; ++i)
+                pb[i] = *reinterpret_cast<const float4 *>(a.W + (size_t)(chunk * KC + kr0 + (kT / BQ) * i) * a.ldw + n0 + 4 * jq);
         }
     };
     auto commit = [&](long tile, int chunk, bool with_b) {
@@ -350,8 +352,14 @@ tg_dgrad_kernel(DgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long row = tile * BM + rb + 32 * i;
-            const bool v = row < a.R && k < a.Kd;
-            const float4 dyv = dy_value<GMODE>(a.dy, row, v, pa[i], cstA + 8 * (v ? k : 0));
+            int kk = 0;
+            int4 av = make_int4(0, 0, 0, 0);
+            if constexpr (GMODE == 2) {
+                const int rr = (int)(row < a.R ? row : a.R - 1);
+                kk = d.kshift >= 0 ? (rr & (d.Kmax - 1)) : (rr % d.Kmax);
+                av = par[i];
+            }
+            const float4 dyv = dy_value<GMODE>(pg[i], py[i], av, kk, row < a.R, cstA + 8 * k);
             float *dst = As + (rb + 32 * i) * LDK + 4 * kq;
             dst[0] = dyv.x; dst[1] = dyv.y; dst[2] = dyv.z; dst[3] = dyv.w;
         }
@@ -377,7 +385,10 @@ tg_dgrad_kernel(DgradArgs a) {
         long ntile = tile;
         int nchunk = chunk + 1;
         if (nchunk == nchunks) { nchunk = 0; ntile += gridDim.x; }
-        if (ntile < T) prefetch(ntile, nchunk, !b_resident);
+        const bool last = chunk == nchunks - 1;
+        // the next chunk's operands are fetched behind this chunk's MFMAs; across a tile boundary only after the epilogue, whose
+        // own loads and temporaries would otherwise have to live next to the prefetched registers
+        if (!last && ntile < T) prefetch(ntile, nchunk, !b_resident);
         if (chunk == 0) {
 #pragma unroll
             for (int nb = 0; nb < NT / 32; ++nb)
@@ -393,8 +404,9 @@ tg_dgrad_kernel(DgradArgs a) {
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
             }
         }
-        if (chunk == nchunks - 1) {
+        if (last) {
             const long row0 = tile * BM + wave * 32 + 4 * kh;
+            const bool full = tile * BM + BM <= a.R;
 #pragma unroll
             for (int nb = 0; nb < NT / 32; ++nb) {
                 const int j = nb * 32 + (lane & 31);
@@ -404,22 +416,34 @@ tg_dgrad_kernel(DgradArgs a) {
                 float *dst = a.Gp + n0 + j;
                 float yv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {  // the sixteen pre-activation loads are independent: issued together
-                    const long row = row0 + (r & 3) + 8 * (r >> 2);
-                    yv[r] = row < a.R ? yp[row * a.ldyp] : 0.f;
+                for (int r = 0; r < 16; ++r) {  // the sixteen pre-activation loads are independent and unconditional (row clamped)
+                    long row = row0 + (r & 3) + 8 * (r >> 2);
+                    row = row < a.R ? row : a.R - 1;
+                    yv[r] = yp[row * a.ldyp];
                 }
+                float gv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long row = row0 + (r & 3) + 8 * (r >> 2);
                     const float xhat = (yv[r] - ce.x) * ce.y;
-                    const float g = (xhat * ce.z + ce.w > 0.f) ? acc[nb][r] : 0.f;
-                    if (row < a.R) dst[row * a.ldgp] = g;  // rows beyond R have acc == 0
-                    s += g;
-                    q += g * xhat;
+                    gv[r] = (xhat * ce.z + ce.w > 0.f) ? acc[nb][r] : 0.f;  // rows beyond R have acc == 0
+                    s += gv[r];
+                    q += gv[r] * xhat;
+                }
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[(row0 + (r & 3) + 8 * (r >> 2)) * a.ldgp] = gv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long row = row0 + (r & 3) + 8 * (r >> 2);
+                        if (row < a.R) dst[row * a.ldgp] = gv[r];
+                    }
                 }
                 cs[nb] += s;
                 cq[nb] += q;
+                __builtin_amdgcn_sched_barrier(0);  // one column block at a time: 16 loads in flight, not 64 registers of them
             }
+            if (ntile < T) prefetch(ntile, nchunk, !b_resident);
         }
         __syncthreads();
         tile = ntile;
@@ -437,6 +461,7 @@ struct WgradArgs {
     const float *mean_p, *invstd_p, *gamma_p, *beta_p;
     float *partial;             // [gridDim.x * KG][N][K]
     long rows_per_split;        // multiple of RC
+    float *dW;                  // zeroed here (row split 0) for tg_reduce's atomic accumulation
 };
 
 template <int MT, int NT, int GMODE>
@@ -460,18 +485,29 @@ tg_wgrad_kernel(WgradArgs a) {
     const long r_end = (r_begin + a.rows_per_split) < a.R ? (r_begin + a.rows_per_split) : a.R;
     constexpr int AQ = MT / 4, AI = MT / 32, HQ = NT / 4, HI = NT / 32;
     const int anq = tid % AQ, ar0 = tid / AQ, hjq = tid % HQ, hr0 = tid / HQ;
-    DyRegs pa[AI];
-    float4 ph[HI];
+    float4 pg[AI], py[AI], ph[HI];
+    int4 par[AI];
+    const DySrc &d = a.dy;
+    const long r_last = r_end - 1;
     auto prefetch = [&](long rbase) {
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const long row = rbase + ar0 + (kT / AQ) * i;
-            dy_fetch<GMODE>(a.dy, row, m0 + 4 * anq, row < r_end, pa[i]);
+            long row = rbase + ar0 + (kT / AQ) * i;
+            row = row < r_end ? row : r_last;  // unconditional loads; the commit zeroes rows beyond this split
+            py[i] = *reinterpret_cast<const float4 *>(d.Y + row * d.ldy + m0 + 4 * anq);
+            if constexpr (GMODE == 2) {
+                const long grp = d.kshift >= 0 ? ((int)row >> d.kshift) : ((int)row / d.Kmax);
+                pg[i] = *reinterpret_cast<const float4 *>(d.G + grp * d.ldg + m0 + 4 * anq);
+                par[i] = *reinterpret_cast<const int4 *>(d.arg + grp * d.ldg + m0 + 4 * anq);
+            } else {
+                pg[i] = *reinterpret_cast<const float4 *>(d.G + row * d.ldg + m0 + 4 * anq);
+            }
         }
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
-            const long row = rbase + hr0 + (kT / HQ) * i;
-            ph[i] = row < r_end ? *reinterpret_cast<const float4 *>(a.Yp + row * a.ldyp + j0 + 4 * hjq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            long row = rbase + hr0 + (kT / HQ) * i;
+            row = row < r_end ? row : r_last;
+            ph[i] = *reinterpret_cast<const float4 *>(a.Yp + row * a.ldyp + j0 + 4 * hjq);
         }
     };
     auto commit = [&](long rbase) {
@@ -479,7 +515,14 @@ tg_wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < AI; ++i) {
             const int rr = ar0 + (kT / AQ) * i;
             const long row = rbase + rr;
-            *reinterpret_cast<float4 *>(Ad + rr * MT + 4 * anq) = dy_value<GMODE>(a.dy, row, row < r_end, pa[i], cstA + 8 * 4 * anq);
+            int kk = 0;
+            int4 av = make_int4(0, 0, 0, 0);
+            if constexpr (GMODE == 2) {
+                const int rr_ = (int)(row < r_end ? row : r_last);
+                kk = d.kshift >= 0 ? (rr_ & (d.Kmax - 1)) : (rr_ % d.Kmax);
+                av = par[i];
+            }
+            *reinterpret_cast<float4 *>(Ad + rr * MT + 4 * anq) = dy_value<GMODE>(pg[i], py[i], av, kk, row < r_end, cstA + 8 * 4 * anq);
         }
         float4 c[4];
 #pragma unroll
@@ -491,7 +534,10 @@ tg_wgrad_kernel(WgradArgs a) {
             const float x[4] = {ph[i].x, ph[i].y, ph[i].z, ph[i].w};
             float h[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = v ? relu_nan(((x[e] - c[e].x) * c[e].y) * c[e].z + c[e].w) : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const float t = relu_nan(((x[e] - c[e].x) * c[e].y) * c[e].z + c[e].w);
+                h[e] = v ? t : 0.f;
+            }
             *reinterpret_cast<float4 *>(Hd + rr * NT + 4 * hjq) = make_float4(h[0], h[1], h[2], h[3]);
         }
     };
@@ -528,38 +574,55 @@ tg_wgrad_kernel(WgradArgs a) {
             const int n = m0 + strip * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             out[(size_t)n * a.K + j0 + nb * 32 + (lane & 31)] = acc[nb][r];
         }
+    if (blockIdx.x == 0) {  // this (m, j) tile of dW starts from zero: tg_reduce accumulates its slices of the partials into it
+        for (int e = tid; e < MT * NT; e += kT) a.dW[(size_t)(m0 + e / NT) * a.K + j0 + e % NT] = 0.f;
+    }
 }
 
-// dW = sum of the partial tiles; dgamma / dbeta of the layer from its backward sums; the conv bias in front of a BatchNorm
-// has an identically zero gradient
+// dW += sum of a slice of the partial tiles (grid.y slices, 64 elements x 4 partial lanes per workgroup: the partials of a
+// narrow layer are few elements deep and thousands of tiles long, so the sum is spread over the partial axis as well);
+// dgamma / dbeta of the layer from its backward sums; the conv bias in front of a BatchNorm has an identically zero gradient
 __global__ void __launch_bounds__(kT)
 tg_reduce_kernel(const float *__restrict__ partial, int P, int numel, float *__restrict__ dW, const double *__restrict__ sums_bwd, int N,
                  float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dbias) {
-    const int e = blockIdx.x * kT + threadIdx.x;
+    __shared__ float red[4][64];
+    const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const int per = (P + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = (p0 + per) < P ? (p0 + per) : P;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < numel) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int p = 0;
-        for (; p + 3 < P; p += 4) {
+        int p = p0 + pl;
+        for (; p + 12 < p1; p += 16) {
             s0 += partial[(size_t)p * numel + e];
-            s1 += partial[(size_t)(p + 1) * numel + e];
-            s2 += partial[(size_t)(p + 2) * numel + e];
-            s3 += partial[(size_t)(p + 3) * numel + e];
+            s1 += partial[(size_t)(p + 4) * numel + e];
+            s2 += partial[(size_t)(p + 8) * numel + e];
+            s3 += partial[(size_t)(p + 12) * numel + e];
         }
-        for (; p < P; ++p) s0 += partial[(size_t)p * numel + e];
-        dW[e] = (s0 + s1) + (s2 + s3);
+        for (; p < p1; p += 4) s0 += partial[(size_t)p * numel + e];
     }
-    if (e < N && sums_bwd) {
+    red[pl][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (pl == 0 && e < numel) atomicAdd(dW + e, (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]));
+    const int c = blockIdx.x * kT + threadIdx.x;
+    if (blockIdx.y == 0 && c < N && sums_bwd) {
         double sa = 0.0, sb = 0.0;
         for (int r = 0; r < kBnRep; ++r) {
-            sa += sums_bwd[(size_t)r * 2 * N + e];
-            sb += sums_bwd[(size_t)r * 2 * N + N + e];
+            sa += sums_bwd[(size_t)r * 2 * N + c];
+            sb += sums_bwd[(size_t)r * 2 * N + N + c];
         }
-        dbeta[e] = (float)sa;
-        dgamma[e] = (float)sb;
-        if (dbias) dbias[e] = 0.f;
+        dbeta[c] = (float)sa;
+        dgamma[c] = (float)sb;
+        if (dbias) dbias[c] = 0.f;
     }
 }
 
+static int kshift_of(int k) {
+    if (k < 1 || (k & (k - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < k) ++s;
+    return s;
+}
 static int col_tile(int n) { return n % 128 == 0 ? 128 : (n % 64 == 0 ? 64 : (n % 32 == 0 ? 32 : 0)); }
 static bool bad_ld(int ld, int c) { return ld < c || ld % 4; }
 
@@ -570,7 +633,7 @@ using namespace pn2;
 using namespace pn2::tg;
 
 extern "C" int pn2x_tg_supported(int c_in, int c_out) {
-    return (c_in >= 4 && c_in % 4 == 0 && c_in <= kMaxC && c_out <= 4096 && col_tile(c_out) != 0) ? 1 : 0;
+    return (c_in >= KC && c_in % KC == 0 && c_in <= kMaxC && c_out <= 4096 && col_tile(c_out) != 0) ? 1 : 0;
 }
 
 extern "C" int pn2x_tg_fwd(long rows, int k, int n, const float *x, int ldx, const float *w, int ldw, float *y, int ldy,
@@ -615,19 +678,23 @@ extern "C" int pn2x_tg_dgrad(long rows, int kd, int n, int gmode, const float *g
     if (int rc = check_dy(gmode, g, ldg, arg, kmax, yi, ldyi, kd, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, rows)) return rc;
     if (!w || !yp || !mean_p || !invstd_p || !gamma_p || !beta_p || !gp || !sums_bwd_p) return PN2_ENULL;
     if (((uintptr_t)w | (uintptr_t)yp | (uintptr_t)gp) % 16) return PN2_EINVAL;
-    DgradArgs a{rows, kd, n, DySrc{g, ldg, arg, kmax, yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i}, w, ldw, yp, ldyp,
+    DgradArgs a{rows, kd, n, DySrc{g, ldg, arg, kmax, kshift_of(kmax), yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i}, w, ldw, yp, ldyp,
                 mean_p, invstd_p, gamma_p, beta_p, gp, ldgp, sums_bwd_p};
-    const int nt = col_tile(n);
+    // column tiles of at most 64: with the 128-wide tile the kernel needs 256 registers (prefetched operands + accumulators + the
+    // epilogue's loads) and ONE workgroup per CU then serialises its HBM round trips; two 64-wide tiles recompute dY twice but
+    // keep two to three workgroups resident
+    int nt = col_tile(n);
+    if (nt > 64) nt = 64;
     const long tiles = (rows + BM - 1) / BM;
     const int ny = n / nt;
     long gx = tiles;
-    const long cap = (long)num_compute_units() * 4 / ny;
+    const long cap = (long)num_compute_units() * 6 / ny;
     if (gx > cap) gx = cap < 1 ? 1 : cap;
     const dim3 grid((unsigned)gx, ny);
     const size_t lds = (size_t)(8 * kd + 4 * nt + BM * LDK + KC * nt + 8 * nt) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define PN2_TG_D(NT_, GM_) hipLaunchKernelGGL((tg_dgrad_kernel<NT_, GM_>), grid, dim3(kT), lds, st, a)
-#define PN2_TG_DN(GM_) do { if (nt == 128) PN2_TG_D(128, GM_); else if (nt == 64) PN2_TG_D(64, GM_); else PN2_TG_D(32, GM_); } while (0)
+#define PN2_TG_DN(GM_) do { if (nt == 64) PN2_TG_D(64, GM_); else PN2_TG_D(32, GM_); } while (0)
     if (gmode == 0) PN2_TG_DN(0);
     else if (gmode == 1) PN2_TG_DN(1);
     else PN2_TG_DN(2);
@@ -674,8 +741,8 @@ extern "C" int pn2x_tg_wgrad(long rows, int n, int k, int gmode, const float *g,
     long rps;
     wgrad_plan(rows, n, k, mt, nt, rps, splits, kg);
     if (partial_floats < (long)splits * kg * n * k) return PN2_ESCRATCH;
-    WgradArgs a{rows, n, k, DySrc{g, ldg, arg, kmax, yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i}, yp, ldyp,
-                mean_p, invstd_p, gamma_p, beta_p, partial, rps};
+    WgradArgs a{rows, n, k, DySrc{g, ldg, arg, kmax, kshift_of(kmax), yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i}, yp, ldyp,
+                mean_p, invstd_p, gamma_p, beta_p, partial, rps, dw};
     const dim3 grid(splits, n / mt, k / nt);
     const size_t lds = (size_t)(8 * mt + 4 * nt + RC * mt + RC * nt) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
@@ -689,8 +756,12 @@ extern "C" int pn2x_tg_wgrad(long rows, int n, int k, int gmode, const float *g,
 #undef PN2_TG_WN
 #undef PN2_TG_W
     if (int rc = check_launch()) return rc;
-    const int numel = n * k;
-    hipLaunchKernelGGL(tg_reduce_kernel, dim3((numel + kT - 1) / kT), dim3(kT), 0, st, partial, splits * kg, numel, dw, sums_bwd_i, n,
+    const int numel = n * k, P = splits * kg;
+    int ps = P / 32;  // >= 32 partial tiles per slice (8 per lane)
+    if (ps < 1) ps = 1;
+    if (ps > 64) ps = 64;
+    // (numel + 63) / 64 >= (n + 255) / 256 workgroups along x: the dgamma / dbeta tail covers every channel
+    hipLaunchKernelGGL(tg_reduce_kernel, dim3((numel + 63) / 64, ps), dim3(kT), 0, st, partial, P, numel, dw, sums_bwd_i, n,
                        dgamma, dbeta, dbias);
     return check_launch();
 }

@@ -37,6 +37,7 @@ _vp, _ci, _cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _SIGS = {
     "pn2_furthest_point_sampling": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "pn2_ball_query": [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp],
+    "pn2x_ball_query_grid": [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp, ctypes.c_long, _vp],
     "pn2_group_points": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "pn2_group_points_grad": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "pn2_gather_points": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
@@ -55,6 +56,8 @@ _lib.pn2_strerror.argtypes = [_ci]
 _lib.pn2_abi_version.restype = _ci
 _lib.pn2_last_hip_error.restype = _ci
 
+_lib.pn2x_ball_query_grid_scratch_words.argtypes = [_ci, _ci]
+_lib.pn2x_ball_query_grid_scratch_words.restype = ctypes.c_long
 _lib.pn2x_scatter_cm_scratch_ints.argtypes = [_ci, _ci, _ci, _ci]
 _lib.pn2x_scatter_cm_scratch_ints.restype = ctypes.c_long
 _lib.pn2x_scatter_cm.argtypes = [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp]
@@ -146,6 +149,14 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     px = _ptr(xyz, "xyz", _f32, b * n * 3)
     o = _ptr(idx, "idx", _i32, b * m * nsample)
     with torch.cuda.device(xyz.device):
+        if n >= 4096 and m * n >= (1 << 22) and radius > 0:
+            # large problem: the cell-grid search with torch-owned scratch (safe under HIP-graph capture); identical output
+            words = int(_lib.pn2x_ball_query_grid_scratch_words(b, n))
+            scratch = torch.empty(words, dtype=torch.int32, device=xyz.device)
+            rc = _lib.pn2x_ball_query_grid(b, n, m, float(radius), nsample, pn, px, o, scratch.data_ptr(), words, _stream(xyz))
+            if rc != -3:  # PN2_ERANGE: shape not covered -> the scan below
+                _check(rc, "ball_query_grid")
+                return 1
         _check(_lib.pn2_ball_query(b, n, m, float(radius), nsample, pn, px, o, _stream(xyz)), "ball_query")
     return 1
 

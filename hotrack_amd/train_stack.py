@@ -1,0 +1,215 @@
+"""A whole train-mode [Conv 1x1 + BatchNorm + ReLU] stack as ONE autograd Function on the fused BatchNorm GEMMs of
+csrc/train_gemm.hip (include/pn2_ext.h: pn2x_tg_fwd / pn2x_tg_dgrad / pn2x_tg_wgrad).
+
+    mlp_stack(y1, layers, ws, max_over=K)
+
+`y1` (R, C1) are the PRE-activations of the stack's first layer (a gather-assembled layer-1 of a set-abstraction scale, or a
+library GEMM over a concatenated input); layers[0] carries only that layer's BatchNorm, layers[i >= 1] a convolution weight
+(C_i, C_{i-1}) and its BatchNorm.  Forward: statistics of y1 (pn2x_bn_stats), then per further layer ONE kernel that
+normalises + rectifies its input on load, multiplies on the fp32 matrix cores and accumulates the statistics of its output;
+the top of the stack is the streaming kernel pair of train_ops (materialised output, or max over every K consecutive rows).
+Backward: one reduction over the top layer, then per layer a weight-gradient and a data-gradient kernel that compute the
+pre-activation gradient dY on load; the first layer's dY is materialised by the streaming apply kernel and returned as the
+gradient of y1.  Neither the normalised activations nor any dY of a hidden layer is ever written to memory.
+
+Semantics are those of torch.nn.BatchNorm1d/2d in training mode (batch statistics, running-statistics update with the
+unbiased variance, num_batches_tracked) -- reference composition: pointnet_utils.py:399-403, :460-462, :504-506, :577-581.
+GPU tensors only (no CPU path).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import pointnet2_hip as _native
+from . import train_ops as _t
+
+_lib = _native._lib
+_vp, _ci, _cl, _cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_lib.pn2x_tg_supported.argtypes = [_ci, _ci]
+_lib.pn2x_tg_supported.restype = _ci
+_lib.pn2x_tg_fwd.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_tg_fwd.restype = _ci
+_DY = [_ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]  # gmode, g, ldg, arg, kmax, yi, ldyi, mean, invstd, gamma, beta, sums_bwd
+_lib.pn2x_tg_dgrad.argtypes = [_cl, _ci, _ci] + _DY + [_vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
+_lib.pn2x_tg_dgrad.restype = _ci
+_lib.pn2x_tg_wgrad_partial_floats.argtypes = [_cl, _ci, _ci]
+_lib.pn2x_tg_wgrad_partial_floats.restype = _cl
+_lib.pn2x_tg_wgrad.argtypes = [_cl, _ci, _ci] + _DY + [_vp, _ci, _vp, _vp, _vp, _vp, _vp, _cl, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_tg_wgrad.restype = _ci
+_lib.pn2x_bn_bwd_reduce.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
+_lib.pn2x_bn_bwd_reduce.restype = _ci
+_lib.pn2x_bn_bwd_apply.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
+_lib.pn2x_bn_bwd_apply.restype = _ci
+_f32 = torch.float32
+_p = _t._p
+
+
+def supported(c_in: int, c_out: int) -> bool:
+    """Layer widths the fused kernels cover (forward, dgrad and wgrad): c_in and c_out multiples of 32, c_in <= 512."""
+    return bool(_lib.pn2x_tg_supported(int(c_in), int(c_out))) and c_in % 32 == 0
+
+
+class Layer:
+    """One layer of a stack: weight (C_out, C_in) | None for the first layer, BatchNorm module, the conv bias (or None)."""
+
+    def __init__(self, weight, bn, conv_bias=None):
+        self.weight, self.bn, self.conv_bias = weight, bn, conv_bias
+
+
+class _Stack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y1, K, ws, metas, *tensors):
+        # tensors: per layer (weight | placeholder, gamma, beta, conv bias | placeholder); metas: per layer (running_mean, running_var, nbt, eps, momentum)
+        L = len(metas)
+        R, C1 = y1.shape
+        dev = y1.device
+        py, ldy = _t._rows2d(y1, "y1")
+        st = _native._stream(y1)
+        ws_f = [ws.take(_lib.pn2x_bn_sums_doubles(tensors[4 * i + 1].shape[0])) for i in range(L)]
+        ws_b = [ws.take(_lib.pn2x_bn_sums_doubles(tensors[4 * i + 1].shape[0])) for i in range(L)]
+        ys, saved = [y1], []
+        with torch.cuda.device(dev):
+            _native._check(_lib.pn2x_bn_stats(R, C1, py, ldy, ws_f[0].data_ptr(), st), "bn_stats")
+            for i in range(1, L):
+                w, gamma_p, beta_p, bias_p = tensors[4 * i], tensors[4 * (i - 1) + 1], tensors[4 * (i - 1) + 2], tensors[4 * (i - 1) + 3]
+                bias_p = bias_p if bias_p.numel() else None
+                rm, rv, nbt, eps, mom = metas[i - 1]
+                N, Kc = w.shape
+                if w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16:
+                    w = w.contiguous()
+                y = torch.empty((R, N), dtype=_f32, device=dev)
+                sv = torch.empty((2, Kc), dtype=_f32, device=dev)
+                x = ys[-1]
+                _native._check(_lib.pn2x_tg_fwd(R, Kc, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), N,
+                                                ws_f[i - 1].data_ptr(), gamma_p.data_ptr(), beta_p.data_ptr(), _p(bias_p), float(eps),
+                                                float(mom), _p(rm), _p(rv), _p(nbt), sv[0].data_ptr(), sv[1].data_ptr(),
+                                                ws_f[i].data_ptr(), st), "tg_fwd")
+                ys.append(y)
+                saved.append(sv)
+            # top of the stack: the streaming kernels (they also finalise the last layer's statistics)
+            gamma, beta, bias = tensors[4 * (L - 1) + 1], tensors[4 * (L - 1) + 2], tensors[4 * (L - 1) + 3]
+            bias = bias if bias.numel() else None
+            rm, rv, nbt, eps, mom = metas[L - 1]
+            yl = ys[-1]
+            C = yl.shape[1]
+            sv = torch.empty((2, C), dtype=_f32, device=dev)
+            arg = None
+            if K:
+                G = R // K
+                out = torch.empty((G, C), dtype=_f32, device=dev)
+                arg = torch.empty((G, C), dtype=torch.int32, device=dev)
+                _native._check(_lib.pn2x_bn_relu_max(G, K, C, yl.data_ptr(), yl.stride(0), ws_f[L - 1].data_ptr(), gamma.data_ptr(),
+                                                     beta.data_ptr(), _p(bias), float(eps), float(mom), _p(rm), _p(rv), _p(nbt),
+                                                     sv[0].data_ptr(), sv[1].data_ptr(), out.data_ptr(), arg.data_ptr(), st), "bn_relu_max")
+            else:
+                out = torch.empty((R, C), dtype=_f32, device=dev)
+                _native._check(_lib.pn2x_bn_relu_apply(R, C, yl.data_ptr(), yl.stride(0), ws_f[L - 1].data_ptr(), gamma.data_ptr(),
+                                                       beta.data_ptr(), _p(bias), float(eps), float(mom), _p(rm), _p(rv), _p(nbt),
+                                                       sv[0].data_ptr(), sv[1].data_ptr(), out.data_ptr(), C, 1, st), "bn_relu_apply")
+            saved.append(sv)
+        ctx.save_for_backward(*ys, *saved, *([arg] if arg is not None else []), *tensors)
+        ctx.L, ctx.K = L, K
+        ctx.has_bias = [tensors[4 * i + 3].numel() > 0 for i in range(L)]
+        ctx.ws, ctx.ws_gen, ctx.ws_b_all = ws, ws.generation, ws_b
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L, K = ctx.L, ctx.K
+        t = ctx.saved_tensors
+        ys, saved = t[:L], t[L:2 * L]
+        off = 2 * L
+        arg = None
+        if K:
+            arg = t[off]
+            off += 1
+        tensors = t[off:]
+        dev = dout.device
+        dout = dout.contiguous()
+        R = ys[0].shape[0]
+        st = _native._stream(dout)
+        # backward accumulators: this forward's slices while they are fresh, zeros otherwise (train_ops.Workspace)
+        if ctx.ws_gen == ctx.ws.generation and not getattr(ctx, "ws_used", False):
+            ctx.ws_used = True
+            sums = ctx.ws_b_all
+        else:
+            sums = [torch.zeros(s.numel(), dtype=torch.float64, device=dev) for s in ctx.ws_b_all]
+        grads = [None] * len(tensors)
+        gam = lambda i: tensors[4 * i + 1]
+        bet = lambda i: tensors[4 * i + 2]
+        with torch.cuda.device(dev):
+            yl, svl = ys[L - 1], saved[L - 1]
+            Cl = yl.shape[1]
+            _native._check(_lib.pn2x_bn_bwd_reduce(R, Cl, dout.data_ptr(), Cl, _p(arg), K if K else 1, yl.data_ptr(), yl.stride(0),
+                                                   svl[0].data_ptr(), svl[1].data_ptr(), gam(L - 1).data_ptr(), bet(L - 1).data_ptr(), 1,
+                                                   sums[L - 1].data_ptr(), st), "bn_bwd_reduce")
+            g, gmode = dout, (2 if K else 1)
+            for i in range(L - 1, 0, -1):
+                w = tensors[4 * i]
+                N, Kc = w.shape
+                wc = w if (w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0) else w.contiguous()
+                yi, yp, svi, svp = ys[i], ys[i - 1], saved[i], saved[i - 1]
+                dy_args = (gmode, g.data_ptr(), g.stride(0), _p(arg) if gmode == 2 else None, K if gmode == 2 else 1, yi.data_ptr(),
+                           yi.stride(0), svi[0].data_ptr(), svi[1].data_ptr(), gam(i).data_ptr(), bet(i).data_ptr(), sums[i].data_ptr())
+                pf = int(_lib.pn2x_tg_wgrad_partial_floats(R, N, Kc))
+                partial = torch.empty(pf, dtype=_f32, device=dev)
+                dw = torch.empty((N, Kc), dtype=_f32, device=dev)
+                dpar = torch.empty((3, N), dtype=_f32, device=dev)
+                _native._check(_lib.pn2x_tg_wgrad(R, N, Kc, *dy_args, yp.data_ptr(), yp.stride(0), svp[0].data_ptr(), svp[1].data_ptr(),
+                                                  gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), partial.data_ptr(), pf, dw.data_ptr(),
+                                                  dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(), st), "tg_wgrad")
+                grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = dw, dpar[0], dpar[1]
+                if ctx.has_bias[i]:
+                    grads[4 * i + 3] = dpar[2]  # zeros: the bias of a convolution in front of a BatchNorm has no gradient
+                gp = torch.empty((R, Kc), dtype=_f32, device=dev)
+                _native._check(_lib.pn2x_tg_dgrad(R, N, Kc, *dy_args, wc.data_ptr(), wc.stride(0), yp.data_ptr(), yp.stride(0),
+                                                  svp[0].data_ptr(), svp[1].data_ptr(), gam(i - 1).data_ptr(), bet(i - 1).data_ptr(),
+                                                  gp.data_ptr(), Kc, sums[i - 1].data_ptr(), st), "tg_dgrad")
+                g, gmode = gp, 0
+            # first layer: materialise dY_1 (its producer -- a row gather or a library GEMM -- takes it from here)
+            y1, sv1 = ys[0], saved[0]
+            C1 = y1.shape[1]
+            dy1 = torch.empty((R, C1), dtype=_f32, device=dev)
+            dpar = torch.empty((3, C1), dtype=_f32, device=dev)
+            _native._check(_lib.pn2x_bn_bwd_apply(R, C1, g.data_ptr(), g.stride(0), y1.data_ptr(), y1.stride(0), sv1[0].data_ptr(),
+                                                  sv1[1].data_ptr(), gam(0).data_ptr(), bet(0).data_ptr(), 0, sums[0].data_ptr(),
+                                                  dy1.data_ptr(), C1, dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(), st),
+                           "bn_bwd_apply")
+            grads[1], grads[2] = dpar[0], dpar[1]
+            if ctx.has_bias[0]:
+                grads[3] = dpar[2]
+        return (dy1, None, None, None, *grads)
+
+
+def mlp_stack(y1: torch.Tensor, layers, ws, max_over: int = 0) -> torch.Tensor:
+    """relu(BN_L(... relu(BN_1(y1)) W_2^T ...)), optionally followed by the max over every `max_over` consecutive rows.
+    y1 (R, C_1) pre-activations of layer 1 (without the conv bias: it cancels in the normalisation); layers: list of Layer;
+    ws: train_ops.Workspace.  Conv biases get no gradient here (identically zero in front of a BatchNorm): the caller returns
+    zeros for them where the reference's `grad is None` mask needs a tensor."""
+    R = y1.shape[0]
+    if max_over and R % max_over:
+        raise ValueError("mlp_stack: rows must be a multiple of max_over")
+    if len(layers) == 1:  # nothing to fuse: the streaming kernels
+        l = layers[0]
+        return _t.bn_relu_max(y1, max_over, l.bn, ws, l.conv_bias) if max_over else _t.bn_relu(y1, l.bn, ws, l.conv_bias)
+    metas, tensors = [], []
+    for i, l in enumerate(layers):
+        bn = l.bn
+        track = bn.track_running_stats and bn.running_mean is not None
+        metas.append((bn.running_mean if track else None, bn.running_var if track else None,
+                      bn.num_batches_tracked if track else None, bn.eps, bn.momentum if bn.momentum is not None else 0.1))
+        none = y1.new_empty(0)
+        tensors += [l.weight if i else none, bn.weight, bn.bias, l.conv_bias if l.conv_bias is not None else none]
+    return _Stack.apply(y1, int(max_over), ws, metas, *tensors)
+
+
+def stack_supported(c1: int, widths) -> bool:
+    """True when every fused layer (C_{i-1} -> C_i, i >= 2) is covered by the kernels."""
+    prev = c1
+    for c in widths:
+        if not supported(prev, c):
+            return False
+        prev = c
+    return c1 % 4 == 0 and c1 <= 1024

@@ -156,6 +156,19 @@ int pn2x_ball_query_picks2(int b, int n, int m, float radius, int nsample, const
                            int *idx, float *new_xyz_copy, int copy_ld, void *stream);
 
 /*
+ * pn2_ball_query through a cell grid (csrc/ball_query_grid.hip): identical output for every input -- the same hit test on
+ * the same pairs, emitted in ascending index order with the reference's first-hit padding (ball_query_gpu.cu:34-43) --
+ * but only the points in the 3x3x3 cells around a centroid are tested, in blocks of consecutive indices with the
+ * reference's early exit after the nsample-th hit.  For clouds of n >= 2048 points (PN2_ERANGE below that and for
+ * radius <= 0: callers run pn2_ball_query).  scratch: pn2x_ball_query_grid_scratch_words(b, n) 4-byte words, 16-byte
+ * aligned, contents irrelevant (the per-cloud grid is rebuilt by every call).  pn2_ball_query itself takes this path for
+ * large problems when it can use library-owned scratch (i.e. outside stream capture).
+ */
+long pn2x_ball_query_grid_scratch_words(int b, int n);
+int pn2x_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                         void *scratch, long scratch_words, void *stream);
+
+/*
  * Row gather on point-major data: out[b, j, :] = src[b, idx[b,j], :]  (src (b,n,c), idx (b,m), out (b,m,c)).
  * The point-major twin of pn2_gather_points (used for the FPS-selected centroid coordinates).
  */

@@ -57,6 +57,8 @@ class FastTrain:
     def __init__(self, net):
         self.net = net
         self.ws = None
+        import os
+        self.use_fused_stacks = os.environ.get("HOTRACK_FUSED_STACKS", "1") != "0"  # 0: round-2 path (library GEMMs + streaming BN)
 
     @staticmethod
     def supported(net) -> bool:
@@ -73,8 +75,18 @@ class FastTrain:
     # ------------------------------------------------------------------------------------------------------------------
     def _stack(self, x2d, convs, bns, first_done=False, max_over=0):
         """[1x1 conv + train-mode BatchNorm + ReLU]*; max_over = K > 0: the last layer also takes the max over every K
-        consecutive rows (its full-size activations are then never written)."""
+        consecutive rows (its full-size activations are then never written).  Layers 2.. run as fused BatchNorm GEMMs
+        (hotrack_amd.train_stack: normalise + ReLU on load, statistics in the epilogue, dY on load in the backward) when
+        their widths are covered; otherwise as library GEMM + streaming BatchNorm kernels (hotrack_amd.train_ops)."""
         from hotrack_amd.train_ops import bn_relu, bn_relu_max
+        if self.use_fused_stacks and len(convs) > 1:
+            from hotrack_amd import train_stack
+            widths = [c.weight.shape[0] for c in convs]
+            if train_stack.stack_supported(widths[0], widths[1:]):
+                y1 = x2d if first_done else F.linear(x2d, _w2d(convs[0]))
+                layers = [train_stack.Layer(None, bns[0], convs[0].bias)]
+                layers += [train_stack.Layer(_w2d(c), bn, c.bias) for c, bn in zip(convs[1:], bns[1:])]
+                return train_stack.mlp_stack(y1, layers, self.ws, max_over)
         last = len(convs) - 1
         for i, (conv, bn) in enumerate(zip(convs, bns)):
             y = x2d if (first_done and i == 0) else F.linear(x2d, _w2d(conv))
@@ -104,8 +116,9 @@ class FastTrain:
             outs.append(h.view(B, S, -1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
 
-    def _fp(self, mod, xyz1, xyz2, points1, points2):
-        """xyz1 (B,N,3), xyz2 (B,S,3), points1 (B,N,D1)|None, points2 (B,S,D2) -> (B*N, D') rows."""
+    def _fp(self, mod, xyz1, xyz2, points1, points2, extra=None):
+        """xyz1 (B,N,3), xyz2 (B,S,3), points1 (B,N,D1)|None, points2 (B,S,D2) -> (B*N, D') rows.
+        extra = (conv, bn): a further Conv1d + BatchNorm + ReLU appended to the module's stack (backbone conv1 / bn1)."""
         from hotrack_amd import ext
         from hotrack_amd.train_ops import interpolate_rows
         B, N, _ = xyz1.shape
@@ -115,7 +128,11 @@ class FastTrain:
             w, i3 = ext.three_nn_weights(xyz1, xyz2)
             interp = interpolate_rows(points2, i3, w)
         x = interp if points1 is None else torch.cat([points1, interp], dim=2)
-        return self._stack(x.reshape(B * N, -1), mod.mlp_convs, mod.mlp_bns)
+        convs, bns = list(mod.mlp_convs), list(mod.mlp_bns)
+        if extra is not None:
+            convs.append(extra[0])
+            bns.append(extra[1])
+        return self._stack(x.reshape(B * N, -1), convs, bns)
 
     # ------------------------------------------------------------------------------------------------------------------
     def forward(self, xyz2_cm: torch.Tensor, xyz1_cm: torch.Tensor):
@@ -146,9 +163,8 @@ class FastTrain:
         l3 = self._stack(x, bh.sa3.mlp_convs, bh.sa3.mlp_bns, max_over=S2).view(B, 1, -1)                    # (B,1,512)
         l2_out = self._fp(bh.fp3, l2_xyz, l2_xyz[:, :1], l2_feat, l3).view(B, S2, -1)
         l1_out = self._fp(bh.fp2, l1_xyz, l2_xyz, l1_feat, l2_out).view(B, S1, -1)
-        l0_out = self._fp(bh.fp1, xyz, l1_xyz, xyz, l1_out)                                             # (B*N, 128), skip = xyz
-        from hotrack_amd.train_ops import bn_relu
-        src2 = bn_relu(F.linear(l0_out, _w2d(bh.conv1)), bh.bn1, self.ws, bh.conv1.bias)               # (B*N, C)
+        # fp1 (skip = xyz) and the backbone's conv1 / bn1 as one stack [131 -> 128 -> 128 -> C]
+        src2 = self._fp(bh.fp1, xyz, l1_xyz, xyz, l1_out, extra=(bh.conv1, bh.bn1))                    # (B*N, C)
         C = src2.shape[1]
 
         # ---- q1 -> r1 -> q2 -> r2 around the J keypoints; one kNN search for both neighbourhood sizes ------------------

@@ -260,3 +260,118 @@ def test_graph_captured_data_parallel_step_two_ranks_one_gpu():
     assert len(line) == 1, out.stdout[-2000:]
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["graph_step"] is True and d["dp_mode"] == "flat" and d["loss"] == d["loss"]
+
+
+# ---- fused BatchNorm GEMM stacks (csrc/train_gemm.hip, hotrack_amd/train_stack.py) ---------------------------------------------
+@pytest.mark.parametrize("R,widths,K", [
+    (32 * 64, [32, 32, 64], 32),        # sa1 widths: 32-column tiles, wgrad with four row groups per workgroup
+    (4000, [64, 64, 128], 0),           # ragged last row tile (4000 = 31 * 128 + 32), dense top
+    (21 * 16 * 5, [128, 128, 192], 16), # keypoint-query widths: 192 = three 64-column tiles, max over K = 16
+    (21 * 64 * 2, [128, 128, 192], 64),
+    (1500, [128, 128, 512], 0),         # four 128-column tiles
+    (999, [256, 256], 0),               # two-layer stack (feature propagation), K = 256: eight reduction chunks
+    (2048, [128, 128, 384], 0),         # fp1 + conv1
+    (128 * 3, [128, 128, 512], 128),    # sa3: max over all 128 points of a cloud
+])
+def test_mlp_stack_matches_torch(R, widths, K):
+    """train_stack.mlp_stack (fused BatchNorm GEMMs) vs the same stack as torch modules in fp64: forward, running statistics,
+    and every gradient (dY_1, weights, gamma / beta; conv biases get exact zeros)."""
+    from hotrack_amd import train_stack
+    from hotrack_amd.train_ops import Workspace
+    g = torch.Generator(device="cuda").manual_seed(R + sum(widths) + K)
+    C1 = widths[0]
+    y1 = (torch.randn(R, C1, device="cuda", generator=g) * 1.5 + 0.3)
+    convs = [torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])]
+    bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in widths]
+    bias1 = torch.randn(C1, device="cuda", generator=g).requires_grad_(True)
+    with torch.no_grad():
+        for i, bn in enumerate(bns):
+            bn.weight.copy_(1 + 0.3 * torch.randn(bn.weight.shape, device="cuda", generator=g))
+            bn.bias.copy_(0.2 * torch.randn(bn.bias.shape, device="cuda", generator=g))
+            bn.momentum = 0.07
+    ref_convs = [torch.nn.Conv1d(a, b, 1).cuda().double() for a, b in zip(widths[:-1], widths[1:])]
+    ref_bns = [torch.nn.BatchNorm1d(c).cuda().double().train() for c in widths]
+    for c, rc in zip(convs, ref_convs):
+        rc.load_state_dict({k: v.double() for k, v in c.state_dict().items()})
+    for b, rb in zip(bns, ref_bns):
+        rb.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in b.state_dict().items()})
+        rb.momentum = b.momentum
+    assert train_stack.stack_supported(C1, widths[1:])
+    import copy
+    convs_c, bns_c = copy.deepcopy(convs), copy.deepcopy(bns)  # for the round-2 baseline below
+    # fused
+    ws = Workspace("cuda")
+    ya = y1.clone().requires_grad_(True)
+    layers = [train_stack.Layer(None, bns[0], bias1)] + [train_stack.Layer(c.weight.view(c.weight.shape[0], -1), bn, c.bias)
+                                                         for c, bn in zip(convs, bns[1:])]
+    out = train_stack.mlp_stack(ya, layers, ws, max_over=K)
+    go = torch.randn(out.shape, device="cuda", generator=g)
+    out.backward(go)
+    # reference (fp64 torch modules; the layer-1 bias enters in front of its BatchNorm as in the network)
+    yb = y1.double().clone().requires_grad_(True)
+    b1 = bias1.detach().double().clone().requires_grad_(True)
+    h = torch.relu(ref_bns[0](yb + b1))
+    for rc, rb in zip(ref_convs, ref_bns[1:]):
+        h = torch.relu(rb(rc(h.t().unsqueeze(0)).squeeze(0).t()))
+    ref = h.view(R // K, K, -1).max(dim=1)[0] if K else h
+    ref.backward(go.double())
+    torch.testing.assert_close(out.double(), ref, rtol=2e-4, atol=2e-4)
+    for b, rb in zip(bns, ref_bns):
+        torch.testing.assert_close(b.running_mean.double(), rb.running_mean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(b.running_var.double(), rb.running_var, rtol=1e-4, atol=1e-5)
+        assert int(b.num_batches_tracked) == 1
+
+    # the same stack through the round-2 kernels (library GEMMs + streaming BatchNorm): train-mode BatchNorm chains amplify
+    # fp32 round-off, so the bar for the fused path is "as close to fp64 as the unfused fp32 path", not an absolute number
+    from hotrack_amd.train_ops import bn_relu, bn_relu_max
+    yc = y1.clone().requires_grad_(True)
+    x = bn_relu(yc, bns_c[0], ws, bias1.detach().clone().requires_grad_(True))
+    for i, (c, bn) in enumerate(zip(convs_c, bns_c[1:])):
+        yy = torch.nn.functional.linear(x, c.weight.view(c.weight.shape[0], -1))
+        x = bn_relu_max(yy, K, bn, ws, c.bias) if (K and i == len(convs) - 1) else bn_relu(yy, bn, ws, c.bias)
+    x.backward(go)
+    base = float((yc.grad.double() - yb.grad).abs().max()) / (float(yb.grad.abs().max()) + 1e-12)
+
+    def close(a, b, what, tol=2e-3):
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a.double() - b).abs().max()) / scale
+        assert err < tol, (what, err, tol)
+
+    close(ya.grad, yb.grad, "dy1", max(2e-3, 3 * base))
+    for i, (c, rc) in enumerate(zip(convs, ref_convs)):
+        close(c.weight.grad, rc.weight.grad, f"dW{i + 2}")
+        assert c.bias.grad is not None and float(c.bias.grad.abs().max()) == 0.0  # bias in front of a BatchNorm: exactly zero
+    for i, (b, rb) in enumerate(zip(bns, ref_bns)):
+        close(b.weight.grad, rb.weight.grad, f"dgamma{i + 1}")
+        close(b.bias.grad, rb.bias.grad, f"dbeta{i + 1}")
+    assert bias1.grad is not None and float(bias1.grad.abs().max()) == 0.0
+
+
+def test_mlp_stack_second_backward_and_stale_workspace():
+    """the fp64 backward accumulators are this forward's workspace slices only for its FIRST backward and only
+    while no later forward reset the workspace; otherwise fresh zeros are used -- gradients never double-count."""
+    from hotrack_amd import train_stack
+    from hotrack_amd.train_ops import Workspace
+    g = torch.Generator(device="cuda").manual_seed(3)
+    R, widths = 1024, [32, 32, 64]
+    convs = [torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])]
+    bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in widths]
+    ws = Workspace("cuda")
+
+    def run(y):
+        layers = [train_stack.Layer(None, bns[0])] + [train_stack.Layer(c.weight.view(c.weight.shape[0], -1), bn, c.bias)
+                                                     for c, bn in zip(convs, bns[1:])]
+        return train_stack.mlp_stack(y, layers, ws, max_over=32)
+
+    y = torch.randn(R, 32, device="cuda", generator=g).requires_grad_(True)
+    ws.reset()
+    out = run(y)
+    go = torch.randn(out.shape, device="cuda", generator=g)
+    (g1,) = torch.autograd.grad(out, y, go, retain_graph=True)
+    (g2,) = torch.autograd.grad(out, y, go, retain_graph=True)   # second backward through the same graph
+    torch.testing.assert_close(g1, g2, rtol=1e-5, atol=1e-6)
+    ws.reset()
+    out_b = run(y.detach().clone().requires_grad_(True))           # a later forward resets the workspace ...
+    (g3,) = torch.autograd.grad(out, y, go)                        # ... and the first graph's backward still gives the same
+    torch.testing.assert_close(g1, g3, rtol=1e-5, atol=1e-6)
+    assert out_b.shape == out.shape
