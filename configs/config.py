@@ -62,5 +62,8 @@ def get_config(args, save=True):
         cfg["device"] = torch.device("cuda", local % torch.cuda.device_count())  # (% only matters for the shared-GPU self-test)
     else:
         cfg["device"] = "cpu"
+    if cfg.get("hand_model") == "synthetic":  # the same instance poses the synthetic sequences and drives the optimiser
+        from models.hand_model import SyntheticLBSHand
+        cfg["hand_model"] = SyntheticLBSHand()
     print("Running on ", cfg["device"])
     return cfg

@@ -69,6 +69,9 @@ class SyntheticSequences(Dataset):
 
 def get_dataloader(cfg, mode="train", shuffle=False, num_workers=0, distributed=False, length=None):
     syn = cfg["data_cfg"].get("synthetic", {})
+    if cfg.get("track") == "hand_IKNet" and cfg.get("use_optimization") and cfg.get("hand_model") is not None:
+        ds = SyntheticHandObjectSequences(cfg, syn.get("test_sequences", 2), syn.get("sequence_frames", 20) if length is None else length)
+        return torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, collate_fn=lambda b: b[0])
     if cfg.get("track") == "obj_opt":
         ds = SyntheticObjectSequences(cfg, syn.get("test_sequences", 2), syn.get("sequence_frames", 30) if length is None else length)
         return torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, collate_fn=lambda b: b[0])
@@ -154,4 +157,62 @@ class SyntheticObjectSequences(Dataset):
             seq.append(fr)
             R = R @ _rot(w_axis, w)
             t = t + vel
+        return seq
+
+
+class SyntheticHandObjectSequences(Dataset):
+    """Sequences for `track: hand_IKNet` with `use_optimization` and a hand model (HandTrackModel's particle-optimisation
+    branch, reference track_network.py:142-156, :203-211): a hand (cfg['hand_model'], models/hand_model.HandModel) grasping the
+    synthetic capsule.  Per frame: hand_points sampled on the posed hand's vertices (+ sensor noise), gt / jittered keypoints,
+    gt_hand_pose (palm template of the model's rest pose, rotation, translation), gt_obj_pose, projection, the silhouette's
+    background mask; frame 0 also carries the object's SDF volume."""
+
+    def __init__(self, cfg, num_sequences: int, frames: int, res: int = 151, stride: float = 0.003):
+        self.cfg, self.ns, self.nf, self.res, self.stride = cfg, num_sequences, frames, res, stride
+        self.hand = cfg["hand_model"]
+        self._vol = None
+
+    def __len__(self):
+        return self.ns
+
+    def __getitem__(self, s):
+        if self._vol is None:
+            self._vol = torch.from_numpy(capsule_volume(self.res, self.stride))
+        rng = np.random.default_rng(50_000 + s)
+        n = self.cfg["num_points"]
+        jitter = self.cfg["hand_jitter_cfg"]["rand_scale"]
+        f = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+        R_obj = _rot(rng.standard_normal(3), rng.uniform(0, np.pi))
+        t_obj = np.array([0.0, 0.0, 0.5]) + rng.uniform(-0.03, 0.03, 3)
+        proj = dict(fx=600.0, fy=600.0, cx=320.0, cy=240.0, w=640, h=480)
+        u, v = t_obj[0] / t_obj[2] * proj["fx"] + proj["cx"], t_obj[1] / t_obj[2] * proj["fy"] + proj["cy"]
+        yy, xx = np.mgrid[0:proj["h"], 0:proj["w"]]
+        background = torch.from_numpy(~((xx - u) ** 2 + (yy - v) ** 2 < 110 ** 2))
+        hm = self.hand.cpu()
+        with torch.no_grad():
+            _, rest_kp = hm.forward(th_pose_coeffs=torch.zeros(1, 3 + hm.num_pose), th_trans=torch.zeros(1, 3))
+        palm = rest_kp[:, PALM]
+        seq = []
+        for k in range(self.nf):
+            R_ho = _rot(np.array([0.3, 0.2, 1.0]), 0.15 + 0.02 * k)
+            t_ho = np.array([0.002 * k, -0.135 + 0.002 * k, 0.045])
+            R = (R_obj @ R_ho).astype(np.float32)
+            t = (R_obj @ t_ho + t_obj).astype(np.float32)
+            theta = (0.2 * np.sin(np.arange(hm.num_pose) * 0.7 + 0.2 * k)).astype(np.float32)
+            # axis-angle of R: the hand model takes the global rotation that way
+            ang = np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
+            ax = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2 * np.sin(ang) + 1e-12)
+            with torch.no_grad():
+                verts, kp = hm.forward(th_pose_coeffs=torch.cat([f(ax * ang)[None], f(theta)[None]], 1), th_trans=f(t)[None])
+            pick = rng.integers(0, verts.shape[1], n)
+            pts = verts[0, pick].numpy() + rng.normal(0, 0.0015, (n, 3))
+            fr = {"hand_points": f(pts).unsqueeze(0), "gt_hand_kp": kp.clone(), "jittered_hand_kp": kp + f(rng.normal(0, jitter, (1, 21, 3))),
+                  "gt_hand_pose": {"palm_template": palm.clone(), "rotation": f(R).reshape(1, 3, 3), "translation": f(t).reshape(1, 3, 1),
+                                   "mano_pose": f(theta)[None]},
+                  "gt_obj_pose": {"rotation": f(R_obj).reshape(1, 3, 3), "translation": f(t_obj).reshape(1, 3, 1)},
+                  "projection": {kk: [vv] for kk, vv in proj.items()}, "background_mask": background,
+                  "category": [self.cfg["obj_category"][0]], "file_name": [f"synthetic_handobj_{s:03d}/{k:04d}"]}
+            if k == 0:
+                fr["sdf_volume"], fr["voxel_scale"] = self._vol, self.stride
+            seq.append(fr)
         return seq

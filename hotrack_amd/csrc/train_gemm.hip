@@ -266,17 +266,28 @@ __device__ __forceinline__ void dy_constants(const DySrc &d, int C, int c0, int 
     }
 }
 
+// the constants of four consecutive channels, fetched from LDS ONCE per chunk and thread (a thread's channels are the same
+// for all its rows of a chunk; re-reading them per row made the commit phase LDS-bound: 32 ds_read_b128 per thread and chunk)
+struct DyConst {
+    float4 c0[4], c1[4];  // c0 = mean, invstd, scale, m1; c1 = m2, gamma, beta, -
+};
+__device__ __forceinline__ void dy_load_constants(DyConst &c, const float *cst) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        c.c0[e] = *reinterpret_cast<const float4 *>(cst + 8 * e);
+        c.c1[e] = *reinterpret_cast<const float4 *>(cst + 8 * e + 4);
+    }
+}
 // one float4 of dY from the fetched registers (g: gradient source, y: pre-activation, ar: arg-max rows (GMODE 2)); kk = row
-// within its max group (GMODE 2); cst points at the constants of the first of the four channels
+// within its max group (GMODE 2)
 template <int GMODE>
-__device__ __forceinline__ float4 dy_value(float4 gv, float4 yv, int4 av, int kk, bool valid, const float *cst) {
+__device__ __forceinline__ float4 dy_value(float4 gv, float4 yv, int4 av, int kk, bool valid, const DyConst &c) {
     const float g[4] = {gv.x, gv.y, gv.z, gv.w}, y[4] = {yv.x, yv.y, yv.z, yv.w};
     const int ar[4] = {av.x, av.y, av.z, av.w};
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float4 c0 = *reinterpret_cast<const float4 *>(cst + 8 * e);
-        const float4 c1 = *reinterpret_cast<const float4 *>(cst + 8 * e + 4);
+        const float4 c0 = c.c0[e], c1 = c.c1[e];
         const float xhat = (y[e] - c0.x) * c0.y;
         float gg = g[e];
         if constexpr (GMODE == 2) gg = ar[e] == kk ? gg : 0.f;
@@ -349,6 +360,8 @@ tg_dgrad_kernel(DgradArgs a) {
     };
     auto commit = [&](long tile, int chunk, bool with_b) {
         const int k = chunk * KC + 4 * kq;
+        DyConst dc;
+        dy_load_constants(dc, cstA + 8 * k);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long row = tile * BM + rb + 32 * i;
@@ -359,7 +372,7 @@ tg_dgrad_kernel(DgradArgs a) {
                 kk = d.kshift >= 0 ? (rr & (d.Kmax - 1)) : (rr % d.Kmax);
                 av = par[i];
             }
-            const float4 dyv = dy_value<GMODE>(pg[i], py[i], av, kk, row < a.R, cstA + 8 * k);
+            const float4 dyv = dy_value<GMODE>(pg[i], py[i], av, kk, row < a.R, dc);
             float *dst = As + (rb + 32 * i) * LDK + 4 * kq;
             dst[0] = dyv.x; dst[1] = dyv.y; dst[2] = dyv.z; dst[3] = dyv.w;
         }
@@ -510,6 +523,11 @@ tg_wgrad_kernel(WgradArgs a) {
             ph[i] = *reinterpret_cast<const float4 *>(a.Yp + row * a.ldyp + j0 + 4 * hjq);
         }
     };
+    DyConst dc;  // this thread's four dY channels and four H channels are the same for every chunk of the kernel
+    dy_load_constants(dc, cstA + 8 * 4 * anq);
+    float4 c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = *reinterpret_cast<const float4 *>(cstH + 4 * (4 * hjq + e));
     auto commit = [&](long rbase) {
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
@@ -522,11 +540,8 @@ tg_wgrad_kernel(WgradArgs a) {
                 kk = d.kshift >= 0 ? (rr_ & (d.Kmax - 1)) : (rr_ % d.Kmax);
                 av = par[i];
             }
-            *reinterpret_cast<float4 *>(Ad + rr * MT + 4 * anq) = dy_value<GMODE>(pg[i], py[i], av, kk, row < r_end, cstA + 8 * 4 * anq);
+            *reinterpret_cast<float4 *>(Ad + rr * MT + 4 * anq) = dy_value<GMODE>(pg[i], py[i], av, kk, row < r_end, dc);
         }
-        float4 c[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) c[e] = *reinterpret_cast<const float4 *>(cstH + 4 * (4 * hjq + e));
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
             const int rr = hr0 + (kT / HQ) * i;

@@ -14,14 +14,28 @@ from . import pointnet_utils
 
 
 class HandTrackModel(nn.Module):
-    def __init__(self, cfg, handnet, IKnet=None):
+    """hand_model (models/hand_model.HandModel, e.g. a MANO layer with the reference's call signature): enables the
+    hand-pose particle optimisation of the reference's `use_optimization` branch (track_network.py:142-156, :203-211) on
+    top of the HandTrackNet tracking loop.  In the reference that branch sits behind IKNet, which supplies the initial
+    MANO pose code and global pose; IKNet needs the MANO assets and its checkpoint, so here those two inputs come from a
+    stand-in with the same role (`_pose_init`): the pose code of the previous frame's optimum and the rigid fit of the hand
+    model's keypoints to HandTrackNet's prediction (device Kabsch).  Everything downstream -- visibility mask, candidate
+    evaluation, update rule, what is fed to the next frame -- is the reference's."""
+
+    def __init__(self, cfg, handnet, IKnet=None, hand_model=None):
         super().__init__()
-        if IKnet is not None or cfg.get("use_optimization", False):
-            raise NotImplementedError("IKNet / particle optimisation need MANO + DeepSDF assets (out of scope)")
+        if IKnet is not None:
+            raise NotImplementedError("IKNet needs the MANO assets and its checkpoint (out of scope)")
         self.device = cfg["device"]
         self.handnet = handnet(cfg)
         self.use_graph = True  # GPU + fused backend: one captured HIP graph per (N, keypoints) shape, replayed per frame
         self._graphs = {}
+        self.use_optimization = bool(cfg.get("use_optimization", False)) and hand_model is not None
+        self.use_pred_obj_pose = bool(cfg.get("use_pred_obj_pose", False))
+        self.optimizer = None
+        if self.use_optimization:
+            from .optimization_hand import gf_optimize_hand_pose
+            self.optimizer = gf_optimize_hand_pose(cfg, hand_model=hand_model, particle_size=int(cfg.get("hand_particles", 5120)))
 
     # A captured graph bakes in the pointers of the BN-folded weights FastEval built at capture time: anything that can
     # change the weights (checkpoint load, fine-tuning, .to()/.float()) drops the captured graphs.
@@ -68,15 +82,34 @@ class HandTrackModel(nn.Module):
         graph.replay()
         return {k: (v.clone() if torch.is_tensor(v) else {kk: vv.clone() for kk, vv in v.items()}) for k, v in out.items()}
 
+    def _pose_init(self, pred_kp, prev_theta):
+        """Stand-in for IKNet's two outputs (see the class docstring): MANO_theta (1,45) and global_pose."""
+        from hotrack_amd import ext
+        hm = self.optimizer.mano_layer_right
+        theta = prev_theta if prev_theta is not None else torch.zeros((1, hm.num_pose), device=pred_kp.device)
+        with torch.no_grad():
+            _, kp0 = hm.forward(th_pose_coeffs=torch.cat([torch.zeros((1, 3), device=pred_kp.device), theta], dim=1),
+                                th_trans=torch.zeros((1, 3), device=pred_kp.device))
+            R, t = ext.kabsch(kp0.contiguous(), pred_kp.contiguous())  # pred ~ R kp0 + t
+        return theta, {"rotation": R.reshape(1, 3, 3), "translation": t.reshape(1, 3, 1)}
+
     def forward(self, input, flag_dict):
         flag_dict["track_flag"] = True
         assert flag_dict["test_flag"]
-        flag_dict["opt_flag"] = False
+        flag_dict["opt_flag"] = self.use_optimization
         palm_template = input[0]["gt_hand_pose"]["palm_template"].to(self.device).float()
         last_kp = None
         rets = []
         graph_ok = (self.use_graph and pointnet_utils.fused_backend() is not None and not self.training
                     and not torch.is_grad_enabled() and torch.device(self.device).type == "cuda")
+        if self.use_optimization:
+            flag_dict["IKNet_flag"] = True  # HandTrackNet also returns the keypoint visibility mask (hand_network.py:149-155)
+            if "sdf_volume" in input[0]:
+                self.optimizer.load_volume(input[0]["sdf_volume"], input[0].get("voxel_scale"))
+            elif self.optimizer.sdf_volume is None:
+                raise RuntimeError("use_optimization: no SDF volume (decoding it from a DeepSDF latent needs the checkpoints); "
+                                   "put 'sdf_volume' / 'voxel_scale' into the sequence's first frame")
+        prev_theta = None
         for data in input:
             data["pred_palm_template"] = palm_template
             points = data["hand_points"].to(self.device, non_blocking=True).float()
@@ -87,6 +120,15 @@ class HandTrackModel(nn.Module):
                 ret = self._graph_step(points, data["jittered_hand_kp"].to(self.device).float(), palm_template, flag_dict)
             else:
                 ret = self.handnet(data, flag_dict)
+            if self.use_optimization:  # track_network.py:142-156 (IKNet's role: _pose_init), :203-211
+                ret["baseline_pred_kp"] = ret["pred_kp"].clone()
+                theta0, pose0 = self._pose_init(ret["baseline_pred_kp"], prev_theta)
+                obj_pose = data["pred_obj_pose"] if (self.use_pred_obj_pose and "pred_obj_pose" in data) else data["gt_obj_pose"]
+                kp, theta, rot, trans = self.optimizer.optimize(theta0, pose0, ret["baseline_pred_kp"], last_kp, ret["pred_kp_vis_mask"],
+                                                                obj_pose, data.get("pred_beta"), data["projection"], data["background_mask"])
+                ret["pred_kp"], ret["MANO_theta"] = kp, theta
+                ret["global_pose"] = {"rotation": rot.unsqueeze(0), "translation": trans.unsqueeze(-1)}
+                prev_theta = theta
             last_kp = (ret["pred_kp"] - centre).clone()
             rets.append(ret)
         return rets

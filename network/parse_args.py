@@ -29,4 +29,8 @@ def add_args(parser):
     # additions of this repo (synthetic runs)
     parser.add_argument("--synthetic_frames", type=int, default=None, help="length of the synthetic train set / sequences")
     parser.add_argument("--max_iters", type=int, default=None, help="stop an epoch after this many iterations (smoke runs)")
+    parser.add_argument("--hand_model", type=str, default=None, choices=["synthetic"],
+                        help="track=hand_IKNet with use_optimization: the hand model of the pose optimiser ('synthetic' = the "
+                             "linear-blend-skinning stand-in of models/hand_model.py; a MANO layer is passed programmatically)")
+    parser.add_argument("--hand_particles", type=int, default=None, help="candidate hands per optimiser iteration (reference: 5120)")
     return parser

@@ -65,13 +65,26 @@ class Trainer(nn.Module):
         if cfg["track"] == "hand":
             self.model = HandTrackModel(cfg, handnet=HandTrackNet)
         elif cfg["track"] == "hand_IKNet":
-            # reference: HandTrackModel(handnet, IKnet=IKNet) + MANO shape / pose optimisation (trainer.py:120-127).  IKNet,
-            # the MANO layer and the hand optimiser's silhouette / regularisation terms need licensed assets (SURVEY.md
-            # section 2 rows 9, 16, 21): without them the entry runs the HandTrackNet tracking branch of the same loop
-            # (track_network.py:214-217) and says so.
-            self.log_string("track=hand_IKNet: IKNet / MANO assets are not available -> HandTrackNet tracking branch only")
-            cfg = dict(cfg, use_optimization=False)
-            self.model = HandTrackModel(cfg, handnet=HandTrackNet)
+            # reference: HandTrackModel(handnet, IKnet=IKNet) + MANO shape / pose optimisation (trainer.py:120-127).  IKNet and
+            # the MANO layer need licensed assets.  With a hand model supplied
+            # (cfg['hand_model']: any models/hand_model.HandModel -- a MANO layer, or `--hand_model synthetic`) the entry runs
+            # HandTrackNet tracking + the hand-pose particle optimisation (models/optimization_hand.py; IKNet's role is taken
+            # by HandTrackModel._pose_init); without one, the HandTrackNet tracking branch of the same loop
+            # (track_network.py:214-217) -- and says so.
+            hm = cfg.get("hand_model")
+            if isinstance(hm, str):
+                if hm != "synthetic":
+                    raise ValueError("hand_model: 'synthetic' or a models.hand_model.HandModel instance")
+                from models.hand_model import SyntheticLBSHand
+                hm = SyntheticLBSHand()
+                cfg["hand_model"] = hm  # the synthetic sequences pose the same model
+            if hm is not None and cfg.get("use_optimization", False):
+                self.log_string("track=hand_IKNet: HandTrackNet tracking + hand-pose particle optimisation (hand model: %s; "
+                                "IKNet's initial pose from the previous frame + a rigid keypoint fit)" % type(hm).__name__)
+                self.model = HandTrackModel(cfg, handnet=HandTrackNet, hand_model=hm)
+            else:
+                self.log_string("track=hand_IKNet: no hand model (IKNet / MANO assets are not available) -> HandTrackNet tracking branch only")
+                self.model = HandTrackModel(dict(cfg, use_optimization=False), handnet=HandTrackNet)
         elif cfg["track"] == "obj_opt":
             self.model = ObjTrackModel_Optimization(cfg)
         elif not cfg["track"]:
