@@ -188,7 +188,8 @@ class SyntheticHandObjectSequences(Dataset):
         u, v = t_obj[0] / t_obj[2] * proj["fx"] + proj["cx"], t_obj[1] / t_obj[2] * proj["fy"] + proj["cy"]
         yy, xx = np.mgrid[0:proj["h"], 0:proj["w"]]
         background = torch.from_numpy(~((xx - u) ** 2 + (yy - v) ** 2 < 110 ** 2))
-        hm = self.hand.cpu()
+        import copy
+        hm = copy.deepcopy(self.hand).cpu()  # (the optimiser's instance lives on the GPU: nn.Module.cpu() moves in place)
         with torch.no_grad():
             _, rest_kp = hm.forward(th_pose_coeffs=torch.zeros(1, 3 + hm.num_pose), th_trans=torch.zeros(1, 3))
         palm = rest_kp[:, PALM]

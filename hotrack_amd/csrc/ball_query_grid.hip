@@ -209,18 +209,47 @@ query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__
             for (int blk = 0; blk < H.nblocks && cnt < nsample; ++blk) {
                 *reinterpret_cast<uint4 *>(bm + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
                 const int kb = blk * H.ncell;
-                for (int ix = x0; ix <= x1; ++ix)
-                    for (int iy = y0; iy <= y1; ++iy) {
-                        const int key = kb + (ix * H.gy + iy) * H.gz;
-                        const int p0 = tab[key + z0], p1 = tab[key + z1 + 1];  // the z-neighbours are contiguous records
-                        for (int p = p0 + lane; p < p1; p += 64) {
-                            const float4 r = rec[p];
-                            if (sqdist(qx, qy, qz, r.x, r.y, r.z) < radius2) {
-                                const int k = __builtin_bit_cast(int, r.w) & (NB - 1);
+                // the (up to) nine runs of this block -- one per (x, y) column, its z-neighbours being contiguous records --
+                // are walked as ONE flattened candidate list: every step issues 64 independent record loads (walking the runs
+                // one after the other made a step a dependent L2 round trip for a handful of candidates each)
+                int rp0[9], rlen[9], ncand = 0;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const int ix = x0 + r / 3, iy = y0 + r % 3;
+                    const bool in = ix <= x1 && iy <= y1;
+                    const int key = kb + ((in ? ix : x0) * H.gy + (in ? iy : y0)) * H.gz;
+                    const int p0 = tab[key + z0], p1 = tab[key + z1 + 1];
+                    rp0[r] = p0;
+                    rlen[r] = in ? p1 - p0 : 0;
+                    ncand += rlen[r];
+                }
+                if (ncand > 384) {  // long runs (dense neighbourhoods): every run fills whole waves by itself, no flattening arithmetic
+#pragma unroll
+                    for (int r = 0; r < 9; ++r)
+                        for (int p = rp0[r] + lane; p < rp0[r] + rlen[r]; p += 64) {
+                            const float4 rc = rec[p];
+                            if (sqdist(qx, qy, qz, rc.x, rc.y, rc.z) < radius2) {
+                                const int k = __builtin_bit_cast(int, rc.w) & (NB - 1);
                                 atomicOr(&bm[k >> 5], 1u << (k & 31));
                             }
                         }
+                    ncand = 0;
+                }
+                for (int f0 = 0; f0 < ncand; f0 += 64) {
+                    int f = f0 + lane, p = -1;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        p = (f >= 0 && f < rlen[r]) ? rp0[r] + f : p;
+                        f -= rlen[r];
                     }
+                    if (p >= 0) {
+                        const float4 r = rec[p];
+                        if (sqdist(qx, qy, qz, r.x, r.y, r.z) < radius2) {
+                            const int k = __builtin_bit_cast(int, r.w) & (NB - 1);
+                            atomicOr(&bm[k >> 5], 1u << (k & 31));
+                        }
+                    }
+                }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const uint4 wv = *reinterpret_cast<const uint4 *>(bm + 4 * lane);

@@ -115,28 +115,24 @@ kabsch_kernel(int b, int xb, int num, const float *__restrict__ x_all, const flo
 // where G = dL/dR - (dL/dt) cx^T collects the rotation gradient (t = cy - R cx), and then
 //     dL/dy_i = (x_i - cx)^T dL/dw + (dL/dt)^T / num        (sum_i (x_i - cx) = 0, so centring y adds nothing).
 // The same derivative autograd takes through an SVD; ~90 element-wise torch launches on (B,3,3) tensors otherwise.
-__global__ void __launch_bounds__(64)
-kabsch_bwd_kernel(int b, int xb, int num, const float *__restrict__ x_all, const float *__restrict__ y_all,
-                  const float *__restrict__ R_all, const float *__restrict__ gR_all, const float *__restrict__ gt_all,
-                  float *__restrict__ dy_all) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= b) return;
-    const float *x = x_all + (size_t)(xb == 1 ? 0 : i) * num * 3, *y = y_all + (size_t)i * num * 3;
+// one fit; y rows are ystride floats apart, dy likewise (dystride); gR (row-major 3x3) / gt may be null
+__device__ void kabsch_backward_one(int num, const float *x, const float *y, int ystride, const float *Rf, const double *gR, const double *gtv,
+                                    float *dy, int dystride, float dy_scale, bool accumulate) {
     double cx[3] = {0, 0, 0}, cy[3] = {0, 0, 0};
     for (int p = 0; p < num; ++p)
-        for (int a = 0; a < 3; ++a) { cx[a] += x[3 * p + a]; cy[a] += y[3 * p + a]; }
+        for (int a = 0; a < 3; ++a) { cx[a] += x[3 * p + a]; cy[a] += y[(size_t)ystride * p + a]; }
     const double inv = 1.0 / num;
     for (int a = 0; a < 3; ++a) { cx[a] *= inv; cy[a] *= inv; }
     double w[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int p = 0; p < num; ++p)
         for (int a = 0; a < 3; ++a)
-            for (int c = 0; c < 3; ++c) w[a][c] += ((double)x[3 * p + a] - cx[a]) * ((double)y[3 * p + c] - cy[c]);
+            for (int c = 0; c < 3; ++c) w[a][c] += ((double)x[3 * p + a] - cx[a]) * ((double)y[(size_t)ystride * p + c] - cy[c]);
     double R[3][3], G[3][3], gt[3];
-    for (int a = 0; a < 3; ++a) gt[a] = gt_all ? (double)gt_all[(size_t)i * 3 + a] : 0.0;
+    for (int a = 0; a < 3; ++a) gt[a] = gtv ? gtv[a] : 0.0;
     for (int a = 0; a < 3; ++a)
         for (int c = 0; c < 3; ++c) {
-            R[a][c] = R_all[(size_t)i * 9 + 3 * a + c];
-            G[a][c] = (gR_all ? (double)gR_all[(size_t)i * 9 + 3 * a + c] : 0.0) - gt[a] * cx[c];
+            R[a][c] = Rf[3 * a + c];
+            G[a][c] = (gR ? gR[3 * a + c] : 0.0) - gt[a] * cx[c];
         }
     double sym[3][3], Bm[3][3];
     for (int a = 0; a < 3; ++a)
@@ -168,13 +164,141 @@ kabsch_bwd_kernel(int b, int xb, int num, const float *__restrict__ x_all, const
             for (int k = 0; k < 3; ++k) s += R[k][a] * hat[k][c];
             dW[a][c] = 2.0 * s;
         }
-    float *dy = dy_all + (size_t)i * num * 3;
     for (int p = 0; p < num; ++p)
         for (int c = 0; c < 3; ++c) {
             double s = gt[c] * inv;
             for (int a = 0; a < 3; ++a) s += ((double)x[3 * p + a] - cx[a]) * dW[a][c];
-            dy[3 * p + c] = (float)s;
+            float *o = dy + (size_t)dystride * p + c;
+            *o = (accumulate ? *o : 0.f) + dy_scale * (float)s;
         }
+}
+
+__global__ void __launch_bounds__(64)
+kabsch_bwd_kernel(int b, int xb, int num, const float *__restrict__ x_all, const float *__restrict__ y_all,
+                  const float *__restrict__ R_all, const float *__restrict__ gR_all, const float *__restrict__ gt_all,
+                  float *__restrict__ dy_all) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= b) return;
+    double gR[9], gt[3];
+    for (int a = 0; a < 9; ++a) gR[a] = gR_all ? (double)gR_all[(size_t)i * 9 + a] : 0.0;
+    for (int a = 0; a < 3; ++a) gt[a] = gt_all ? (double)gt_all[(size_t)i * 3 + a] : 0.0;
+    kabsch_backward_one(num, x_all + (size_t)(xb == 1 ? 0 : i) * num * 3, y_all + (size_t)i * num * 3, 3, R_all + (size_t)i * 9, gR, gt,
+                        dy_all + (size_t)i * num * 3, 3, 1.f, false);
+}
+
+// ---- the loss / metric dictionary of HandTrackNet.compute_loss (reference hand_network.py:159-221) in two launches ---------------
+// Forward: per cloud b (two lanes: role 0 fits the ground-truth palm, role 1 the predicted palm)
+//   gt_hf = R_c^T (gt - t_c) / s; pred_s = s pred_hf, gt_s = s gt_hf, init_s = s init_hf           (canonicalize, hand_utils.py:30-31)
+//   out[0] hand_pred_kp_loss = mean |pred_s - gt_s|           out[1] hand_pred_r_loss = mean |R - R_gt|    out[2] hand_pred_t_loss = mean |t - t_gt|
+//   out[3] hand_pred_kp_diff = mean_k ||pred_kp - gt_kp||      out[4] hand_init_kp_diff = mean_k ||init_s - gt_s||
+//   out[5] hand_init_r_diff = mean angle(R_gt) [deg]           out[6] hand_init_t_diff = mean ||t_gt||
+//   out[7] hand_pred_r_diff = mean angle(R^T R_gt) [deg]       out[8] hand_pred_t_diff = mean ||t - t_gt||
+// with (R, t) = Kabsch(palm template -> palm keypoints of pred_s), (R_gt, t_gt) likewise of gt_s (hand_network.py:186-190).
+// The torch composition of the same dictionary is ~75 launches of 4-5 us in a captured training step (forward + backward).
+constexpr int kHlJ = 21, kHlPalm = 6;
+__constant__ int kHlPalmIdx[kHlPalm] = {0, 1, 5, 9, 13, 17};  // hand_utils.handkp2palmkp
+
+__global__ void __launch_bounds__(128)
+hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const float *__restrict__ init_hf, const float *__restrict__ gt_kp,
+                     const float *__restrict__ pred_kp, const float *__restrict__ Rc, const float *__restrict__ tc, float s,
+                     const float *__restrict__ palm, float *__restrict__ out, float *__restrict__ saved) {
+    // saved per cloud: [0:63) gt_s (3,21 channel-major) | [63:72) R | [72:75) t | [75:84) R_gt | [84:87) t_gt
+    __shared__ float acc[9];
+    __shared__ float xch[64][12];
+    if (threadIdx.x < 9) acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int role = threadIdx.x & 1, slot = threadIdx.x >> 1;
+    float part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + slot;
+        const bool on = b < B;
+        double R[3][3], t[3];
+        float yl[kHlPalm * 3];
+        if (on) {
+            const float *Rb = Rc + 9 * (size_t)b, *tb = tc + 3 * (size_t)b;
+            float *sv = saved + 87 * (size_t)b;
+            for (int k = 0; k < kHlJ; ++k) {
+                const float *g = gt_kp + ((size_t)b * kHlJ + k) * 3;
+                const float d0 = g[0] - tb[0], d1 = g[1] - tb[1], d2 = g[2] - tb[2];
+                float gs[3];
+                for (int c = 0; c < 3; ++c) gs[c] = ((d0 * Rb[c] + d1 * Rb[3 + c] + d2 * Rb[6 + c]) / s) * s;  // canonicalize, then * s
+                if (role == 0) {
+                    float n2 = 0.f;
+                    for (int c = 0; c < 3; ++c) {
+                        sv[c * kHlJ + k] = gs[c];
+                        const float ps = pred_hf[((size_t)b * 3 + c) * kHlJ + k] * s, is = init_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
+                        part[0] += fabsf(ps - gs[c]);
+                        n2 += (is - gs[c]) * (is - gs[c]);
+                    }
+                    part[4] += sqrtf(n2);
+                } else {
+                    const float *pk = pred_kp + ((size_t)b * kHlJ + k) * 3;
+                    part[3] += sqrtf((pk[0] - g[0]) * (pk[0] - g[0]) + (pk[1] - g[1]) * (pk[1] - g[1]) + (pk[2] - g[2]) * (pk[2] - g[2]));
+                }
+                for (int j = 0; j < kHlPalm; ++j)
+                    if (kHlPalmIdx[j] == k)
+                        for (int c = 0; c < 3; ++c) yl[3 * j + c] = role == 0 ? gs[c] : pred_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
+            }
+            kabsch_solve(kHlPalm, palm + (size_t)(pb == 1 ? 0 : b) * kHlPalm * 3, yl, 3, R, t);
+            float *dst = sv + (role == 0 ? 75 : 63);
+            for (int a = 0; a < 3; ++a) {
+                for (int c = 0; c < 3; ++c) dst[3 * a + c] = (float)R[a][c];
+                dst[9 + a] = (float)t[a];
+            }
+            if (role == 1) {  // the predicted fit goes to the lane that holds the ground-truth fit
+                for (int a = 0; a < 9; ++a) xch[slot][a] = (float)R[a / 3][a % 3];
+                for (int a = 0; a < 3; ++a) xch[slot][9 + a] = (float)t[a];
+            }
+        }
+        __syncthreads();
+        if (on && role == 0) {  // R, t here = ground truth fit; xch = predicted fit
+            const float *Rp = xch[slot], *tp = xch[slot] + 9;
+            float tr_gt = (float)(R[0][0] + R[1][1] + R[2][2]), tr_rel = 0.f, tn = 0.f, dn = 0.f;
+            for (int a = 0; a < 3; ++a) {
+                for (int c = 0; c < 3; ++c) {
+                    part[1] += fabsf(Rp[3 * a + c] - (float)R[a][c]);
+                    tr_rel += Rp[3 * a + c] * (float)R[a][c];  // trace(R^T R_gt) = sum_ac R[a][c] R_gt[a][c]
+                }
+                part[2] += fabsf(tp[a] - (float)t[a]);
+                tn += (float)(t[a] * t[a]);
+                dn += (tp[a] - (float)t[a]) * (tp[a] - (float)t[a]);
+            }
+            const float k180 = 57.29577951308232f;
+            part[5] += acosf(fminf(fmaxf((tr_gt - 1.f) * 0.5f, -1.f), 1.f)) * k180;
+            part[6] += sqrtf(tn);
+            part[7] += acosf(fminf(fmaxf((tr_rel - 1.f) * 0.5f, -1.f), 1.f)) * k180;
+            part[8] += sqrtf(dn);
+        }
+        __syncthreads();
+    }
+    for (int i = 0; i < 9; ++i) atomicAdd(&acc[i], part[i]);
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const float denom[9] = {(float)B * 63.f, (float)B * 9.f, (float)B * 3.f, (float)B * 21.f, (float)B * 21.f, (float)B, (float)B, (float)B, (float)B};
+        out[threadIdx.x] = acc[threadIdx.x] / denom[threadIdx.x];
+    }
+}
+
+// d(sum_i w_i out[i], i < 3) / d pred_hf, w = (dL/d kp_loss, dL/d r_loss, dL/d t_loss) read from the device (grad (3,))
+__global__ void __launch_bounds__(64)
+hand_loss_bwd_kernel(int B, int pb, const float *__restrict__ pred_hf, float s, const float *__restrict__ palm,
+                     const float *__restrict__ saved, const float *__restrict__ grad, float *__restrict__ d_pred_hf) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float *sv = saved + 87 * (size_t)b;
+    const float wk = grad[0] / ((float)B * 63.f), wr = grad[1] / ((float)B * 9.f), wt = grad[2] / ((float)B * 3.f);
+    float *d = d_pred_hf + (size_t)b * 63;
+    auto sgn = [](float v) { return (float)((v > 0.f) - (v < 0.f)); };
+    for (int e = 0; e < 63; ++e) d[e] = wk * sgn(pred_hf[(size_t)b * 63 + e] * s - sv[e]) * s;
+    double gR[9], gt[3];
+    for (int a = 0; a < 9; ++a) gR[a] = (double)(wr * sgn(sv[63 + a] - sv[75 + a]));
+    for (int a = 0; a < 3; ++a) gt[a] = (double)(wt * sgn(sv[72 + a] - sv[84 + a]));
+    float yl[kHlPalm * 3], dyl[kHlPalm * 3];
+    for (int j = 0; j < kHlPalm; ++j)
+        for (int c = 0; c < 3; ++c) yl[3 * j + c] = pred_hf[((size_t)b * 3 + c) * kHlJ + kHlPalmIdx[j]] * s;
+    kabsch_backward_one(kHlPalm, palm + (size_t)(pb == 1 ? 0 : b) * kHlPalm * 3, yl, 3, sv + 63, gR, gt, dyl, 3, 1.f, false);
+    for (int j = 0; j < kHlPalm; ++j)
+        for (int c = 0; c < 3; ++c) d[c * kHlJ + kHlPalmIdx[j]] += dyl[3 * j + c] * s;
 }
 
 // pn2x_hand_frame: Kabsch on the palm keypoints + canonicalisation of the whole cloud, one workgroup per cloud.
@@ -248,6 +372,24 @@ extern "C" int pn2x_kabsch_backward(int b, int xb, int num, const float *x, cons
     if (b == 0) return PN2_OK;
     if (!x || !y || !R || !grad_y) return PN2_ENULL;
     hipLaunchKernelGGL(pn2::kabsch_bwd_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, b, xb, num, x, y, R, grad_R, grad_t, grad_y);
+    return pn2::check_launch();
+}
+
+extern "C" int pn2x_hand_losses(int b, int pb, const float *pred_hf, const float *init_hf, const float *gt_kp, const float *pred_kp,
+                                const float *R, const float *t, float scale, const float *palm, float *out, float *saved, void *stream) {
+    if (b < 1 || !(pb == 1 || pb == b) || !(scale > 0.f)) return PN2_EINVAL;
+    if (!pred_hf || !init_hf || !gt_kp || !pred_kp || !R || !t || !palm || !out || !saved) return PN2_ENULL;
+    hipLaunchKernelGGL(pn2::hand_loss_fwd_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, b, pb, pred_hf, init_hf, gt_kp, pred_kp, R, t,
+                       scale, palm, out, saved);
+    return pn2::check_launch();
+}
+
+extern "C" int pn2x_hand_losses_backward(int b, int pb, const float *pred_hf, float scale, const float *palm, const float *saved,
+                                         const float *grad3, float *d_pred_hf, void *stream) {
+    if (b < 1 || !(pb == 1 || pb == b) || !(scale > 0.f)) return PN2_EINVAL;
+    if (!pred_hf || !palm || !saved || !grad3 || !d_pred_hf) return PN2_ENULL;
+    hipLaunchKernelGGL(pn2::hand_loss_bwd_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, b, pb, pred_hf, scale, palm, saved,
+                       grad3, d_pred_hf);
     return pn2::check_launch();
 }
 

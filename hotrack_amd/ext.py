@@ -479,3 +479,49 @@ def fps_two_level(xyz: torch.Tensor, m1: int, m2: int, query=None):
         _native._check(_native._call(_lib.pn2x_furthest_point_sampling_prefix, "fps_prefix_kernel", None, B, m1, m2, l1.data_ptr(),
                                      flags.data_ptr(), nf, i2.data_ptr(), st), "fps_two_level/2")
     return (i1, l1, i2) if query is None else (i1, l1, i2, idx1)
+
+
+_lib.pn2x_hand_losses.argtypes = [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp]
+_lib.pn2x_hand_losses.restype = _ci
+_lib.pn2x_hand_losses_backward.argtypes = [_ci, _ci, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_hand_losses_backward.restype = _ci
+HAND_LOSS_NAMES = ("hand_pred_kp_loss", "hand_pred_r_loss", "hand_pred_t_loss", "hand_pred_kp_diff", "hand_init_kp_diff",
+                   "hand_init_r_diff", "hand_init_t_diff", "hand_pred_r_diff", "hand_pred_t_diff")
+
+
+class HandLosses(torch.autograd.Function):
+    """The nine entries of HandTrackNet.compute_loss's dictionary (include/pn2_ext.h: pn2x_hand_losses) as a (9,) tensor;
+    differentiable with respect to pred_hf through the first three (keypoint L1, rotation L1 and translation L1 of the palm
+    fit -- the closed-form Kabsch gradient), the rest are metrics."""
+
+    @staticmethod
+    def forward(ctx, pred_hf, init_hf, gt_kp, pred_kp, R, t, scale, palm):
+        f32 = torch.float32
+        B = pred_hf.shape[0]
+        pred_hf = pred_hf.contiguous()
+        palm = palm.contiguous().float()
+        if palm.dim() == 2:
+            palm = palm.unsqueeze(0)
+        args = [x.detach().contiguous().float() for x in (init_hf, gt_kp, pred_kp, R, t)]
+        out = torch.empty(9, dtype=f32, device=pred_hf.device)
+        saved = torch.empty((B, 87), dtype=f32, device=pred_hf.device)
+        with torch.cuda.device(pred_hf.device):
+            _native._check(_lib.pn2x_hand_losses(B, palm.shape[0], _native._ptr(pred_hf, "pred_hf", f32, B * 63), _native._ptr(args[0], "init_hf", f32, B * 63),
+                                                 _native._ptr(args[1], "gt_kp", f32, B * 63), _native._ptr(args[2], "pred_kp", f32, B * 63),
+                                                 _native._ptr(args[3], "R", f32, B * 9), _native._ptr(args[4], "t", f32, B * 3), float(scale),
+                                                 _native._ptr(palm, "palm", f32, palm.shape[0] * 18), out.data_ptr(), saved.data_ptr(),
+                                                 _native._stream(pred_hf)), "hand_losses")
+        ctx.save_for_backward(pred_hf, palm, saved)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        pred_hf, palm, saved = ctx.saved_tensors
+        B = pred_hf.shape[0]
+        g3 = grad[:3].contiguous().float()
+        d = torch.empty_like(pred_hf)
+        with torch.cuda.device(pred_hf.device):
+            _native._check(_lib.pn2x_hand_losses_backward(B, palm.shape[0], pred_hf.data_ptr(), ctx.scale, palm.data_ptr(), saved.data_ptr(),
+                                                          g3.data_ptr(), d.data_ptr(), _native._stream(pred_hf)), "hand_losses_backward")
+        return d, None, None, None, None, None, None, None

@@ -396,6 +396,29 @@ int pn2x_tg_wgrad(long rows, int n, int k, int gmode, const float *g, int ldg, c
                   const float *yp, int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p,
                   float *partial, long partial_floats, float *dw, float *dgamma, float *dbeta, float *dbias, void *stream);
 
+/*
+ * The loss / metric dictionary of HandTrackNet.compute_loss (reference hand_network.py:159-221, training mode without MANO
+ * terms) in one launch, and its gradient with respect to the predicted hand-frame keypoints in another (csrc/kabsch.hip).
+ * pred_hf / init_hf (b,3,21) channel-major hand-frame keypoints, gt_kp / pred_kp (b,21,3) camera frame, R (b,3,3) / t (b,3) /
+ * scale: the canonical pose, palm (pb,6,3) with pb in {1,b}: the palm template.  out[9] =
+ *   {hand_pred_kp_loss, hand_pred_r_loss, hand_pred_t_loss, hand_pred_kp_diff, hand_init_kp_diff, hand_init_r_diff,
+ *    hand_init_t_diff, hand_pred_r_diff, hand_pred_t_diff};  saved (b, 87) floats for the backward.
+ * backward: d_pred_hf (b,3,21) = d(grad3[0] out[0] + grad3[1] out[1] + grad3[2] out[2]) / d pred_hf, grad3 on the device.
+ */
+int pn2x_hand_losses(int b, int pb, const float *pred_hf, const float *init_hf, const float *gt_kp, const float *pred_kp,
+                     const float *R, const float *t, float scale, const float *palm, float *out, float *saved, void *stream);
+int pn2x_hand_losses_backward(int b, int pb, const float *pred_hf, float scale, const float *palm, const float *saved,
+                              const float *grad3, float *d_pred_hf, void *stream);
+
+/*
+ * One Adam step over n fp32 tensors (csrc/adam.hip): torch.optim.Adam semantics (L2 weight decay added to the gradient, bias
+ * corrections from the per-tensor `step` counters, no amsgrad -- reference trainer.py:49-52), the arithmetic of torch's fused
+ * kernel.  p / g / m / v / step: HOST arrays of n device pointers (m = exp_avg, v = exp_avg_sq, step = one fp32 counter per
+ * tensor, advanced by this call); numel: host array of n element counts.  The tensor table travels in the kernel arguments.
+ */
+int pn2x_adam_multi(int n, void *const *p, const void *const *g, void *const *m, void *const *v, void *const *step,
+                    const long *numel, double lr, double beta1, double beta2, double eps, double weight_decay, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,29 @@ def _rot_angle_deg(R: torch.Tensor) -> torch.Tensor:
     return torch.mean(torch.acos(torch.clamp((tr - 1) / 2, min=-1, max=1))) * 180 / math.pi
 
 
+_CONSTS = {}
+
+
+def _palm_idx(device):
+    key = ("palm", str(device))
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.tensor([0, 1, 5, 9, 13, 17], dtype=torch.int32, device=device)  # hand_utils.handkp2palmkp
+    return _CONSTS[key]
+
+
+def _scale_const(device):
+    key = ("scale", str(device))
+    if key not in _CONSTS:
+        _CONSTS[key] = 0.2 * torch.ones(1, device=device)
+    return _CONSTS[key]
+
+
+class LossDict(dict):
+    """The loss dictionary, plus (attribute, not an entry) the (9,) tensor all its values are views of when they come from the
+    fused loss kernel -- Trainer.summarize_losses then forms the weighted total with one dot product."""
+    fused_values = None
+
+
 class HandTrackNet(nn.Module):
     def __init__(self, cfg, elide_dead_attention: bool = True):
         super().__init__()
@@ -67,6 +90,7 @@ class HandTrackNet(nn.Module):
         self.use_fast_eval = True  # eval + fused backend + GPU -> models/fast_eval.py (set False to force this file's path)
         self._fast = None
         self.use_fast_train = True  # training on the GPU -> models/fast_train.py (point-major GEMM + fused BatchNorm/ReLU kernels)
+        self.use_fused_losses = True  # GPU: compute_loss's dictionary and its gradient as two launches (hotrack_amd.ext.HandLosses)
         self._ftrain = None
         self.bhand = PointNet2Msg_fast(cfg, C)
         self.r1 = rearrange_module(channel=C)
@@ -127,28 +151,39 @@ class HandTrackNet(nn.Module):
         hand_points = input["hand_points"].to(dev).float()
         ret = {}
 
-        if self.handframe == "OBB":
-            canon_pose = {k: v.to(dev).float() for k, v in input["OBB_pose"].items()}
+        kp_num = jittered_kp.shape[1]
+        elide = self.elide_dead_attention
+        cam = None
+        use_ft = getattr(self, "_force_fast_train", self.use_fast_train)  # class-level override: tests compare the two paths
+        if (self.training and use_ft and self.handframe == "kp" and elide and hand_points.is_cuda and kp_num == 21
+                and palm_template.shape[-2] == 6 and pointnet_utils.hip_backend_active()):
+            # training on the GPU: the hand frame (Kabsch of the palm template + canonicalisation of cloud and keypoints) as ONE
+            # launch, as in the inference path -- no gradient flows through it (inputs only); the torch composition below is
+            # ~12 launches (gather, device Kabsch, cat, transposes, subtract, matmul, divide, two copies)
+            from hotrack_amd import ext
+            R, t, xyz2_pm, xyz1_pm = ext.hand_frame(palm_template.contiguous(), jittered_kp.contiguous(), _palm_idx(hand_points.device),
+                                                    hand_points.contiguous(), 0.2)
+            canon_pose = {"scale": _scale_const(hand_points.device), "rotation": R, "translation": t}
+            xyz2, xyz1 = xyz2_pm.transpose(1, 2), xyz1_pm.transpose(1, 2)  # (B,3,N) / (B,3,kp) views of point-major buffers
         else:
-            canon_pose = self._hand_frame(palm_template, jittered_kp, hand_points)
+            if self.handframe == "OBB":
+                canon_pose = {k: v.to(dev).float() for k, v in input["OBB_pose"].items()}
+            else:
+                canon_pose = self._hand_frame(palm_template, jittered_kp, hand_points)
+            cam = canonicalize(torch.cat([hand_points, jittered_kp], dim=1).transpose(2, 1), canon_pose)  # (B,3,N+kp)
+            xyz2 = cam[..., :-kp_num].contiguous()  # hand points
+            xyz1 = cam[..., -kp_num:].contiguous()  # keypoints
         ret["canon_pose"] = canon_pose
 
-        kp_num = jittered_kp.shape[1]
-        cam = canonicalize(torch.cat([hand_points, jittered_kp], dim=1).transpose(2, 1), canon_pose)  # (B,3,N+kp)
-        xyz2 = cam[..., :-kp_num].contiguous()  # hand points
-        xyz1 = cam[..., -kp_num:].contiguous()  # keypoints
-
-        elide = self.elide_dead_attention
         pos1 = pos2 = None
         if not elide:
             pe = self.positionEmbedding(cam)
             pos2, pos1 = pe[..., :-kp_num], pe[..., -kp_num:]
 
-        fast = (pointnet_utils.fused_backend() is not None and cam.is_cuda and not self.training
+        fast = (pointnet_utils.fused_backend() is not None and xyz2.is_cuda and not self.training
                 and not torch.is_grad_enabled())
         ftrain = None
-        use_ft = getattr(self, "_force_fast_train", self.use_fast_train)  # class-level override: tests compare the two paths
-        if self.training and use_ft and cam.is_cuda and pointnet_utils.hip_backend_active():
+        if self.training and use_ft and xyz2.is_cuda and pointnet_utils.hip_backend_active():
             if self._ftrain is None:
                 from .fast_train import FastTrain
                 self._ftrain = FastTrain(self) if FastTrain.supported(self) else False
@@ -157,6 +192,7 @@ class HandTrackNet(nn.Module):
             f14, src2_pm = ftrain.forward(xyz2, xyz1)
             src2 = None if elide else src2_pm.transpose(1, 2)
         else:
+            xyz2, xyz1 = xyz2.contiguous(), xyz1.contiguous()
             src2 = self.bhand(xyz2)  # (B,C,N)
             f11, group_idx = self.q1(xyz2, src2, xyz1, None, return_group_idx=True)
             f12 = self.r1(f11, True)
@@ -184,9 +220,26 @@ class HandTrackNet(nn.Module):
     def compute_loss(self, input, ret_dict, flag_dict):
         """Loss / metric dictionary of the reference (hand_network.py:159-221), minus the MANO term."""
         dev = self.device
+        canon_pose = ret_dict["canon_pose"]
+        if (self.use_fused_losses and self.handframe != "OBB" and "global_pose" not in ret_dict and not flag_dict["track_flag"]
+                and ret_dict["pred_kp"].is_cuda and ret_dict["pred_kp"].shape[1] == 21 and pointnet_utils.hip_backend_active()):
+            # the whole dictionary in one launch, its gradient in another (hotrack_amd.ext.HandLosses, csrc/kabsch.hip): the torch
+            # composition below is ~75 launches of 4-5 us inside a captured training step
+            from hotrack_amd import ext
+            gt = input["gt_hand_kp"].to(dev).float()
+            palm = input["gt_hand_pose"]["palm_template"].to(dev).float()
+            s = float(0.2)  # _hand_frame / fast paths: the constant hand-frame scale (hand_network.py:95)
+            vals = ext.HandLosses.apply(ret_dict["pred_kp_handframe"], ret_dict["init_kp_handframe"], gt, ret_dict["pred_kp"], canon_pose["rotation"],
+                                        canon_pose["translation"].reshape(-1, 3), s, palm)
+            ret_dict["gt_kp_handframe"] = canonicalize(gt.transpose(-1, -2), canon_pose) if flag_dict.get("save_flag") else None
+            loss = {k: vals[i] for i, k in enumerate(ext.HAND_LOSS_NAMES)}
+            order = ["hand_pred_kp_loss", "hand_pred_kp_diff", "hand_init_kp_diff", "hand_pred_r_loss", "hand_pred_t_loss", "hand_init_r_diff",
+                     "hand_init_t_diff", "hand_pred_r_diff", "hand_pred_t_diff"]
+            loss = LossDict((k, loss[k]) for k in order)
+            loss.fused_values = vals  # (9,) in ext.HAND_LOSS_NAMES order: lets the trainer form the weighted total with one dot product
+            return loss, ret_dict
         gt_kp = input["gt_hand_kp"].to(dev).float().transpose(-1, -2)  # (B,3,kp)
         pred_kp = ret_dict["pred_kp"].transpose(-1, -2)
-        canon_pose = ret_dict["canon_pose"]
         s = canon_pose["scale"][:, None, None]
         ret_dict["gt_kp_handframe"] = canonicalize(gt_kp, canon_pose)
         init_s = ret_dict["init_kp_handframe"] * s

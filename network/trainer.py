@@ -99,9 +99,15 @@ class Trainer(nn.Module):
                 # GPU: the fused multi-tensor Adam (one or two launches over all parameters instead of ~15 foreach kernels;
                 # device-side step counters, so it is graph-capturable as is).  Same update rule: L2 weight decay, no amsgrad.
                 on_gpu = isinstance(self.device, torch.device) and self.device.type == "cuda"
-                kw = dict(fused=True, capturable=self.graph_step) if on_gpu and cfg.get("fused_adam", True) else dict(capturable=self.graph_step)
-                self.optimizer = torch.optim.Adam(params, lr=cfg["learning_rate"], betas=(0.9, 0.999), eps=1e-8,
-                                                  weight_decay=cfg["weight_decay"], **kw)
+                if on_gpu and cfg.get("fused_adam", True) and cfg.get("adam_impl", "hip") == "hip":
+                    # hotrack_amd.optim.FusedAdam: the whole update as one stream over all parameters (csrc/adam.hip), torch's
+                    # state_dict layout, capture-safe; adam_impl: torch selects torch's own fused multi-tensor kernel
+                    from hotrack_amd.optim import FusedAdam
+                    self.optimizer = FusedAdam(params, lr=cfg["learning_rate"], betas=(0.9, 0.999), eps=1e-8, weight_decay=cfg["weight_decay"])
+                else:
+                    kw = dict(fused=True, capturable=self.graph_step) if on_gpu and cfg.get("fused_adam", True) else dict(capturable=self.graph_step)
+                    self.optimizer = torch.optim.Adam(params, lr=cfg["learning_rate"], betas=(0.9, 0.999), eps=1e-8,
+                                                      weight_decay=cfg["weight_decay"], **kw)
             else:
                 self.optimizer = torch.optim.SGD(params, lr=cfg["learning_rate"], momentum=0.9)
             self.scheduler = self._make_scheduler()
@@ -144,6 +150,15 @@ class Trainer(nn.Module):
                 self.logger.info(s)
 
     def summarize_losses(self, loss_dict):
+        vals = getattr(loss_dict, "fused_values", None)
+        if vals is not None:  # all terms live in one (9,) tensor (hotrack_amd.ext.HandLosses): the weighted total is ONE dot product
+            from hotrack_amd.ext import HAND_LOSS_NAMES
+            key = (vals.device, tuple(sorted(self.loss_weights.items())))
+            if getattr(self, "_wvec_key", None) != key:
+                self._wvec = torch.tensor([float(self.loss_weights.get(k, 0.0)) for k in HAND_LOSS_NAMES], dtype=vals.dtype, device=vals.device)
+                self._wvec_key = key
+            loss_dict["total_loss"] = torch.dot(vals, self._wvec)
+            return loss_dict
         total = 0
         for key, w in self.loss_weights.items():
             if key in loss_dict:

@@ -73,12 +73,25 @@ def main():
         a1f = torch.matmul(feat.transpose(1, 2), w1f_t)
         return ext.sa_mlp_max(idx, W2, b2, W3, b3, a1f=a1f, xyz=xyz, cxyz=new_xyz, wx=wx, b1=b1)
     t = timeit(fused)
-    flops = 2.0 * B * S * K * ((C + 3) * 64 + 64 * 64 + 64 * 128)
+    # flops ACTUALLY executed: layer 1 is split -- its per-point half is a GEMM over the N points (not over the S*K grouped slots),
+    # the xyz half 3 MACs per slot and channel in-kernel -- then layers 2-3 over all slots
+    flops = 2.0 * B * (N * C * 64 + S * K * (3 * 64 + 64 * 64 + 64 * 128))
     comp = B * (4 * C * N + 12 * N + 12 * S + 4 * S * K + 4 * 128 * S)  # compulsory traffic of a fused SA layer
-    rec("fused SA layer [67->64->64->128] + max (a1f GEMM + sa_mlp_max)", t, comp, flops)
+    rec("fused SA layer [67->64->64->128] + max (a1f GEMM + sa_mlp_max), executed flops", t, comp, flops,
+        equivalent_TFLOPs_of_the_grouped_formulation=round(2.0 * B * S * K * ((C + 3) * 64 + 64 * 64 + 64 * 128) / t / 1e12, 2))
     a1f = torch.matmul(feat.transpose(1, 2), w1f_t)
     t = timeit(lambda: ext.sa_mlp_max(idx, W2, b2, W3, b3, a1f=a1f, xyz=xyz, cxyz=new_xyz, wx=wx, b1=b1))
     rec("sa_mlp_max kernel alone", t, None, 2.0 * B * S * K * (64 * 64 + 64 * 128))
+    # whole set-abstraction level of the stress shape: sample -> gather -> query -> fused MLP + max (what one SA layer costs)
+    def whole():
+        i = ops.furthest_point_sample(xyz, S)
+        c = ext.gather_rows(xyz, i)
+        j = ops.ball_query(0.2, K, xyz, c)
+        a1 = torch.matmul(feat.transpose(1, 2), w1f_t)
+        return ext.sa_mlp_max(j, W2, b2, W3, b3, a1f=a1, xyz=xyz, cxyz=c, wx=wx, b1=b1)
+    t = timeit(whole, iters=3, warm=1)
+    rec("whole SA level (fps + gather + ball_query + a1f GEMM + sa_mlp_max), %d clouds" % B, t, None, None, clouds_per_s=round(B / t, 1))
+    assert all(r.get("mfma_frac", 0) <= 1 and r.get("hbm_frac", 0) <= 1 for r in res), "a roofline fraction above 1 is a labelling bug"
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
 

@@ -1,0 +1,28 @@
+#!/bin/bash
+# usage (GPU box, repo root): scripts/evidence_round.sh rNN  -> gpurun_out/rNN_*: the round's measurements in one call
+#   pytest -m gpu summary, profile_round.sh (bench line + rocprofv3 kernel stats + PMC traffic / MfmaUtil), per-operator,
+#   stress, latency, SDF and training benches, the training step kernel by kernel, the multi-rank self-test.
+set -u
+tag=$1
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/${tag}_pytest_gpu.log
+bash scripts/profile_round.sh $tag > $O/${tag}_profile_round.log 2>&1
+python scripts/bench_ops.py --out $O/${tag}_bench_ops.json > /dev/null 2>&1 || python scripts/bench_ops.py > $O/${tag}_bench_ops.json 2>/dev/null
+python scripts/bench_stress.py --out $O/${tag}_stress.json > $O/${tag}_stress.log 2>&1
+python scripts/bench_latency.py > $O/${tag}_bench_latency.json 2>/dev/null
+python scripts/bench_train.py --graph > $O/${tag}_bench_train_graph.json 2>/dev/null
+HOTRACK_FUSED_STACKS=0 python scripts/bench_train.py --graph > $O/${tag}_bench_train_graph_unfused_stacks.json 2>/dev/null
+python scripts/bench_train.py > $O/${tag}_bench_train_eager.json 2>/dev/null
+python scripts/probes/tg_bench.py --iters 10 > $O/${tag}_tg_bench.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/ts && rocprofv3 --kernel-trace --output-format csv -d /tmp/ts -o t -- python $R/scripts/bench_train.py --graph --steps 12 --warmup 4 > /dev/null 2>&1
+python $R/scripts/trace_one_step.py $(find /tmp/ts -name "*kernel_trace.csv" | head -1) > $O/${tag}_train_one_step.csv
+python $R/scripts/trace_window.py $(find /tmp/ts -name "*kernel_trace.csv" | head -1) --frac 0.3 --steps-in-window 0 > $O/${tag}_train_graph_window.csv
+rm -rf /tmp/tst && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tst -o t -- python $R/scripts/bench_stress.py > /dev/null 2>&1
+cp $(find /tmp/tst -name "*kernel_stats.csv" | head -1) $O/${tag}_stress_kernel_stats.csv
+cd $R
+bash scripts/scale_selftest.sh 2 > $O/${tag}_scale_selftest.log 2>&1
+tail -3 $O/${tag}_pytest_gpu.log; cat $O/${tag}_bench_train_graph.json; tail -2 $O/${tag}_scale_selftest.log
