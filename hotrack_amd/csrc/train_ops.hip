@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(kTT)
 bn_relu_bwd_reduce_kernel(long rows, int C, const float *__restrict__ dH, int ldd, const float *__restrict__ Y, int ldy,
                           const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
                           const float *__restrict__ beta, int rows_per_block, int relu, double *__restrict__ sums,
-                          const int *__restrict__ arg, int K) {
+                          const int *__restrict__ arg, int K, float *__restrict__ g_out = nullptr, int ldg = 0) {
     const int Q = C >> 2, rpp = kTT / Q;
     const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
     const long r0 = (long)blockIdx.x * rows_per_block;
@@ -226,13 +226,14 @@ bn_relu_bwd_reduce_kernel(long rows, int C, const float *__restrict__ dH, int ld
     if (rr < rpp) {
         BnCh k;
         load_saved(k, 4 * q, mean, invstd, gamma, beta);
-        auto acc = [&](const float4 y, float4 g) {
+        auto acc = [&](const float4 y, float4 g, long row = -1) {
             if (relu) {
                 if (!(bn_act(y.x, k, 0) > 0.f)) g.x = 0.f;
                 if (!(bn_act(y.y, k, 1) > 0.f)) g.y = 0.f;
                 if (!(bn_act(y.z, k, 2) > 0.f)) g.z = 0.f;
                 if (!(bn_act(y.w, k, 3) > 0.f)) g.w = 0.f;
             }
+            if (g_out && row >= 0) *reinterpret_cast<float4 *>(g_out + row * ldg + 4 * q) = g;  // the masked / routed gradient, dense
             s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
             t.x += g.x * ((y.x - k.mean[0]) * k.invstd[0]);
             t.y += g.y * ((y.y - k.mean[1]) * k.invstd[1]);
@@ -242,7 +243,7 @@ bn_relu_bwd_reduce_kernel(long rows, int C, const float *__restrict__ dH, int ld
         long r = r0 + rr;
         if (arg) {  // dH is d(max over K) (rows / K groups): only the arg-max row of a group receives it
             for (; r < r1; r += rpp)
-                acc(*reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q), max_grad(dH, ldd, arg, C, K, r, q));
+                acc(*reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q), max_grad(dH, ldd, arg, C, K, r, q), r);
         }
         for (; r + 3L * rpp < r1; r += 4L * rpp) {  // eight independent 16-byte loads in flight per thread
             const float *py = Y + r * ldy + 4 * q, *pg = dH + r * ldd + 4 * q;
@@ -567,13 +568,20 @@ extern "C" int pn2x_bn_relu_bwd(long rows, int c, const float *dh, int ldd, cons
 extern "C" int pn2x_bn_bwd_reduce(long rows, int c, const float *dh, int ldd, const int *arg, int k, const float *y, int ldy,
                                   const float *mean, const float *invstd, const float *gamma, const float *beta, int relu, double *sums,
                                   void *stream) {
+    return pn2x_bn_bwd_reduce_g(rows, c, dh, ldd, arg, k, y, ldy, mean, invstd, gamma, beta, relu, sums, nullptr, 0, stream);
+}
+
+extern "C" int pn2x_bn_bwd_reduce_g(long rows, int c, const float *dh, int ldd, const int *arg, int k, const float *y, int ldy,
+                                    const float *mean, const float *invstd, const float *gamma, const float *beta, int relu, double *sums,
+                                    float *g_out, int ldg, void *stream) {
     using namespace pn2;
     if (rows < 1 || bad_c(c) || ldy < c || ldy % 4 || ldd < c || ldd % 4 || (arg && (k < 1 || rows % k))) return PN2_EINVAL;
     if (!dh || !y || !mean || !invstd || !gamma || !beta || !sums) return PN2_ENULL;
-    if (((uintptr_t)y | (uintptr_t)dh | (uintptr_t)arg) % 16) return PN2_EINVAL;
+    if (((uintptr_t)y | (uintptr_t)dh | (uintptr_t)arg | (uintptr_t)g_out) % 16) return PN2_EINVAL;
+    if (g_out && (ldg < c || ldg % 4)) return PN2_EINVAL;
     const int rpb = rows_per_block_for(rows, c);
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kTT), 0, (hipStream_t)stream, rows, c, dh,
-                       ldd, y, ldy, mean, invstd, gamma, beta, rpb, arg ? 1 : relu, sums, arg, arg ? k : 1);
+                       ldd, y, ldy, mean, invstd, gamma, beta, rpb, arg ? 1 : relu, sums, arg, arg ? k : 1, arg ? g_out : nullptr, ldg);
     return check_launch();
 }
 

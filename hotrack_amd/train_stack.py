@@ -40,6 +40,10 @@ _lib.pn2x_tg_wgrad.argtypes = [_cl, _ci, _ci] + _DY + [_vp, _ci, _vp, _vp, _vp, 
 _lib.pn2x_tg_wgrad.restype = _ci
 _lib.pn2x_bn_bwd_reduce.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
 _lib.pn2x_bn_bwd_reduce.restype = _ci
+_lib.pn2x_bn_bwd_reduce_g.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp]
+_lib.pn2x_bn_bwd_reduce_g.restype = _ci
+import os as _os
+ROUTE_DENSE = _os.environ.get("HOTRACK_STACK_ROUTE_DENSE", "1") != "0"  # max-routed top gradient materialised once by the reduction
 _lib.pn2x_bn_bwd_apply.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_bn_bwd_apply.restype = _ci
 _f32 = torch.float32
@@ -142,10 +146,17 @@ class _Stack(torch.autograd.Function):
         with torch.cuda.device(dev):
             yl, svl = ys[L - 1], saved[L - 1]
             Cl = yl.shape[1]
-            _native._check(_lib.pn2x_bn_bwd_reduce(R, Cl, dout.data_ptr(), Cl, _p(arg), K if K else 1, yl.data_ptr(), yl.stride(0),
-                                                   svl[0].data_ptr(), svl[1].data_ptr(), gam(L - 1).data_ptr(), bet(L - 1).data_ptr(), 1,
-                                                   sums[L - 1].data_ptr(), st), "bn_bwd_reduce")
             g, gmode = dout, (2 if K else 1)
+            g_dense = None
+            if K and ROUTE_DENSE:
+                # the reduction reads dout / arg / y_L anyway: it also writes the routed, masked gradient once (dense), and the two
+                # GEMMs of the top layer read that instead of routing through arg-max on every load (their slowest variant)
+                g_dense = torch.empty((R, Cl), dtype=_f32, device=dev)
+            _native._check(_lib.pn2x_bn_bwd_reduce_g(R, Cl, dout.data_ptr(), Cl, _p(arg), K if K else 1, yl.data_ptr(), yl.stride(0),
+                                                     svl[0].data_ptr(), svl[1].data_ptr(), gam(L - 1).data_ptr(), bet(L - 1).data_ptr(), 1,
+                                                     sums[L - 1].data_ptr(), _p(g_dense), Cl, st), "bn_bwd_reduce")
+            if g_dense is not None:
+                g, gmode = g_dense, 0
             for i in range(L - 1, 0, -1):
                 w = tensors[4 * i]
                 N, Kc = w.shape

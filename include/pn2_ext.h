@@ -357,6 +357,11 @@ int pn2x_bn_relu_max_bwd(long groups, int k, int c, const float *dout, const int
  */
 int pn2x_bn_bwd_reduce(long rows, int c, const float *dh, int ldd, const int *arg, int k, const float *y, int ldy, const float *mean,
                        const float *invstd, const float *gamma, const float *beta, int relu, double *sums, void *stream);
+/* ... and, for the max-routed form (arg != NULL), the routed + masked gradient itself written densely to g_out (rows x c, row
+ * stride ldg) or NULL: the fused GEMMs of the layer below then read a plain gradient instead of routing it on every load. */
+int pn2x_bn_bwd_reduce_g(long rows, int c, const float *dh, int ldd, const int *arg, int k, const float *y, int ldy, const float *mean,
+                         const float *invstd, const float *gamma, const float *beta, int relu, double *sums, float *g_out, int ldg,
+                         void *stream);
 int pn2x_bn_bwd_apply(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean, const float *invstd,
                       const float *gamma, const float *beta, int relu, const double *sums, float *dy, int ldo, float *dgamma,
                       float *dbeta, float *dbias, void *stream);
