@@ -1,0 +1,129 @@
+"""The 21-token tail of HandTrackNet in training mode as autograd Functions over csrc/tail_train.hip
+(include/pn2_ext.h: pn2x_tail_ln_fwd / _bwd, pn2x_tail_relu_drop_fwd / _bwd).
+
+    TailGrads(device, sizes)             one zero-filled buffer per forward for every dgamma / dbeta / dbias of the tail
+    ln(x, norm_a, norm_b, ...)           LN_b(LN_a(x + dropout(y + bias)))        (y / bias / norm_b optional)
+    relu_dropout(z, bias, p, ...)        dropout(relu(z + bias))
+
+torch semantics (LayerNorm: biased variance, eps inside the sqrt; dropout: kept elements scaled by 1 / (1 - p)); the dropout
+masks are a hash of (per-forward seed, site, element index), regenerated in the backward.  GPU tensors only."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import pointnet2_hip as _native
+
+_lib = _native._lib
+_vp, _ci, _cl, _cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_lib.pn2x_tail_ln_fwd.argtypes = [_cl, _ci, _vp, _vp, _vp, _cf, _ci, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _cf, _vp, _vp, _vp]
+_lib.pn2x_tail_ln_fwd.restype = _ci
+_lib.pn2x_tail_ln_bwd.argtypes = [_cl, _ci, _vp, _vp, _vp, _cf, _ci, _vp, _vp, _vp, _cf, _vp, _vp, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_tail_ln_bwd.restype = _ci
+_lib.pn2x_tail_relu_drop_fwd.argtypes = [_cl, _ci, _vp, _vp, _cf, _ci, _vp, _vp, _vp]
+_lib.pn2x_tail_relu_drop_fwd.restype = _ci
+_lib.pn2x_tail_relu_drop_bwd.argtypes = [_cl, _ci, _vp, _vp, _cf, _ci, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_tail_relu_drop_bwd.restype = _ci
+_f32 = torch.float32
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class TailGrads:
+    """Zero-filled accumulators for the parameter gradients the backward kernels add into (one fill launch per forward)."""
+
+    def __init__(self, device, n_floats: int):
+        self.buf = torch.zeros(n_floats, dtype=_f32, device=device)
+        self.used = 0
+
+    def take(self, n: int) -> torch.Tensor:
+        out = self.buf[self.used:self.used + n]
+        self.used += n
+        assert self.used <= self.buf.numel()
+        return out
+
+
+def _fresh(ctx, acc=None):
+    """The forward's zeroed accumulators on the first backward through a node, fresh zeros on any later one (the kernels ADD)."""
+    acc = ctx.acc if acc is None else acc
+    if getattr(ctx, "_acc_used", False):
+        return tuple(None if a is None else torch.zeros_like(a) for a in acc)
+    ctx._acc_used = True
+    return acc
+
+
+class _Ln(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, bias, ga, ba, gb, bb, eps_a, eps_b, p, site, seed_in, seed_dev, seed_out, grads):
+        rows, c = x.shape
+        x = x.contiguous()
+        y = None if y is None else y.contiguous()
+        out = torch.empty_like(x)
+        stats = torch.empty((rows, 4), dtype=_f32, device=x.device)
+        with torch.cuda.device(x.device):
+            _native._check(_lib.pn2x_tail_ln_fwd(rows, c, x.data_ptr(), _p(y), _p(bias), float(p), int(site), _p(seed_in), _p(seed_dev),
+                                                 _p(seed_out), ga.data_ptr(), ba.data_ptr(), float(eps_a), _p(gb), _p(bb), float(eps_b),
+                                                 out.data_ptr(), stats.data_ptr(), _native._stream(x)), "tail_ln_fwd")
+        ctx.save_for_backward(x, y, bias, ga, ba, gb, bb, stats, seed_in)
+        ctx.meta = (float(eps_a), float(eps_b), float(p), int(site))
+        # accumulators of this call's parameter gradients (zeroed with the whole buffer at the start of the forward)
+        ctx.acc = (grads.take(c), grads.take(c), grads.take(c) if gb is not None else None, grads.take(c) if gb is not None else None,
+                   grads.take(c) if (y is not None and bias is not None) else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, bias, ga, ba, gb, bb, stats, seed_in = ctx.saved_tensors
+        eps_a, eps_b, p, site = ctx.meta
+        rows, c = x.shape
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        dy = torch.empty_like(x) if y is not None else None
+        dga, dba, dgb, dbb, dbias = _fresh(ctx)
+        with torch.cuda.device(x.device):
+            _native._check(_lib.pn2x_tail_ln_bwd(rows, c, x.data_ptr(), _p(y), _p(bias), p, site, _p(seed_in), ga.data_ptr(), ba.data_ptr(), eps_a,
+                                                 _p(gb), _p(bb), eps_b, stats.data_ptr(), dout.data_ptr(), dx.data_ptr(), _p(dy), dga.data_ptr(),
+                                                 dba.data_ptr(), _p(dgb), _p(dbb), _p(dbias), _native._stream(x)), "tail_ln_bwd")
+        return dx, dy, dbias, dga, dba, dgb, dbb, None, None, None, None, None, None, None, None
+
+
+def ln(x, norm_a, norm_b, grads, y=None, bias=None, p=0.0, site=0, seed_in=None, seed_dev=None, seed_out=None):
+    """LN_b(LN_a(x + dropout(y + bias))) on rows (R, C); norm_a / norm_b: torch.nn.LayerNorm modules (norm_b may be None)."""
+    gb, bb, eps_b = (None, None, 0.0) if norm_b is None else (norm_b.weight, norm_b.bias, norm_b.eps)
+    return _Ln.apply(x, y, bias, norm_a.weight, norm_a.bias, gb, bb, norm_a.eps, eps_b, p, site, seed_in, seed_dev, seed_out, grads)
+
+
+class _ReluDrop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, bias, p, site, seed_in, grads):
+        rows, c = z.shape
+        z = z.contiguous()
+        out = torch.empty_like(z)
+        with torch.cuda.device(z.device):
+            _native._check(_lib.pn2x_tail_relu_drop_fwd(rows, c, z.data_ptr(), _p(bias), float(p), int(site), _p(seed_in), out.data_ptr(),
+                                                        _native._stream(z)), "tail_relu_drop_fwd")
+        ctx.save_for_backward(z, bias, seed_in)
+        ctx.meta = (float(p), int(site))
+        ctx.acc = grads.take(c) if bias is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        z, bias, seed_in = ctx.saved_tensors
+        p, site = ctx.meta
+        rows, c = z.shape
+        dh = dh.contiguous()
+        dz = torch.empty_like(z)
+        (acc,) = _fresh(ctx, (ctx.acc,))
+        with torch.cuda.device(z.device):
+            _native._check(_lib.pn2x_tail_relu_drop_bwd(rows, c, z.data_ptr(), _p(bias), p, site, _p(seed_in), dh.data_ptr(), dz.data_ptr(),
+                                                        _p(acc), _native._stream(z)), "tail_relu_drop_bwd")
+        return dz, acc, None, None, None, None
+
+
+def relu_dropout(z, bias, p, site, seed_in, grads):
+    """dropout(relu(z + bias)) on rows (R, C), C % 4 == 0."""
+    return _ReluDrop.apply(z, bias, p, site, seed_in, grads)

@@ -416,6 +416,30 @@ int pn2x_hand_losses_backward(int b, int pb, const float *pred_hf, float scale, 
                               const float *grad3, float *d_pred_hf, void *stream);
 
 /*
+ * The 21-token tail in TRAINING mode (csrc/tail_train.hip; reference transformer.py:65-67, hand_network.py:139-147 with
+ * attn=False): every element-wise run between two GEMMs as one launch per direction.  Rows are tokens (rows x c, contiguous).
+ *   pn2x_tail_ln_fwd   u = x + dropout(y + bias) (y, bias optional), out = LN_b(LN_a(u)) (LN_b optional: gb = bb = NULL);
+ *                      stats (rows, 4) = mean_a, rstd_a, mean_b, rstd_b for the backward.  seed_dev != NULL: this launch
+ *                      advances the device seed counter and writes the new value to seed_out (it must have no dropout itself);
+ *                      otherwise seed_in is the per-forward seed the dropout mask is hashed from (site: which dropout).
+ *   pn2x_tail_ln_bwd   dx (= du), dy (if y), and -- ATOMICALLY ADDED onto zero-initialised c-float buffers -- dga, dba, dgb,
+ *                      dbb, dbias.  c <= 512.
+ *   pn2x_tail_relu_drop_fwd / _bwd   h = dropout(relu(z + bias)); dz, dbias (atomically added).  c % 4 == 0.
+ * Dropout: kept elements scaled by 1 / (1 - p); the mask is regenerated in the backward from (seed, site, index).
+ */
+int pn2x_tail_ln_fwd(long rows, int c, const float *x, const float *y, const float *bias, float p, int site, const long long *seed_in,
+                     long long *seed_dev, long long *seed_out, const float *ga, const float *ba, float eps_a, const float *gb,
+                     const float *bb, float eps_b, float *out, float *stats, void *stream);
+int pn2x_tail_ln_bwd(long rows, int c, const float *x, const float *y, const float *bias, float p, int site, const long long *seed_in,
+                     const float *ga, const float *ba, float eps_a, const float *gb, const float *bb, float eps_b, const float *stats,
+                     const float *dout, float *dx, float *dy, float *dga, float *dba, float *dgb, float *dbb, float *dbias,
+                     void *stream);
+int pn2x_tail_relu_drop_fwd(long rows, int c, const float *z, const float *bias, float p, int site, const long long *seed_in,
+                            float *out, void *stream);
+int pn2x_tail_relu_drop_bwd(long rows, int c, const float *z, const float *bias, float p, int site, const long long *seed_in,
+                            const float *dh, float *dz, float *dbias, void *stream);
+
+/*
  * One Adam step over n fp32 tensors (csrc/adam.hip): torch.optim.Adam semantics (L2 weight decay added to the gradient, bias
  * corrections from the per-tensor `step` counters, no amsgrad -- reference trainer.py:49-52), the arithmetic of torch's fused
  * kernel.  p / g / m / v / step: HOST arrays of n device pointers (m = exp_avg, v = exp_avg_sq, step = one fp32 counter per

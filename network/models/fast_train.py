@@ -179,6 +179,7 @@ class FastTrain:
         f12 = self._rearrange(net.r1, f11)                                                                 # (B*J, C)
         f13 = self._sa_scales(net.q2, xyz, kp, src2, idxs, center2d=f12)
         f14 = self._rearrange(net.r2, f13).view(B, J, C)
+        self.last_token_rows = f14.view(B * J, C)  # token-major rows for FastTail (the transposed view below is what `r2` returns)
         return f14.transpose(1, 2), src2.view(B, N, C)
 
     @staticmethod
@@ -191,3 +192,50 @@ class FastTrain:
             mod._perm_flat = flat
         g = tok.index_select(1, flat)  # (B, J*re, C)
         return F.linear(g.view(B * J, mod.re * C), mod.linear.weight.squeeze(-1), mod.linear.bias)
+
+
+class FastTail:
+    """The 21-token tail in training mode on the GPU (TransT.s11 -> c11 -> c3 with attn=False, final_mlp, residual on the initial
+    keypoints, de-canonicalisation; reference transformer.py:65-67,72-82, hand_network.py:139-147): token-major rows, library
+    GEMMs without bias, and every element-wise run between two GEMMs as one launch per direction (hotrack_amd.tail_train:
+    LayerNorm pairs, bias + ReLU + dropout, dropout + residual + LayerNorm(s)).  Same parameters, same mathematics; only the
+    dropout random stream differs from torch's (statistically equivalent; identical when p = 0)."""
+
+    def __init__(self, net):
+        self.net = net
+        self.seed = None
+
+    @staticmethod
+    def supported(net) -> bool:
+        t, c3 = net.transt, net.c3
+        mods = (t.s11, t.c11, c3)
+        if any(m.concat for m in mods) or not t.s11.no_linear or t.c11.no_linear or c3.no_linear:
+            return False
+        C = t.c11.norm1.normalized_shape[0]
+        H = t.c11.linear1.out_features
+        ok_act = all(m.activation is F.relu for m in (t.c11, c3))
+        return ok_act and C % 4 == 0 and C <= 512 and H % 4 == 0 and net.final_mlp[0].weight.shape[0] % 4 == 0
+
+    def forward(self, rows, xyz1, canon_pose):
+        """rows (B*J, C) token-major output of r2; xyz1 (B,3,J) hand-frame keypoints -> (pred_kp_handframe (B,3,J), pred_kp (B,J,3))."""
+        from hotrack_amd import tail_train as T
+        from .hand_utils import decanonicalize
+        net = self.net
+        s11, c11, c3 = net.transt.s11, net.transt.c11, net.c3
+        dev = rows.device
+        B, _, J = xyz1.shape
+        C, H, Hf = rows.shape[1], c11.linear1.out_features, net.final_mlp[0].weight.shape[0]
+        if self.seed is None or self.seed.device != dev:
+            self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        seed_used = torch.empty(1, dtype=torch.int64, device=dev)
+        grads = T.TailGrads(dev, 14 * C + 2 * H + Hf)
+        pd = lambda m: float(m.p) if m.training else 0.0
+        h = T.ln(rows, s11.norm1, c11.norm1, grads, seed_dev=self.seed, seed_out=seed_used)
+        d = T.relu_dropout(F.linear(h, c11.linear1.weight), c11.linear1.bias, pd(c11.dropout2), 1, seed_used, grads)
+        h2 = T.ln(h, c11.norm2, c3.norm1, grads, y=F.linear(d, c11.linear2.weight), bias=c11.linear2.bias, p=pd(c11.dropout3), site=2, seed_in=seed_used)
+        d2 = T.relu_dropout(F.linear(h2, c3.linear1.weight), c3.linear1.bias, pd(c3.dropout2), 3, seed_used, grads)
+        h3 = T.ln(h2, c3.norm2, None, grads, y=F.linear(d2, c3.linear2.weight), bias=c3.linear2.bias, p=pd(c3.dropout3), site=4, seed_in=seed_used)
+        hf = T.relu_dropout(F.linear(h3, net.final_mlp[0].weight.squeeze(-1)), net.final_mlp[0].bias, 0.0, 0, None, grads)
+        delta = F.linear(hf, net.final_mlp[2].weight.squeeze(-1), net.final_mlp[2].bias)     # (B*J, 3)
+        pred_hf = delta.view(B, J, 3).transpose(1, 2) + xyz1
+        return pred_hf, decanonicalize(pred_hf, canon_pose).transpose(2, 1)

@@ -91,6 +91,8 @@ class HandTrackNet(nn.Module):
         self._fast = None
         self.use_fast_train = True  # training on the GPU -> models/fast_train.py (point-major GEMM + fused BatchNorm/ReLU kernels)
         self.use_fused_losses = True  # GPU: compute_loss's dictionary and its gradient as two launches (hotrack_amd.ext.HandLosses)
+        self.use_fast_tail = True  # training on the GPU: the 21-token tail with fused element-wise runs (fast_train.FastTail)
+        self._ftail = None
         self._ftrain = None
         self.bhand = PointNet2Msg_fast(cfg, C)
         self.r1 = rearrange_module(channel=C)
@@ -198,15 +200,23 @@ class HandTrackNet(nn.Module):
             f12 = self.r1(f11, True)
             f13 = self.q2(xyz2, src2, xyz1, f12, pre_group_idx=group_idx)
             f14 = self.r2(f13, True)
-        f15, f251 = self.transt(src1=f14, pos1=pos1, src2=src2, pos2=pos2, attn=False, elide_dead=elide,
-                                need_result2=not elide)
-        fused = self.c3(f15, pos1, f251, pos2, attn=False, elide_dead=elide)
-
-        delta = _conv1x1(self.final_mlp[2], F.relu(_conv1x1(self.final_mlp[0], fused)))
-        ret["pred_kp_handframe"] = delta + xyz1  # (B,3,kp)
+        ftail = None
+        if ftrain is not None and elide and self.use_fast_tail:
+            if self._ftail is None:
+                from .fast_train import FastTail
+                self._ftail = FastTail(self) if FastTail.supported(self) else False
+            ftail = self._ftail or None
+        if ftail is not None:  # the 21-token tail, token-major, fused element-wise runs (fast_train.FastTail)
+            ret["pred_kp_handframe"], ret["pred_kp"] = ftail.forward(ftrain.last_token_rows, xyz1, canon_pose)
+        else:
+            f15, f251 = self.transt(src1=f14, pos1=pos1, src2=src2, pos2=pos2, attn=False, elide_dead=elide,
+                                    need_result2=not elide)
+            fused = self.c3(f15, pos1, f251, pos2, attn=False, elide_dead=elide)
+            delta = _conv1x1(self.final_mlp[2], F.relu(_conv1x1(self.final_mlp[0], fused)))
+            ret["pred_kp_handframe"] = delta + xyz1  # (B,3,kp)
+            ret["pred_kp"] = decanonicalize(ret["pred_kp_handframe"], canon_pose).transpose(2, 1)
         ret["init_kp_handframe"] = xyz1
         ret["points_handframe"] = xyz2
-        ret["pred_kp"] = decanonicalize(ret["pred_kp_handframe"], canon_pose).transpose(2, 1)
 
         if flag_dict.get("IKNet_flag", False):
             d4, _ = knn_point(4, ret["pred_kp"].contiguous(), hand_points.contiguous())

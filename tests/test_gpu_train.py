@@ -466,3 +466,119 @@ def test_fused_hand_losses_match_the_torch_composition():
         assert abs(la[k] - lb[k]) <= 2e-5 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
     ga, gb = res[True][1], res[False][1]
     assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-7, float((ga - gb).abs().max())
+
+
+# ---- the 21-token tail in training mode (csrc/tail_train.hip, hotrack_amd/tail_train.py) ----------------------------------------
+@pytest.mark.parametrize("rows,C,two,with_y", [(672, 384, True, False), (672, 384, True, True), (21, 384, False, True), (100, 256, True, True), (7, 64, False, False)])
+def test_tail_ln_matches_torch(rows, C, two, with_y):
+    """LN_b(LN_a(x + y + bias)) forward / backward (dropout off) vs torch.nn.LayerNorm in fp64."""
+    from hotrack_amd import tail_train as T
+    g = torch.Generator(device="cuda").manual_seed(rows + C)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    na, nb = torch.nn.LayerNorm(C).cuda(), torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        for n in (na, nb):
+            n.weight.copy_(1 + 0.3 * r(C))
+            n.bias.copy_(0.2 * r(C))
+    x, y, bias = r(rows, C).requires_grad_(True), r(rows, C).requires_grad_(True), r(C).requires_grad_(True)
+    grads = T.TailGrads("cuda", 8 * C)
+    out = T.ln(x, na, nb if two else None, grads, y=y if with_y else None, bias=bias if with_y else None)
+    go = r(rows, C)
+    out.backward(go)
+    got = [t.grad.clone() if t.grad is not None else None for t in (x, y, bias, na.weight, na.bias, nb.weight, nb.bias)]
+    for t in (x, y, bias, na.weight, na.bias, nb.weight, nb.bias):
+        t.grad = None
+    xd, yd, bd = x.detach().double().requires_grad_(True), y.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True)
+    nad, nbd = torch.nn.LayerNorm(C).cuda().double(), torch.nn.LayerNorm(C).cuda().double()
+    nad.load_state_dict({k: v.double() for k, v in na.state_dict().items()})
+    nbd.load_state_dict({k: v.double() for k, v in nb.state_dict().items()})
+    u = xd + (yd + bd if with_y else 0)
+    ref = nad(u)
+    if two:
+        ref = nbd(ref)
+    ref.backward(go.double())
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
+    want = [xd.grad, yd.grad if with_y else None, bd.grad if with_y else None, nad.weight.grad, nad.bias.grad,
+            nbd.weight.grad if two else None, nbd.bias.grad if two else None]
+    for a, b, name in zip(got, want, ("dx", "dy", "dbias", "dga", "dba", "dgb", "dbb")):
+        if b is None:
+            assert a is None or name in ("dy", "dbias"), name
+            continue
+        assert a is not None, name
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a.double() - b).abs().max()) / scale < 1e-4, (name, float((a.double() - b).abs().max()) / scale)
+
+
+def test_tail_relu_dropout_mask_is_consistent_and_unbiased():
+    """dropout(relu(z + bias)): p = 0 equals torch exactly; with p > 0 the keep rate is 1 - p, kept elements are scaled by
+    1 / (1 - p), the backward regenerates the same mask, and two forwards with different seeds draw different masks."""
+    from hotrack_amd import tail_train as T
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rows, C = 672, 1024
+    z = torch.randn(rows, C, device="cuda", generator=g).requires_grad_(True)
+    bias = torch.randn(C, device="cuda", generator=g).requires_grad_(True)
+    grads = T.TailGrads("cuda", 4 * C)
+    h0 = T.relu_dropout(z, bias, 0.0, 1, None, grads)
+    assert torch.equal(h0, torch.relu(z + bias))
+    h0.backward(torch.ones_like(h0))
+    assert torch.equal(z.grad, (z + bias > 0).float()) and torch.allclose(bias.grad, (z + bias > 0).float().sum(0), rtol=1e-5)
+    z.grad = bias.grad = None
+    seeds = [torch.tensor([s], dtype=torch.int64, device="cuda") for s in (5, 6)]
+    outs = []
+    for sd in seeds:
+        h = T.relu_dropout(z, bias, 0.1, 3, sd, grads)
+        pos = (z + bias > 0)
+        kept = (h != 0) & pos
+        rate = float(kept.sum()) / float(pos.sum())
+        assert abs(rate - 0.9) < 0.01, rate
+        assert torch.allclose(h[kept], (z + bias)[kept] / 0.9, rtol=1e-6)
+        (gz,) = torch.autograd.grad(h, z, torch.ones_like(h))
+        assert torch.equal(gz != 0, kept) and torch.allclose(gz[kept], torch.full_like(gz[kept], 1 / 0.9))
+        outs.append(kept)
+    assert float((outs[0] ^ outs[1]).float().mean()) > 0.05  # different seeds, different masks
+
+
+def test_fast_tail_equals_module_tail():
+    """FastTail (token-major, fused element-wise runs) vs the module composition TransT -> c3 -> final_mlp on the same
+    weights with dropout off: outputs 1e-5, every parameter gradient 1e-4 relative."""
+    from _netinit import deterministic_init, make_cfg
+    from models.hand_network import HandTrackNet
+    from models.fast_train import FastTail
+    from models.hand_utils import decanonicalize
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    net = HandTrackNet(make_cfg("cuda"))
+    deterministic_init(net)
+    net = net.cuda().train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    g = torch.Generator(device="cuda").manual_seed(1)
+    B, J, C = 5, 21, 384
+    rows = torch.randn(B * J, C, device="cuda", generator=g)
+    xyz1 = torch.randn(B, 3, J, device="cuda", generator=g)
+    canon = {"scale": 0.2 * torch.ones(1, device="cuda"), "rotation": torch.eye(3, device="cuda").repeat(B, 1, 1), "translation": torch.randn(B, 3, 1, device="cuda", generator=g)}
+    assert FastTail.supported(net)
+    res = {}
+    for fast in (True, False):
+        net.zero_grad()
+        r_ = rows.clone().requires_grad_(True)
+        if fast:
+            hf, kp = FastTail(net).forward(r_, xyz1, canon)
+        else:
+            f14 = r_.view(B, J, C).transpose(1, 2)
+            f15, f251 = net.transt(src1=f14, pos1=None, src2=None, pos2=None, attn=False, elide_dead=True, need_result2=False)
+            fused = net.c3(f15, None, f251, None, attn=False, elide_dead=True)
+            lin = lambda conv, x: F.linear(x.transpose(1, 2), conv.weight.squeeze(-1), conv.bias).transpose(1, 2)
+            hf = lin(net.final_mlp[2], F.relu(lin(net.final_mlp[0], fused))) + xyz1
+            kp = decanonicalize(hf, canon).transpose(2, 1)
+        ((hf * torch.cos(torch.arange(hf.numel(), device="cuda").view_as(hf) * 0.1)).sum() + kp.sum()).backward()
+        res[fast] = (hf.detach(), kp.detach(), r_.grad, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    a, b = res[True], res[False]
+    torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a[1], b[1], rtol=1e-5, atol=1e-5)
+    assert set(a[3]) == set(b[3]) and len(a[3]) > 20
+    for k in b[3]:
+        scale = float(b[3][k].abs().max()) + 1e-12
+        assert float((a[3][k] - b[3][k]).abs().max()) / scale < 1e-4, k
+    assert float((a[2] - b[2]).abs().max()) / float(b[2].abs().max()) < 1e-4
