@@ -198,80 +198,85 @@ kabsch_bwd_kernel(int b, int xb, int num, const float *__restrict__ x_all, const
 constexpr int kHlJ = 21, kHlPalm = 6;
 __constant__ int kHlPalmIdx[kHlPalm] = {0, 1, 5, 9, 13, 17};  // hand_utils.handkp2palmkp
 
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(1024)
 hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const float *__restrict__ init_hf, const float *__restrict__ gt_kp,
                      const float *__restrict__ pred_kp, const float *__restrict__ Rc, const float *__restrict__ tc, float s,
                      const float *__restrict__ palm, float *__restrict__ out, float *__restrict__ saved) {
     // saved per cloud: [0:63) gt_s (3,21 channel-major) | [63:72) R | [72:75) t | [75:84) R_gt | [84:87) t_gt
+    // one workgroup of 16 waves; a wave takes clouds w, w + 16, ...: lanes 0..20 = the keypoints (all loads of a cloud in flight
+    // together), lanes 0 / 1 then fit the ground-truth / predicted palm
     __shared__ float acc[9];
-    __shared__ float xch[64][12];
+    __shared__ float yl[16][2][kHlPalm * 3];
+    __shared__ float fit[16][2][12];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x < 9) acc[threadIdx.x] = 0.f;
     __syncthreads();
-    const int role = threadIdx.x & 1, slot = threadIdx.x >> 1;
     float part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b0 = 0; b0 < B; b0 += 64) {
-        const int b = b0 + slot;
-        const bool on = b < B;
+    for (int b = w; b < B; b += 16) {
+        const float *Rb = Rc + 9 * (size_t)b, *tb = tc + 3 * (size_t)b;
+        float *sv = saved + 87 * (size_t)b;
+        float l1 = 0.f, dinit = 0.f, dpred = 0.f;
+        if (lane < kHlJ) {
+            const int k = lane;
+            const float *g = gt_kp + ((size_t)b * kHlJ + k) * 3, *pk = pred_kp + ((size_t)b * kHlJ + k) * 3;
+            const float d0 = g[0] - tb[0], d1 = g[1] - tb[1], d2 = g[2] - tb[2];
+            float gs[3], ps[3], n2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                gs[c] = ((d0 * Rb[c] + d1 * Rb[3 + c] + d2 * Rb[6 + c]) / s) * s;  // canonicalize (hand_utils.py:30-31), then * s
+                ps[c] = pred_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
+                const float is = init_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
+                sv[c * kHlJ + k] = gs[c];
+                l1 += fabsf(ps[c] - gs[c]);
+                n2 += (is - gs[c]) * (is - gs[c]);
+            }
+            dinit = sqrtf(n2);
+            dpred = sqrtf((pk[0] - g[0]) * (pk[0] - g[0]) + (pk[1] - g[1]) * (pk[1] - g[1]) + (pk[2] - g[2]) * (pk[2] - g[2]));
+#pragma unroll
+            for (int j = 0; j < kHlPalm; ++j)
+                if (kHlPalmIdx[j] == k)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { yl[w][0][3 * j + c] = gs[c]; yl[w][1][3 * j + c] = ps[c]; }
+        }
+        l1 = wave_sum_f32(l1); dinit = wave_sum_f32(dinit); dpred = wave_sum_f32(dpred);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         double R[3][3], t[3];
-        float yl[kHlPalm * 3];
-        if (on) {
-            const float *Rb = Rc + 9 * (size_t)b, *tb = tc + 3 * (size_t)b;
-            float *sv = saved + 87 * (size_t)b;
-            for (int k = 0; k < kHlJ; ++k) {
-                const float *g = gt_kp + ((size_t)b * kHlJ + k) * 3;
-                const float d0 = g[0] - tb[0], d1 = g[1] - tb[1], d2 = g[2] - tb[2];
-                float gs[3];
-                for (int c = 0; c < 3; ++c) gs[c] = ((d0 * Rb[c] + d1 * Rb[3 + c] + d2 * Rb[6 + c]) / s) * s;  // canonicalize, then * s
-                if (role == 0) {
-                    float n2 = 0.f;
-                    for (int c = 0; c < 3; ++c) {
-                        sv[c * kHlJ + k] = gs[c];
-                        const float ps = pred_hf[((size_t)b * 3 + c) * kHlJ + k] * s, is = init_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
-                        part[0] += fabsf(ps - gs[c]);
-                        n2 += (is - gs[c]) * (is - gs[c]);
-                    }
-                    part[4] += sqrtf(n2);
-                } else {
-                    const float *pk = pred_kp + ((size_t)b * kHlJ + k) * 3;
-                    part[3] += sqrtf((pk[0] - g[0]) * (pk[0] - g[0]) + (pk[1] - g[1]) * (pk[1] - g[1]) + (pk[2] - g[2]) * (pk[2] - g[2]));
-                }
-                for (int j = 0; j < kHlPalm; ++j)
-                    if (kHlPalmIdx[j] == k)
-                        for (int c = 0; c < 3; ++c) yl[3 * j + c] = role == 0 ? gs[c] : pred_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
-            }
-            kabsch_solve(kHlPalm, palm + (size_t)(pb == 1 ? 0 : b) * kHlPalm * 3, yl, 3, R, t);
-            float *dst = sv + (role == 0 ? 75 : 63);
+        if (lane < 2) {  // lane 0: ground-truth fit, lane 1: predicted fit
+            float y[kHlPalm * 3];
+            for (int i = 0; i < kHlPalm * 3; ++i) y[i] = yl[w][lane][i];
+            kabsch_solve(kHlPalm, palm + (size_t)(pb == 1 ? 0 : b) * kHlPalm * 3, y, 3, R, t);
+            float *dst = sv + (lane == 0 ? 75 : 63);
             for (int a = 0; a < 3; ++a) {
-                for (int c = 0; c < 3; ++c) dst[3 * a + c] = (float)R[a][c];
-                dst[9 + a] = (float)t[a];
-            }
-            if (role == 1) {  // the predicted fit goes to the lane that holds the ground-truth fit
-                for (int a = 0; a < 9; ++a) xch[slot][a] = (float)R[a / 3][a % 3];
-                for (int a = 0; a < 3; ++a) xch[slot][9 + a] = (float)t[a];
+                for (int c = 0; c < 3; ++c) dst[3 * a + c] = fit[w][lane][3 * a + c] = (float)R[a][c];
+                dst[9 + a] = fit[w][lane][9 + a] = (float)t[a];
             }
         }
-        __syncthreads();
-        if (on && role == 0) {  // R, t here = ground truth fit; xch = predicted fit
-            const float *Rp = xch[slot], *tp = xch[slot] + 9;
-            float tr_gt = (float)(R[0][0] + R[1][1] + R[2][2]), tr_rel = 0.f, tn = 0.f, dn = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const float *Rg = fit[w][0], *tg = Rg + 9, *Rp = fit[w][1], *tp = Rp + 9;
+            float tr_gt = Rg[0] + Rg[4] + Rg[8], tr_rel = 0.f, tn = 0.f, dn = 0.f;
+            for (int a = 0; a < 9; ++a) {
+                part[1] += fabsf(Rp[a] - Rg[a]);
+                tr_rel += Rp[a] * Rg[a];  // trace(R^T R_gt)
+            }
             for (int a = 0; a < 3; ++a) {
-                for (int c = 0; c < 3; ++c) {
-                    part[1] += fabsf(Rp[3 * a + c] - (float)R[a][c]);
-                    tr_rel += Rp[3 * a + c] * (float)R[a][c];  // trace(R^T R_gt) = sum_ac R[a][c] R_gt[a][c]
-                }
-                part[2] += fabsf(tp[a] - (float)t[a]);
-                tn += (float)(t[a] * t[a]);
-                dn += (tp[a] - (float)t[a]) * (tp[a] - (float)t[a]);
+                part[2] += fabsf(tp[a] - tg[a]);
+                tn += tg[a] * tg[a];
+                dn += (tp[a] - tg[a]) * (tp[a] - tg[a]);
             }
             const float k180 = 57.29577951308232f;
+            part[0] += l1; part[3] += dpred; part[4] += dinit;
             part[5] += acosf(fminf(fmaxf((tr_gt - 1.f) * 0.5f, -1.f), 1.f)) * k180;
             part[6] += sqrtf(tn);
             part[7] += acosf(fminf(fmaxf((tr_rel - 1.f) * 0.5f, -1.f), 1.f)) * k180;
             part[8] += sqrtf(dn);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
-    for (int i = 0; i < 9; ++i) atomicAdd(&acc[i], part[i]);
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) atomicAdd(&acc[i], part[i]);
     __syncthreads();
     if (threadIdx.x < 9) {
         const float denom[9] = {(float)B * 63.f, (float)B * 9.f, (float)B * 3.f, (float)B * 21.f, (float)B * 21.f, (float)B, (float)B, (float)B, (float)B};
@@ -379,7 +384,7 @@ extern "C" int pn2x_hand_losses(int b, int pb, const float *pred_hf, const float
                                 const float *R, const float *t, float scale, const float *palm, float *out, float *saved, void *stream) {
     if (b < 1 || !(pb == 1 || pb == b) || !(scale > 0.f)) return PN2_EINVAL;
     if (!pred_hf || !init_hf || !gt_kp || !pred_kp || !R || !t || !palm || !out || !saved) return PN2_ENULL;
-    hipLaunchKernelGGL(pn2::hand_loss_fwd_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, b, pb, pred_hf, init_hf, gt_kp, pred_kp, R, t,
+    hipLaunchKernelGGL(pn2::hand_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, b, pb, pred_hf, init_hf, gt_kp, pred_kp, R, t,
                        scale, palm, out, saved);
     return pn2::check_launch();
 }

@@ -194,14 +194,19 @@ tail_ln_bwd_kernel(LnBwdArgs b) {
             }
         }
     }
+    // the four waves' column sums meet in LDS: one atomic per column, accumulator and workgroup
+    __shared__ float red[4][5][64 * EPL];
+    const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int ch = lane + 64 * e;
-        if (ch >= c) continue;
-        atomicAdd(b.dga + ch, sga[e]);
-        atomicAdd(b.dba + ch, sba[e]);
-        if (b.dgb) { atomicAdd(b.dgb + ch, sgb[e]); atomicAdd(b.dbb + ch, sbb[e]); }
-        if (b.dbias) atomicAdd(b.dbias + ch, sbias[e]);
+        red[w][0][ch] = sga[e]; red[w][1][ch] = sba[e]; red[w][2][ch] = sgb[e]; red[w][3][ch] = sbb[e]; red[w][4][ch] = sbias[e];
+    }
+    __syncthreads();
+    float *const dst[5] = {b.dga, b.dba, b.dgb, b.dbb, b.dbias};
+    for (int i = threadIdx.x; i < 5 * c; i += 256) {
+        const int k = i / c, ch = i - k * c;
+        if (dst[k]) atomicAdd(dst[k] + ch, (red[0][k][ch] + red[1][k][ch]) + (red[2][k][ch] + red[3][k][ch]));
     }
 }
 
@@ -226,26 +231,36 @@ tail_relu_drop_fwd_kernel(long n, int c, const float *__restrict__ z, const floa
     *reinterpret_cast<float4 *>(out + i) = make_float4(h[0], h[1], h[2], h[3]);
 }
 
-// dz = dh * mask * [z + bias > 0]; dbias += column sums.  One wave per `rows_per_wave` rows, lanes stride the columns by quads.
+// dz = dh * mask * [z + bias > 0]; dbias += column sums.  A workgroup owns 16 rows x 256 columns: wave w takes rows 4w .. 4w+3,
+// lane l the column quad 4l of the tile (four independent 16-byte load pairs in flight); the four waves' column sums meet in LDS
+// and leave as ONE atomic per column and workgroup.
 __global__ void __launch_bounds__(256)
 tail_relu_drop_bwd_kernel(long rows, int c, const float *__restrict__ z, const float *__restrict__ bias, float p, unsigned site,
                           const long long *__restrict__ seed_in, const float *__restrict__ dh, float *__restrict__ dz,
-                          float *__restrict__ dbias, int rows_per_wave) {
-    const int lane = threadIdx.x & 63;
-    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long r0 = wave_id * rows_per_wave;
-    const long r1 = r0 + rows_per_wave < rows ? r0 + rows_per_wave : rows;
+                          float *__restrict__ dbias) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q0 = blockIdx.y * 256 + lane * 4;
+    const long r0 = (long)blockIdx.x * 16 + w * 4;
     const unsigned thresh = drop_threshold(p);
     const unsigned long long seed = thresh ? (unsigned long long)seed_in[0] : 0ull;
     const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
-    for (int q0 = lane * 4; q0 < c; q0 += 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (q0 < c) {
         const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + q0) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (long row = r0; row < r1; ++row) {
-            const long i = row * c + q0;
-            const float4 zv = *reinterpret_cast<const float4 *>(z + i), gv = *reinterpret_cast<const float4 *>(dh + i);
-            const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+        float4 zv[4], gv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = r0 + r < rows ? r0 + r : rows - 1;
+            zv[r] = *reinterpret_cast<const float4 *>(z + row * c + q0);
+            gv[r] = *reinterpret_cast<const float4 *>(dh + row * c + q0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r0 + r >= rows) break;
+            const long i = (r0 + r) * c + q0;
+            const float zz[4] = {zv[r].x, zv[r].y, zv[r].z, zv[r].w}, gg[4] = {gv[r].x, gv[r].y, gv[r].z, gv[r].w};
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -256,11 +271,13 @@ tail_relu_drop_bwd_kernel(long rows, int c, const float *__restrict__ z, const f
             }
             *reinterpret_cast<float4 *>(dz + i) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        if (dbias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(dbias + q0 + e, acc[e]);
-        }
     }
+    if (!dbias) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = acc[e];
+    __syncthreads();
+    const int col = blockIdx.y * 256 + threadIdx.x;
+    if (col < c) atomicAdd(dbias + col, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 static int epl_of(int c) { return c <= 128 ? 2 : (c <= 256 ? 4 : (c <= 512 ? 8 : (c <= 1024 ? 16 : 0))); }
@@ -300,7 +317,7 @@ extern "C" int pn2x_tail_ln_bwd(long rows, int c, const float *x, const float *y
     if (y && p > 0.f && !seed_in) return PN2_ENULL;
     LnBwdArgs b{LnArgs{rows, c, x, y, bias, p, (unsigned)site, seed_in, nullptr, nullptr, ga, ba, eps_a, gb, bb, eps_b, nullptr,
                        const_cast<float *>(stats)},
-                dout, dx, dy, dga, dba, gb ? dgb : nullptr, gb ? dbb : nullptr, (y && bias) ? dbias : nullptr, 4};
+                dout, dx, dy, dga, dba, gb ? dgb : nullptr, gb ? dbb : nullptr, (y && bias) ? dbias : nullptr, 2};
     const long waves = (rows + b.rows_per_wave - 1) / b.rows_per_wave;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
@@ -330,9 +347,7 @@ extern "C" int pn2x_tail_relu_drop_bwd(long rows, int c, const float *z, const f
     if (rows == 0) return PN2_OK;
     if (!z || !dh || !dz || (p > 0.f && !seed_in)) return PN2_ENULL;
     if (((uintptr_t)z | (uintptr_t)dh | (uintptr_t)dz | (uintptr_t)bias) % 16) return PN2_EINVAL;
-    const int rpw = 8;
-    const long waves = (rows + rpw - 1) / rpw;
-    hipLaunchKernelGGL(tail_relu_drop_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, c, z, bias, p,
-                       (unsigned)site, seed_in, dh, dz, dbias, rpw);
+    hipLaunchKernelGGL(tail_relu_drop_bwd_kernel, dim3((unsigned)((rows + 15) / 16), (unsigned)((c + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rows, c, z, bias, p, (unsigned)site, seed_in, dh, dz, dbias);
     return check_launch();
 }

@@ -87,7 +87,9 @@ class _Ln(torch.autograd.Function):
             _native._check(_lib.pn2x_tail_ln_bwd(rows, c, x.data_ptr(), _p(y), _p(bias), p, site, _p(seed_in), ga.data_ptr(), ba.data_ptr(), eps_a,
                                                  _p(gb), _p(bb), eps_b, stats.data_ptr(), dout.data_ptr(), dx.data_ptr(), _p(dy), dga.data_ptr(),
                                                  dba.data_ptr(), _p(dgb), _p(dbb), _p(dbias), _native._stream(x)), "tail_ln_bwd")
-        return dx, dy, dbias, dga, dba, dgb, dbb, None, None, None, None, None, None, None, None
+        # fresh view objects: autograd keeps a gradient it is the sole owner of instead of cloning it (a copy launch per parameter)
+        v = lambda t: None if t is None else t[:]
+        return dx, dy, v(dbias), v(dga), v(dba), v(dgb), v(dbb), None, None, None, None, None, None, None, None
 
 
 def ln(x, norm_a, norm_b, grads, y=None, bias=None, p=0.0, site=0, seed_in=None, seed_dev=None, seed_out=None):
@@ -121,7 +123,7 @@ class _ReluDrop(torch.autograd.Function):
         with torch.cuda.device(z.device):
             _native._check(_lib.pn2x_tail_relu_drop_bwd(rows, c, z.data_ptr(), _p(bias), p, site, _p(seed_in), dh.data_ptr(), dz.data_ptr(),
                                                         _p(acc), _native._stream(z)), "tail_relu_drop_bwd")
-        return dz, acc, None, None, None, None
+        return dz, (None if acc is None else acc[:]), None, None, None, None
 
 
 def relu_dropout(z, bias, p, site, seed_in, grads):
