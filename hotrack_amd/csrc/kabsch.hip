@@ -198,64 +198,71 @@ kabsch_bwd_kernel(int b, int xb, int num, const float *__restrict__ x_all, const
 constexpr int kHlJ = 21, kHlPalm = 6;
 __constant__ int kHlPalmIdx[kHlPalm] = {0, 1, 5, 9, 13, 17};  // hand_utils.handkp2palmkp
 
+constexpr int kHlChunk = 128;  // clouds per pass of the single workgroup
+
 __global__ void __launch_bounds__(1024)
 hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const float *__restrict__ init_hf, const float *__restrict__ gt_kp,
                      const float *__restrict__ pred_kp, const float *__restrict__ Rc, const float *__restrict__ tc, float s,
                      const float *__restrict__ palm, float *__restrict__ out, float *__restrict__ saved) {
     // saved per cloud: [0:63) gt_s (3,21 channel-major) | [63:72) R | [72:75) t | [75:84) R_gt | [84:87) t_gt
-    // one workgroup of 16 waves; a wave takes clouds w, w + 16, ...: lanes 0..20 = the keypoints (all loads of a cloud in flight
-    // together), lanes 0 / 1 then fit the ground-truth / predicted palm
+    // One workgroup of 16 waves, clouds in passes of 128: (1) a wave per cloud with lanes 0..20 = the keypoints (all loads of a cloud
+    // in flight together), palm points to LDS; (2) 2 x 128 threads each solve ONE rigid fit (ground truth / predicted) -- all fits of a
+    // pass run side by side, the Jacobi solve is the long pole (~15 us once); (3) a thread per cloud forms the rotation / translation terms.
     __shared__ float acc[9];
-    __shared__ float yl[16][2][kHlPalm * 3];
-    __shared__ float fit[16][2][12];
+    __shared__ float yl[kHlChunk][2][kHlPalm * 3];
+    __shared__ float fit[kHlChunk][2][12];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x < 9) acc[threadIdx.x] = 0.f;
-    __syncthreads();
     float part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = w; b < B; b += 16) {
-        const float *Rb = Rc + 9 * (size_t)b, *tb = tc + 3 * (size_t)b;
-        float *sv = saved + 87 * (size_t)b;
-        float l1 = 0.f, dinit = 0.f, dpred = 0.f;
-        if (lane < kHlJ) {
-            const int k = lane;
-            const float *g = gt_kp + ((size_t)b * kHlJ + k) * 3, *pk = pred_kp + ((size_t)b * kHlJ + k) * 3;
-            const float d0 = g[0] - tb[0], d1 = g[1] - tb[1], d2 = g[2] - tb[2];
-            float gs[3], ps[3], n2 = 0.f;
+    for (int b0 = 0; b0 < B; b0 += kHlChunk) {
+        const int nb = (B - b0) < kHlChunk ? (B - b0) : kHlChunk;
+        __syncthreads();
+        for (int i = w; i < nb; i += 16) {
+            const int b = b0 + i;
+            const float *Rb = Rc + 9 * (size_t)b, *tb = tc + 3 * (size_t)b;
+            float *sv = saved + 87 * (size_t)b;
+            float l1 = 0.f, dinit = 0.f, dpred = 0.f;
+            if (lane < kHlJ) {
+                const int k = lane;
+                const float *g = gt_kp + ((size_t)b * kHlJ + k) * 3, *pk = pred_kp + ((size_t)b * kHlJ + k) * 3;
+                const float d0 = g[0] - tb[0], d1 = g[1] - tb[1], d2 = g[2] - tb[2];
+                float gs[3], ps[3], n2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                gs[c] = ((d0 * Rb[c] + d1 * Rb[3 + c] + d2 * Rb[6 + c]) / s) * s;  // canonicalize (hand_utils.py:30-31), then * s
-                ps[c] = pred_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
-                const float is = init_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
-                sv[c * kHlJ + k] = gs[c];
-                l1 += fabsf(ps[c] - gs[c]);
-                n2 += (is - gs[c]) * (is - gs[c]);
+                for (int c = 0; c < 3; ++c) {
+                    gs[c] = ((d0 * Rb[c] + d1 * Rb[3 + c] + d2 * Rb[6 + c]) / s) * s;  // canonicalize (hand_utils.py:30-31), then * s
+                    ps[c] = pred_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
+                    const float is = init_hf[((size_t)b * 3 + c) * kHlJ + k] * s;
+                    sv[c * kHlJ + k] = gs[c];
+                    l1 += fabsf(ps[c] - gs[c]);
+                    n2 += (is - gs[c]) * (is - gs[c]);
+                }
+                dinit = sqrtf(n2);
+                dpred = sqrtf((pk[0] - g[0]) * (pk[0] - g[0]) + (pk[1] - g[1]) * (pk[1] - g[1]) + (pk[2] - g[2]) * (pk[2] - g[2]));
+#pragma unroll
+                for (int j = 0; j < kHlPalm; ++j)
+                    if (kHlPalmIdx[j] == k)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { yl[i][0][3 * j + c] = gs[c]; yl[i][1][3 * j + c] = ps[c]; }
             }
-            dinit = sqrtf(n2);
-            dpred = sqrtf((pk[0] - g[0]) * (pk[0] - g[0]) + (pk[1] - g[1]) * (pk[1] - g[1]) + (pk[2] - g[2]) * (pk[2] - g[2]));
-#pragma unroll
-            for (int j = 0; j < kHlPalm; ++j)
-                if (kHlPalmIdx[j] == k)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { yl[w][0][3 * j + c] = gs[c]; yl[w][1][3 * j + c] = ps[c]; }
+            l1 = wave_sum_f32(l1); dinit = wave_sum_f32(dinit); dpred = wave_sum_f32(dpred);
+            if (lane == 0) { part[0] += l1; part[3] += dpred; part[4] += dinit; }
         }
-        l1 = wave_sum_f32(l1); dinit = wave_sum_f32(dinit); dpred = wave_sum_f32(dpred);
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double R[3][3], t[3];
-        if (lane < 2) {  // lane 0: ground-truth fit, lane 1: predicted fit
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * nb) {  // thread 2i: ground-truth fit of cloud i, 2i + 1: predicted fit
+            const int i = threadIdx.x >> 1, role = threadIdx.x & 1, b = b0 + i;
             float y[kHlPalm * 3];
-            for (int i = 0; i < kHlPalm * 3; ++i) y[i] = yl[w][lane][i];
+            for (int e = 0; e < kHlPalm * 3; ++e) y[e] = yl[i][role][e];
+            double R[3][3], t[3];
             kabsch_solve(kHlPalm, palm + (size_t)(pb == 1 ? 0 : b) * kHlPalm * 3, y, 3, R, t);
-            float *dst = sv + (lane == 0 ? 75 : 63);
+            float *dst = saved + 87 * (size_t)b + (role == 0 ? 75 : 63);
             for (int a = 0; a < 3; ++a) {
-                for (int c = 0; c < 3; ++c) dst[3 * a + c] = fit[w][lane][3 * a + c] = (float)R[a][c];
-                dst[9 + a] = fit[w][lane][9 + a] = (float)t[a];
+                for (int c = 0; c < 3; ++c) dst[3 * a + c] = fit[i][role][3 * a + c] = (float)R[a][c];
+                dst[9 + a] = fit[i][role][9 + a] = (float)t[a];
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            const float *Rg = fit[w][0], *tg = Rg + 9, *Rp = fit[w][1], *tp = Rp + 9;
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {
+            const float *Rg = fit[threadIdx.x][0], *tg = Rg + 9, *Rp = fit[threadIdx.x][1], *tp = Rp + 9;
             float tr_gt = Rg[0] + Rg[4] + Rg[8], tr_rel = 0.f, tn = 0.f, dn = 0.f;
             for (int a = 0; a < 9; ++a) {
                 part[1] += fabsf(Rp[a] - Rg[a]);
@@ -267,16 +274,15 @@ hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const flo
                 dn += (tp[a] - tg[a]) * (tp[a] - tg[a]);
             }
             const float k180 = 57.29577951308232f;
-            part[0] += l1; part[3] += dpred; part[4] += dinit;
             part[5] += acosf(fminf(fmaxf((tr_gt - 1.f) * 0.5f, -1.f), 1.f)) * k180;
             part[6] += sqrtf(tn);
             part[7] += acosf(fminf(fmaxf((tr_rel - 1.f) * 0.5f, -1.f), 1.f)) * k180;
             part[8] += sqrtf(dn);
         }
-        __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0)
-        for (int i = 0; i < 9; ++i) atomicAdd(&acc[i], part[i]);
+    __syncthreads();
+    for (int i = 0; i < 9; ++i)
+        if (part[i] != 0.f) atomicAdd(&acc[i], part[i]);
     __syncthreads();
     if (threadIdx.x < 9) {
         const float denom[9] = {(float)B * 63.f, (float)B * 9.f, (float)B * 3.f, (float)B * 21.f, (float)B * 21.f, (float)B, (float)B, (float)B, (float)B};

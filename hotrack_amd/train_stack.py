@@ -38,12 +38,55 @@ _lib.pn2x_tg_wgrad_partial_floats.argtypes = [_cl, _ci, _ci]
 _lib.pn2x_tg_wgrad_partial_floats.restype = _cl
 _lib.pn2x_tg_wgrad.argtypes = [_cl, _ci, _ci] + _DY + [_vp, _ci, _vp, _vp, _vp, _vp, _vp, _cl, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_tg_wgrad.restype = _ci
+_lib.pn2x_tg_wgrad2.argtypes = _lib.pn2x_tg_wgrad.argtypes[:-1] + [ctypes.POINTER(_ci), _vp]
+_lib.pn2x_tg_wgrad2.restype = _ci
+_lib.pn2x_tg_reduce_multi.argtypes = [_ci, ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_vp),
+                                      ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                      ctypes.POINTER(_vp), _vp]
+_lib.pn2x_tg_reduce_multi.restype = _ci
 _lib.pn2x_bn_bwd_reduce.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
 _lib.pn2x_bn_bwd_reduce.restype = _ci
 _lib.pn2x_bn_bwd_reduce_g.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp]
 _lib.pn2x_bn_bwd_reduce_g.restype = _ci
 import os as _os
 ROUTE_DENSE = _os.environ.get("HOTRACK_STACK_ROUTE_DENSE", "1") != "0"  # max-routed top gradient materialised once by the reduction
+# The weight gradients are not read before the optimiser: the backward writes only partial tiles and ONE launch at the end of
+# the pass (autograd's final callbacks) sums the tiles of every layer of every stack.  Off (HOTRACK_STACK_DEFER_REDUCE=0, or
+# `DEFER_REDUCE = False`) where something reads .grad from inside the pass -- DistributedDataParallel's bucket hooks do.
+DEFER_REDUCE = _os.environ.get("HOTRACK_STACK_DEFER_REDUCE", "1") != "0"
+_pending = []
+_pending_task = [None]  # the autograd pass the pending items belong to (a pass that raised leaves stale ones behind)
+
+
+def _defer(item):
+    task = torch._C._current_graph_task_id()
+    if _pending_task[0] != task:
+        _pending.clear()
+        _pending_task[0] = task
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_reductions)
+    _pending.append(item)
+
+
+def _flush_reductions():
+    items, _pending[:] = list(_pending), []
+    _pending_task[0] = None
+    if not items:
+        return
+    n = len(items)
+    arr = lambda: (_vp * n)()
+    part, dw, sm, dg, db, dbi = arr(), arr(), arr(), arr(), arr(), arr()
+    P, numel, ch = (_ci * n)(), (_ci * n)(), (_ci * n)()
+    for j, (partial, np_, dwt, sums, dpar, _st) in enumerate(items):
+        part[j], dw[j], sm[j] = partial.data_ptr(), dwt.data_ptr(), sums.data_ptr()
+        dg[j], db[j], dbi[j] = dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr()
+        P[j], numel[j], ch[j] = np_, dwt.numel(), dwt.shape[0]
+    st = items[0][5]
+    if any(it[5] != st for it in items):
+        raise RuntimeError("train_stack: deferred reductions recorded on different streams")
+    with torch.cuda.device(items[0][2].device):
+        _native._check(_lib.pn2x_tg_reduce_multi(n, part, P, numel, dw, sm, ch, dg, db, dbi, st), "tg_reduce_multi")
+
+
 _lib.pn2x_bn_bwd_apply.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_bn_bwd_apply.restype = _ci
 _f32 = torch.float32
@@ -56,7 +99,8 @@ def supported(c_in: int, c_out: int) -> bool:
 
 
 class Layer:
-    """One layer of a stack: weight (C_out, C_in) | None for the first layer, BatchNorm module, the conv bias (or None)."""
+    """One layer of a stack: weight (C_out, C_in[, 1[, 1]]) | None for the first layer, BatchNorm module, the conv bias (or
+    None).  Pass the convolution's weight PARAMETER itself (not a view of it) to let its gradient sum be deferred."""
 
     def __init__(self, weight, bn, conv_bias=None):
         self.weight, self.bn, self.conv_bias = weight, bn, conv_bias
@@ -80,6 +124,7 @@ class _Stack(torch.autograd.Function):
                 w, gamma_p, beta_p, bias_p = tensors[4 * i], tensors[4 * (i - 1) + 1], tensors[4 * (i - 1) + 2], tensors[4 * (i - 1) + 3]
                 bias_p = bias_p if bias_p.numel() else None
                 rm, rv, nbt, eps, mom = metas[i - 1]
+                w = w.view(w.shape[0], -1)  # a Conv1d / Conv2d 1x1 weight parameter as (C_out, C_in)
                 N, Kc = w.shape
                 if w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16:
                     w = w.contiguous()
@@ -141,6 +186,11 @@ class _Stack(torch.autograd.Function):
         else:
             sums = [torch.zeros(s.numel(), dtype=torch.float64, device=dev) for s in ctx.ws_b_all]
         grads = [None] * len(tensors)
+        # deferring is only sound when autograd ADOPTS the returned tensors (grad is None); an in-place accumulation into an
+        # existing .grad would read them before the reduction ran
+        # (nor may anything downstream consume them inside the pass: leaves only)
+        defer = DEFER_REDUCE and all(tensors[j].is_leaf and tensors[j].grad is None
+                                     for i in range(1, L) for j in (4 * i, 4 * i + 1, 4 * i + 2))
         gam = lambda i: tensors[4 * i + 1]
         bet = lambda i: tensors[4 * i + 2]
         with torch.cuda.device(dev):
@@ -158,7 +208,8 @@ class _Stack(torch.autograd.Function):
             if g_dense is not None:
                 g, gmode = g_dense, 0
             for i in range(L - 1, 0, -1):
-                w = tensors[4 * i]
+                w_shape = tensors[4 * i].shape
+                w = tensors[4 * i].view(w_shape[0], -1)
                 N, Kc = w.shape
                 wc = w if (w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0) else w.contiguous()
                 yi, yp, svi, svp = ys[i], ys[i - 1], saved[i], saved[i - 1]
@@ -168,9 +219,14 @@ class _Stack(torch.autograd.Function):
                 partial = torch.empty(pf, dtype=_f32, device=dev)
                 dw = torch.empty((N, Kc), dtype=_f32, device=dev)
                 dpar = torch.empty((3, N), dtype=_f32, device=dev)
-                _native._check(_lib.pn2x_tg_wgrad(R, N, Kc, *dy_args, yp.data_ptr(), yp.stride(0), svp[0].data_ptr(), svp[1].data_ptr(),
-                                                  gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), partial.data_ptr(), pf, dw.data_ptr(),
-                                                  dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(), st), "tg_wgrad")
+                np_ = _ci(0)
+                _native._check(_lib.pn2x_tg_wgrad2(R, N, Kc, *dy_args, yp.data_ptr(), yp.stride(0), svp[0].data_ptr(), svp[1].data_ptr(),
+                                                   gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), partial.data_ptr(), pf, dw.data_ptr(),
+                                                   dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(),
+                                                   ctypes.byref(np_) if defer else None, st), "tg_wgrad")
+                if defer:
+                    _defer((partial, np_.value, dw, sums[i], dpar, st))
+                dw = dw.view(w_shape)  # a fresh view: autograd adopts it (no clone); a late reduction lands in the adopted storage
                 grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = dw, dpar[0], dpar[1]
                 if ctx.has_bias[i]:
                     grads[4 * i + 3] = dpar[2]  # zeros: the bias of a convolution in front of a BatchNorm has no gradient

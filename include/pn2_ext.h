@@ -447,6 +447,17 @@ int pn2x_tail_relu_drop_bwd(long rows, int c, const float *z, const float *bias,
  */
 int pn2x_adam_multi(int n, void *const *p, const void *const *g, void *const *m, void *const *v, void *const *step,
                     const long *numel, double lr, double beta1, double beta2, double eps, double weight_decay, void *stream);
+/* pn2x_tg_wgrad with the reduction deferred: n_partials != NULL -> only the partial tiles are written (dw zeroed) and their count
+ * returned; pn2x_tg_reduce_multi then sums the partial tiles of SEVERAL layers (host arrays of `count` entries) and emits their
+ * dgamma / dbeta (/ zero dbias) in one launch -- the weight gradients are not needed before the optimiser step. */
+int pn2x_tg_wgrad2(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi, int ldyi,
+                   const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i, const double *sums_bwd_i,
+                   const float *yp, int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p,
+                   float *partial, long partial_floats, float *dw, float *dgamma, float *dbeta, float *dbias, int *n_partials,
+                   void *stream);
+int pn2x_tg_reduce_multi(int count, const float *const *partial, const int *n_partials, const int *numel, float *const *dw,
+                         const double *const *sums_bwd, const int *channels, float *const *dgamma, float *const *dbeta,
+                         float *const *dbias, void *stream);
 
 #ifdef __cplusplus
 }

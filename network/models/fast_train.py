@@ -85,7 +85,7 @@ class FastTrain:
             if train_stack.stack_supported(widths[0], widths[1:]):
                 y1 = x2d if first_done else F.linear(x2d, _w2d(convs[0]))
                 layers = [train_stack.Layer(None, bns[0], convs[0].bias)]
-                layers += [train_stack.Layer(_w2d(c), bn, c.bias) for c, bn in zip(convs[1:], bns[1:])]
+                layers += [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(convs[1:], bns[1:])]
                 return train_stack.mlp_stack(y1, layers, self.ws, max_over)
         last = len(convs) - 1
         for i, (conv, bn) in enumerate(zip(convs, bns)):

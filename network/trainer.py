@@ -129,6 +129,9 @@ class Trainer(nn.Module):
         self._flat = self._flat_grads = self._opt_graph = None
         if self.world > 1 and self.optimizer is not None:
             if self.dp_mode == "ddp":
+                if torch.cuda.is_available():  # DDP's bucket hooks read .grad inside the pass: no deferred weight-gradient sums
+                    from hotrack_amd import train_stack as _ts
+                    _ts.DEFER_REDUCE = False
                 ids = [self.device.index] if isinstance(self.device, torch.device) and self.device.type == "cuda" else None
                 self.ddp = nn.parallel.DistributedDataParallel(_StepModule(self.model), device_ids=ids,
                                                                find_unused_parameters=True, broadcast_buffers=False)

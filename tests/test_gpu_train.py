@@ -379,6 +379,62 @@ def test_mlp_stack_second_backward_and_stale_workspace():
     assert out_b.shape == out.shape
 
 
+def test_mlp_stack_deferred_weight_gradient_sums():
+    """The weight-gradient reductions of all stacks run as ONE launch at the end of the autograd pass (train_stack._defer):
+    same gradients as the immediate reductions; more layers in a pass than one kernel-argument pack holds; a second pass
+    that ACCUMULATES into existing .grad falls back to immediate reductions (autograd would read the tensors too early)."""
+    from hotrack_amd import train_stack
+    from hotrack_amd.train_ops import Workspace
+    g = torch.Generator(device="cuda").manual_seed(5)
+    R, widths, n_stacks = 2048, [32, 64, 32, 64], 10          # 30 fused layers in one pass (> kRmMax = 24)
+    stacks = [([torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])],
+               [torch.nn.BatchNorm1d(c).cuda().train() for c in widths]) for _ in range(n_stacks)]
+    params = [p for convs, bns in stacks for m in convs + bns for p in m.parameters()]
+    ws = Workspace("cuda")
+    ys = [torch.randn(R, 32, device="cuda", generator=g) for _ in range(n_stacks)]
+    gos = [torch.randn(R // 16, 64, device="cuda", generator=g) for _ in range(n_stacks)]
+
+    def run_pass():
+        ws.reset()
+        total = 0
+        for (convs, bns), y, go in zip(stacks, ys, gos):
+            layers = [train_stack.Layer(None, bns[0])] + [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(convs, bns[1:])]
+            total = total + (train_stack.mlp_stack(y, layers, ws, max_over=16) * go).sum()
+        total.backward()
+
+    def grads():
+        return [None if p.grad is None else p.grad.clone() for p in params]
+
+    def zero():
+        for p in params:
+            p.grad = None
+
+    old = train_stack.DEFER_REDUCE
+    try:
+        train_stack.DEFER_REDUCE = False
+        zero(); run_pass(); ref = grads()
+        train_stack.DEFER_REDUCE = True
+        seen = []
+        flush = train_stack._flush_reductions
+        train_stack._flush_reductions = lambda: (seen.append(len(train_stack._pending)), flush())
+        try:
+            zero(); run_pass(); got = grads()
+            assert seen == [n_stacks * (len(widths) - 1)] and not train_stack._pending   # ONE flush over all 30 layers
+            for a, b in zip(got, ref):
+                assert (a is None) == (b is None)
+                if a is not None:   # atomics: the order of the partial sums is free
+                    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * max(1.0, float(b.abs().max())))
+            run_pass()                                  # accumulate a second pass into the existing gradients: nothing deferred
+            assert len(seen) == 1
+            for p, b in zip(params, ref):
+                if b is not None:
+                    torch.testing.assert_close(p.grad, 2 * b, rtol=1e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
+        finally:
+            train_stack._flush_reductions = flush
+    finally:
+        train_stack.DEFER_REDUCE = old
+
+
 # ---- multi-tensor Adam (csrc/adam.hip, hotrack_amd/optim.py) ---------------------------------------------------------------------
 @pytest.mark.parametrize("wd", [0.0, 1e-4])
 def test_fused_adam_matches_torch_adam(wd):
