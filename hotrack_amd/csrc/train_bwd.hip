@@ -1,0 +1,423 @@
+// train_bwd.hip -- the whole backward of one fused [Conv 1x1 + BatchNorm + ReLU] layer in ONE kernel (gfx950).
+//
+// train_gemm.hip runs the backward of layer i as two kernels, tg_dgrad (G_{i-1} = (dY_i W_i) . mask) and tg_wgrad
+// (dW_i = dY_i^T H_{i-1}); each of them reads G_i and Y_i and rebuilds the pre-activation gradient
+//      dY_i = gamma_i invstd_i (g_i - mean(g_i) - xhat_i mean(g_i xhat_i))
+// on the way into LDS (tg_dgrad once per 64-column block), and each reads Y_{i-1}.  On the layer shapes of the training step
+// that traffic IS the cost: the wide-row / narrow-channel layers (262144 x 32..64, 131072 x 64..128) run at the HBM rate, the
+// others at a quarter of the matrix rate.  Here a persistent 512-thread workgroup takes a 64-row tile and
+//   1. builds dY_i (64 x C_i) and xhat_{i-1} (64 x C_{i-1}) ONCE, in LDS (operands fetched into registers one tile ahead);
+//   2. data gradient:   acc_g (64 x C_{i-1}) = dY_i W_i            -- A from LDS, W_i straight from L2 (it is re-read by every
+//                                                                     tile of every workgroup: 4..96 KiB, cache resident);
+//   3. weight gradient: acc_w (C_i x C_{i-1}) += dY_i^T H_{i-1}    -- both operands from LDS, H = relu(xhat gamma + beta) on
+//                       the way into the matrix instruction; the accumulators stay in registers for ALL tiles of the workgroup
+//                       and are written once, as one partial tile per workgroup (tg_reduce_multi sums them);
+//   4. epilogue: ReLU mask of layer i-1, its BatchNorm-backward sums, G_{i-1} stored as float4 rows.
+// So G_i, Y_i and Y_{i-1} are read once and G_{i-1} written once: 201 MB instead of 368 MB for a 131072 x (64 -> 128) layer.
+//
+// v_mfma_f32_32x32x2_f32 throughout.  Work split over the 8 waves: the 64 x C_{i-1} data-gradient tile is 2 NB blocks of
+// 32 x 32 (C_{i-1} = 32 NB); with fewer than 8 blocks the reduction over C_i is split across wave groups and summed in the
+// epilogue.  The C_i x C_{i-1} weight gradient is NB KB blocks (C_i = 32 KB): a wave owns NB KB / 8 of them (sharing the H
+// operand), or, with fewer than 8 blocks, a slice of the tile's 64 rows (one partial tile per slice).
+// Only the dense pre-masked gradient source (GMODE 0 of train_gemm.hip): the top layer's gradient is materialised by
+// bn_bwd_reduce_g, every lower one by this kernel.
+#include "pn2_common.h"
+#include "../../include/pn2_ext.h"
+
+namespace pn2 {
+namespace tgb {
+
+constexpr int kT = 512;
+constexpr int BM = 64;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float relu_nan(float h) { return !(h <= 0.f) ? h : 0.f; }  // propagates NaN like torch
+
+struct BwdArgs {
+    long R;
+    const float *G; int ldg;    // g_i = dH_i . [H_i > 0]   (R x C_i)
+    const float *Y; int ldy;    // pre-activations of layer i
+    const float *mean, *invstd, *gamma;
+    const double *sums_bwd;     // layer i: kBnRep copies of [sum(g) | sum(g xhat)]
+    const float *W; int ldw;    // (C_i x C_{i-1})
+    const float *Yp; int ldyp;  // pre-activations of layer i-1 (R x C_{i-1})
+    const float *mean_p, *invstd_p, *gamma_p, *beta_p;
+    float *Gp; int ldgp;        // out: g_{i-1}
+    double *sums_bwd_p;         // out (accumulated): layer i-1
+    float *partial;             // out: [gridDim.x * KS_W][C_i][C_{i-1}]
+    float *dW;                  // zeroed by workgroup 0 (tg_reduce_multi accumulates into it)
+#ifdef PN2_TGB_PROFILE
+    long long *prof;            // tuning builds: [gridDim.x][8] cycle counts of thread 0 (scripts/probes/tgb_profile.py)
+#endif
+};
+
+#ifdef PN2_TGB_PROFILE
+#define TGB_T(var) const long long var = clock64()
+#define TGB_ADD(slot, t1, t0) do { if (tid == 0) pacc[slot] += (t1) - (t0); } while (0)
+#else
+#define TGB_T(var)
+#define TGB_ADD(slot, t1, t0)
+#endif
+
+template <int NB, int KB>
+struct Plan {
+    static constexpr int N = 32 * NB, Kd = 32 * KB;
+    static constexpr int LDY = Kd + 1;   // odd: the 32 rows a data-gradient A read touches fall on 32 banks
+    static constexpr int LDX = N + 4;    // float4 rows
+    static constexpr int DBLK = 2 * NB;
+    static constexpr int KS_D = DBLK >= 8 ? 1 : 8 / DBLK;
+    static constexpr int WBLK = NB * KB;
+    static constexpr int KS_W = WBLK >= 8 ? 1 : 8 / WBLK;
+    static constexpr int WB = WBLK >= 8 ? WBLK / 8 : 1;
+    static constexpr int QN = N / 4, RG = kT / QN;  // epilogue / Yp mapping: thread = (column quad, row group), NB rows each
+    // W_i: resident in LDS for the narrow layers (<= 32 KiB; their kernels are HBM-bound and the next tile's operands can then
+    // be requested a whole tile ahead), streamed from L2 through a register double buffer for the 128-channel ones
+    static constexpr bool WLDS = NB <= 2;
+    static constexpr int steps_d = (Kd / 2) / KS_D;      // matrix instructions of a wave's data-gradient block
+    static constexpr int U = steps_d >= 32 ? 16 : steps_d / 2;  // W values per register buffer
+    static constexpr int lds_floats = 5 * Kd + 4 * N + BM * LDY + BM * LDX + KS_D * BM * LDX + (WLDS ? Kd * N : 0);
+    static_assert(WLDS || (steps_d % (2 * U) == 0 && U >= 1), "data-gradient batches come in pairs");
+    static_assert(NB == 1 || NB == 2 || NB == 4, "C_{i-1} in {32, 64, 128}");
+    static_assert(WBLK < 8 || WBLK % 8 == 0, "weight-gradient blocks must split evenly over 8 waves");
+    static_assert(2 * RG * N <= KS_D * BM * LDX, "the final column-sum staging reuses the data-gradient staging");
+};
+
+template <int NB, int KB>
+__global__ void __launch_bounds__(kT, (NB == 1 && KB <= 2 ? 4 : 2))  // sa1's layers: two workgroups per CU (<= 128 registers)
+tg_bwd_kernel(BwdArgs a) {
+    using P = Plan<NB, KB>;
+    constexpr int N = P::N, Kd = P::Kd, LDY = P::LDY, LDX = P::LDX;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *cA = lds;                        // [5][Kd]: mean, invstd, scale = gamma invstd, m1 = sum(g) / R, m2 = sum(g xhat) / R
+    float *cP = cA + 5 * Kd;                // [4][N]: mean, invstd, gamma, beta of layer i-1
+    float *dYs = cP + 4 * N;                // [BM][LDY]
+    float *Xs = dYs + BM * LDY;             // [BM][LDX]  xhat_{i-1}
+    float *Gs = Xs + BM * LDX;              // [KS_D][BM][LDX]
+    float *Ws = Gs + P::KS_D * BM * LDX;    // [Kd][N] (WLDS)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+#ifdef PN2_TGB_PROFILE
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TGB_T(t_start);
+
+    {
+        const float inv_r = (float)(1.0 / (double)a.R);
+        for (int c = tid; c < Kd; c += kT) {
+            double sa = 0.0, sb = 0.0;
+            for (int r = 0; r < kBnRep; ++r) {
+                sa += a.sums_bwd[(size_t)r * 2 * Kd + c];
+                sb += a.sums_bwd[(size_t)r * 2 * Kd + Kd + c];
+            }
+            const float is = a.invstd[c];
+            cA[c] = a.mean[c]; cA[Kd + c] = is; cA[2 * Kd + c] = a.gamma[c] * is;
+            cA[3 * Kd + c] = (float)sa * inv_r; cA[4 * Kd + c] = (float)sb * inv_r;
+        }
+        for (int c = tid; c < N; c += kT) {
+            cP[c] = a.mean_p[c]; cP[N + c] = a.invstd_p[c]; cP[2 * N + c] = a.gamma_p[c]; cP[3 * N + c] = a.beta_p[c];
+        }
+        if (blockIdx.x == 0)
+            for (int e = tid; e < Kd * N; e += kT) a.dW[e] = 0.f;
+        if constexpr (P::WLDS)
+            for (int e = tid; e < Kd * N / 4; e += kT) {
+                const int kd = e / (N / 4), q = e % (N / 4);
+                *reinterpret_cast<float4 *>(Ws + kd * N + 4 * q) = *reinterpret_cast<const float4 *>(a.W + (size_t)kd * a.ldw + 4 * q);
+            }
+    }
+    __syncthreads();
+
+    const long T = (a.R + BM - 1) / BM;
+    // dY operands: a wave fetches 8 rows x 8 float4 (128 contiguous bytes per row) per step; KB steps cover its 8 rows
+    const int arow = 8 * wave + (lane >> 3), aq = lane & 7;
+    // Yp operands and the epilogue: thread = (column quad cq, row group rg), rows rg + RG i
+    const int cq = tid % P::QN, rg = tid / P::QN;
+    float4 pg[KB], py[KB], ph[NB];
+    auto prefetch = [&](long tile) {
+        long row = tile * BM + arow;
+        row = row < a.R ? row : a.R - 1;  // unconditional loads; the commit zeroes what lies beyond the problem
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            pg[i] = *reinterpret_cast<const float4 *>(a.G + row * a.ldg + 4 * (8 * i + aq));
+            py[i] = *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + 4 * (8 * i + aq));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            long r = tile * BM + rg + P::RG * i;
+            r = r < a.R ? r : a.R - 1;
+            ph[i] = *reinterpret_cast<const float4 *>(a.Yp + r * a.ldyp + 4 * cq);
+        }
+    };
+    // this thread's four channels of layer i-1 (the same for every tile)
+    const float4 pm = *reinterpret_cast<const float4 *>(cP + 4 * cq), pis = *reinterpret_cast<const float4 *>(cP + N + 4 * cq);
+    const float4 pga = *reinterpret_cast<const float4 *>(cP + 2 * N + 4 * cq), pbe = *reinterpret_cast<const float4 *>(cP + 3 * N + 4 * cq);
+    // xhat_{i-1} of this thread's elements: built by the commit, used again by the epilogue of the same tile (kept in registers
+    // where there is room, re-read from LDS by the 128-channel kernels)
+    constexpr bool kKeepX = NB < 4;
+    float4 xh[kKeepX ? NB : 1];
+    auto commit = [&](long tile) {
+        const bool v = tile * BM + arow < a.R;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const int c = 4 * (8 * i + aq);
+            const float4 mean = *reinterpret_cast<const float4 *>(cA + c), is = *reinterpret_cast<const float4 *>(cA + Kd + c);
+            const float4 sc = *reinterpret_cast<const float4 *>(cA + 2 * Kd + c), m1 = *reinterpret_cast<const float4 *>(cA + 3 * Kd + c);
+            const float4 m2 = *reinterpret_cast<const float4 *>(cA + 4 * Kd + c);
+            float *dst = dYs + arow * LDY + c;
+            // same expression as train_gemm.hip's dy_value (GMODE 0)
+            const float d0 = sc.x * (pg[i].x - m1.x - ((py[i].x - mean.x) * is.x) * m2.x);
+            const float d1 = sc.y * (pg[i].y - m1.y - ((py[i].y - mean.y) * is.y) * m2.y);
+            const float d2 = sc.z * (pg[i].z - m1.z - ((py[i].z - mean.z) * is.z) * m2.z);
+            const float d3 = sc.w * (pg[i].w - m1.w - ((py[i].w - mean.w) * is.w) * m2.w);
+            dst[0] = v ? d0 : 0.f; dst[1] = v ? d1 : 0.f; dst[2] = v ? d2 : 0.f; dst[3] = v ? d3 : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r = rg + P::RG * i;
+            const bool vr = tile * BM + r < a.R;
+            float4 x;
+            x.x = vr ? (ph[i].x - pm.x) * pis.x : 0.f;
+            x.y = vr ? (ph[i].y - pm.y) * pis.y : 0.f;
+            x.z = vr ? (ph[i].z - pm.z) * pis.z : 0.f;
+            x.w = vr ? (ph[i].w - pm.w) * pis.w : 0.f;
+            if constexpr (kKeepX) xh[i] = x;
+            *reinterpret_cast<float4 *>(Xs + r * LDX + 4 * cq) = x;
+        }
+    };
+
+    // data gradient: this wave's 32 x 32 block of the tile and its slice of the reduction
+    const int db = wave % P::DBLK, ksd = wave / P::DBLK, rblk = db / NB, nbd = db % NB;
+    constexpr int steps_d = P::steps_d, U = P::U;
+    const float *wp = a.W + (size_t)(kh + 2 * ksd * steps_d) * a.ldw + nbd * 32 + l31;
+    float wv0[P::WLDS ? 1 : U], wv1[P::WLDS ? 1 : U];
+    auto load_w = [&](float *wv, int batch) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wv[u] = wp[(size_t)(2 * (batch * U + u)) * a.ldw];
+    };
+    if constexpr (!P::WLDS) load_w(wv0, 0);
+    // weight gradient: this wave's blocks (sharing the column block nbw) and its slice of the tile's rows
+    const int wb0 = P::WBLK >= 8 ? wave * P::WB : wave % P::WBLK;
+    const int ksw = P::WBLK >= 8 ? 0 : wave / P::WBLK;
+    const int nbw = wb0 / KB, kb0 = wb0 % KB;
+    constexpr int steps_w = (BM / 2) / P::KS_W;
+    const float wga = cP[2 * N + nbw * 32 + l31], wbe = cP[3 * N + nbw * 32 + l31];
+    f32x16 accw[P::WB];
+#pragma unroll
+    for (int j = 0; j < P::WB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cqs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    long tile = blockIdx.x;
+    if (tile < T) prefetch(tile);
+    TGB_T(t_pro);
+    TGB_ADD(0, t_pro, t_start);
+    while (tile < T) {
+        TGB_T(t0);
+        commit(tile);
+        TGB_T(t1);
+        __syncthreads();
+        TGB_T(t2);
+        const long ntile = tile + gridDim.x;
+        if constexpr (P::WLDS) {  // nothing else of this tile touches global memory before the epilogue's stores
+            if (ntile < T) prefetch(ntile);
+        }
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float *ap = dYs + (rblk * 32 + l31) * LDY + kh + 2 * ksd * steps_d;
+            if constexpr (P::WLDS) {
+                const float *bp = Ws + (kh + 2 * ksd * steps_d) * N + nbd * 32 + l31;
+#pragma unroll 8
+                for (int s = 0; s < steps_d; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s * N], acc, 0, 0, 0);
+            } else {
+                // W_i is the same for every tile: the buffer for batch 0 is refilled by the last pair of this tile
+                constexpr int NBATCH = steps_d / U;
+#pragma unroll 1
+                for (int b = 0; b < NBATCH; b += 2) {
+                    load_w(wv1, b + 1);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * (b * U + u)], wv0[u], acc, 0, 0, 0);
+                    load_w(wv0, (b + 2) % NBATCH);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ((b + 1) * U + u)], wv1[u], acc, 0, 0, 0);
+                }
+            }
+            float *gs = Gs + (ksd * BM + rblk * 32 + 4 * kh) * LDX + nbd * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2)) * LDX] = acc[r];
+        }
+        // the next tile's operands travel behind the weight-gradient instructions (which touch LDS only; the data gradient's
+        // own global loads would otherwise queue behind these in the in-order load counter)
+        TGB_T(t3);
+        if constexpr (!P::WLDS) {
+            if (ntile < T) prefetch(ntile);
+        }
+        {
+            const float *xp = Xs + (kh + 2 * ksw * steps_w) * LDX + nbw * 32 + l31;
+            const float *ap = dYs + (kh + 2 * ksw * steps_w) * LDY + kb0 * 32 + l31;
+#pragma unroll 4
+            for (int s = 0; s < steps_w; ++s) {
+                const float bv = relu_nan(xp[2 * s * LDX] * wga + wbe);
+#pragma unroll
+                for (int j = 0; j < P::WB; ++j) {
+                    const float av = ap[2 * s * LDY + 32 * j];
+                    accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);
+                }
+            }
+        }
+        TGB_T(t4);
+        __syncthreads();
+        TGB_T(t5);
+        {
+            const bool full = tile * BM + BM <= a.R;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int r = rg + P::RG * i;
+                float4 g = *reinterpret_cast<const float4 *>(Gs + r * LDX + 4 * cq);
+#pragma unroll
+                for (int k = 1; k < P::KS_D; ++k) {
+                    const float4 t = *reinterpret_cast<const float4 *>(Gs + (k * BM + r) * LDX + 4 * cq);
+                    g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                }
+                float4 x;
+                if constexpr (kKeepX) x = xh[i];
+                else x = *reinterpret_cast<const float4 *>(Xs + r * LDX + 4 * cq);
+                g.x = (x.x * pga.x + pbe.x > 0.f) ? g.x : 0.f;  // [relu(BN(y)) > 0], torch's evaluation order
+                g.y = (x.y * pga.y + pbe.y > 0.f) ? g.y : 0.f;
+                g.z = (x.z * pga.z + pbe.z > 0.f) ? g.z : 0.f;
+                g.w = (x.w * pga.w + pbe.w > 0.f) ? g.w : 0.f;
+                cs[0] += g.x; cs[1] += g.y; cs[2] += g.z; cs[3] += g.w;   // rows beyond R: dY == 0 -> g == 0, xhat == 0
+                cqs[0] += g.x * x.x; cqs[1] += g.y * x.y; cqs[2] += g.z * x.z; cqs[3] += g.w * x.w;
+                const long row = tile * BM + r;
+                if (full || row < a.R) *reinterpret_cast<float4 *>(a.Gp + row * a.ldgp + 4 * cq) = g;
+            }
+        }
+        // no barrier here: the next commit overwrites dYs / Xs, whose readers all passed the barrier above; Gs is rewritten
+        // only after the next commit's barrier, which every thread reaches after its epilogue reads
+        TGB_T(t6);
+        TGB_ADD(1, t1, t0); TGB_ADD(2, t2, t1); TGB_ADD(3, t3, t2); TGB_ADD(4, t4, t3); TGB_ADD(5, t5, t4); TGB_ADD(6, t6, t5);
+        tile = ntile;
+    }
+    TGB_T(t_loop);
+
+    // weight-gradient partial tile of this workgroup (and row slice)
+    {
+        float *out = a.partial + ((size_t)blockIdx.x * P::KS_W + ksw) * (size_t)(Kd * N);
+#pragma unroll
+        for (int j = 0; j < P::WB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kd = (kb0 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[(size_t)kd * N + nbw * 32 + l31] = accw[j][r];
+            }
+    }
+    // BatchNorm-backward sums of layer i-1
+    __syncthreads();
+    float *redS = Gs, *redQ = Gs + P::RG * N;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        redS[rg * N + 4 * cq + e] = cs[e];
+        redQ[rg * N + 4 * cq + e] = cqs[e];
+    }
+    __syncthreads();
+    if (tid < N) {
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < P::RG; ++r) {
+            s += (double)redS[r * N + tid];
+            q += (double)redQ[r * N + tid];
+        }
+        double *dst = a.sums_bwd_p + (size_t)(blockIdx.x % kBnRep) * 2 * N;
+        unsafeAtomicAdd(dst + tid, s);
+        unsafeAtomicAdd(dst + N + tid, q);
+    }
+#ifdef PN2_TGB_PROFILE
+    if (tid == 0 && a.prof) {
+        pacc[7] = clock64() - t_loop;
+        for (int k = 0; k < 8; ++k) a.prof[(size_t)blockIdx.x * 8 + k] = pacc[k];
+    }
+#endif
+}
+
+struct Shape {
+    int nb, kb, ks_w;
+    size_t lds;
+};
+template <int NB, int KB>
+static Shape shape_of() { return Shape{NB, KB, Plan<NB, KB>::KS_W, (size_t)Plan<NB, KB>::lds_floats * sizeof(float)}; }
+
+// the instantiated (C_{i-1} / 32, C_i / 32) pairs
+#define PN2_TGB_SHAPES(X) X(1, 1) X(1, 2) X(1, 4) X(2, 1) X(2, 2) X(2, 4) X(4, 2) X(4, 4) X(4, 6)
+
+static bool find_shape(int c_in, int c_out, Shape &s) {
+    if (c_in % 32 || c_out % 32) return false;
+    const int nb = c_in / 32, kb = c_out / 32;
+#define X(NB_, KB_) if (nb == NB_ && kb == KB_) { s = shape_of<NB_, KB_>(); return true; }
+    PN2_TGB_SHAPES(X)
+#undef X
+    return false;
+}
+
+static int grid_of(long rows, const Shape &s) {
+    const long tiles = (rows + BM - 1) / BM;
+    // persistent workgroups: one per CU where the LDS footprint admits only one, two otherwise
+    const long cap = (long)num_compute_units() * (s.lds * 2 <= 160 * 1024 ? 2 : 1);
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+}  // namespace tgb
+}  // namespace pn2
+
+using namespace pn2;
+using namespace pn2::tgb;
+
+#ifdef PN2_TGB_PROFILE
+static long long *g_prof = nullptr;
+extern "C" void pn2x_tg_bwd_set_profile(long long *p) { g_prof = p; }
+#endif
+
+extern "C" int pn2x_tg_bwd_supported(int c_in, int c_out) {
+    Shape s;
+    return find_shape(c_in, c_out, s) ? 1 : 0;
+}
+
+extern "C" int pn2x_tg_bwd_partials(long rows, int c_out, int c_in) {
+    Shape s;
+    if (rows < 1 || !find_shape(c_in, c_out, s)) return -1;
+    return grid_of(rows, s) * s.ks_w;
+}
+
+extern "C" int pn2x_tg_bwd(long rows, int n, int k, const float *g, int ldg, const float *yi, int ldyi, const float *mean_i,
+                           const float *invstd_i, const float *gamma_i, const double *sums_bwd_i, const float *w, int ldw,
+                           const float *yp, int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p,
+                           const float *beta_p, float *gp, int ldgp, double *sums_bwd_p, float *partial, long partial_floats,
+                           float *dw, void *stream) {
+    Shape s;
+    if (rows < 1 || rows > 0x7fffffffL || !find_shape(k, n, s)) return PN2_EINVAL;
+    if (ldg < n || ldg % 4 || ldyi < n || ldyi % 4 || ldw < k || ldyp < k || ldyp % 4 || ldgp < k || ldgp % 4) return PN2_EINVAL;
+    if (!g || !yi || !mean_i || !invstd_i || !gamma_i || !sums_bwd_i || !w || !yp || !mean_p || !invstd_p || !gamma_p || !beta_p ||
+        !gp || !sums_bwd_p || !partial || !dw)
+        return PN2_ENULL;
+    if (((uintptr_t)g | (uintptr_t)yi | (uintptr_t)yp | (uintptr_t)gp) % 16) return PN2_EINVAL;
+    const int grid = grid_of(rows, s);
+    if (partial_floats < (long)grid * s.ks_w * n * k) return PN2_ESCRATCH;
+    BwdArgs a{rows, g, ldg, yi, ldyi, mean_i, invstd_i, gamma_i, sums_bwd_i, w, ldw, yp, ldyp, mean_p, invstd_p, gamma_p, beta_p,
+              gp, ldgp, sums_bwd_p, partial, dw
+#ifdef PN2_TGB_PROFILE
+              , g_prof
+#endif
+    };
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = k / 32, kb = n / 32;
+#define X(NB_, KB_)                                                                                                   \
+    if (nb == NB_ && kb == KB_) {                                                                                     \
+        static PerDeviceOnce once;                                                                                    \
+        if (once.first_use())                                                                                         \
+            (void)hipFuncSetAttribute((const void *)tg_bwd_kernel<NB_, KB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)s.lds);                                                                    \
+        hipLaunchKernelGGL((tg_bwd_kernel<NB_, KB_>), dim3(grid), dim3(kT), s.lds, st, a);                            \
+    }
+    PN2_TGB_SHAPES(X)
+#undef X
+    return check_launch();
+}

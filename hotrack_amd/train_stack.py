@@ -19,6 +19,7 @@ GPU tensors only (no CPU path).
 from __future__ import annotations
 
 import ctypes
+import os as _os
 
 import torch
 
@@ -44,11 +45,18 @@ _lib.pn2x_tg_reduce_multi.argtypes = [_ci, ctypes.POINTER(_vp), ctypes.POINTER(_
                                       ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                       ctypes.POINTER(_vp), _vp]
 _lib.pn2x_tg_reduce_multi.restype = _ci
+_lib.pn2x_tg_bwd_supported.argtypes = [_ci, _ci]
+_lib.pn2x_tg_bwd_supported.restype = _ci
+_lib.pn2x_tg_bwd_partials.argtypes = [_cl, _ci, _ci]
+_lib.pn2x_tg_bwd_partials.restype = _ci
+_lib.pn2x_tg_bwd.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci,
+                             _vp, _vp, _cl, _vp, _vp]
+_lib.pn2x_tg_bwd.restype = _ci
+FUSED_BWD = _os.environ.get("HOTRACK_STACK_FUSED_BWD", "1") != "0"  # data + weight gradient of a layer in one kernel (train_bwd.hip)
 _lib.pn2x_bn_bwd_reduce.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
 _lib.pn2x_bn_bwd_reduce.restype = _ci
 _lib.pn2x_bn_bwd_reduce_g.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp]
 _lib.pn2x_bn_bwd_reduce_g.restype = _ci
-import os as _os
 ROUTE_DENSE = _os.environ.get("HOTRACK_STACK_ROUTE_DENSE", "1") != "0"  # max-routed top gradient materialised once by the reduction
 # The weight gradients are not read before the optimiser: the backward writes only partial tiles and ONE launch at the end of
 # the pass (autograd's final callbacks) sums the tiles of every layer of every stack.  Off (HOTRACK_STACK_DEFER_REDUCE=0, or
@@ -70,6 +78,14 @@ def _defer(item):
 def _flush_reductions():
     items, _pending[:] = list(_pending), []
     _pending_task[0] = None
+    _reduce_items(items)
+
+
+def _pending_now(item):
+    _reduce_items([item])
+
+
+def _reduce_items(items):
     if not items:
         return
     n = len(items)
@@ -215,10 +231,29 @@ class _Stack(torch.autograd.Function):
                 yi, yp, svi, svp = ys[i], ys[i - 1], saved[i], saved[i - 1]
                 dy_args = (gmode, g.data_ptr(), g.stride(0), _p(arg) if gmode == 2 else None, K if gmode == 2 else 1, yi.data_ptr(),
                            yi.stride(0), svi[0].data_ptr(), svi[1].data_ptr(), gam(i).data_ptr(), bet(i).data_ptr(), sums[i].data_ptr())
-                pf = int(_lib.pn2x_tg_wgrad_partial_floats(R, N, Kc))
-                partial = torch.empty(pf, dtype=_f32, device=dev)
                 dw = torch.empty((N, Kc), dtype=_f32, device=dev)
                 dpar = torch.empty((3, N), dtype=_f32, device=dev)
+                gp = torch.empty((R, Kc), dtype=_f32, device=dev)
+                if FUSED_BWD and gmode == 0 and _lib.pn2x_tg_bwd_supported(Kc, N):
+                    np_ = int(_lib.pn2x_tg_bwd_partials(R, N, Kc))
+                    partial = torch.empty(np_ * N * Kc, dtype=_f32, device=dev)
+                    _native._check(_lib.pn2x_tg_bwd(R, N, Kc, g.data_ptr(), g.stride(0), yi.data_ptr(), yi.stride(0), svi[0].data_ptr(),
+                                                    svi[1].data_ptr(), gam(i).data_ptr(), sums[i].data_ptr(), wc.data_ptr(), wc.stride(0),
+                                                    yp.data_ptr(), yp.stride(0), svp[0].data_ptr(), svp[1].data_ptr(),
+                                                    gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), gp.data_ptr(), Kc, sums[i - 1].data_ptr(),
+                                                    partial.data_ptr(), partial.numel(), dw.data_ptr(), st), "tg_bwd")
+                    item = (partial, np_, dw, sums[i], dpar, st)
+                    if defer:
+                        _defer(item)
+                    else:
+                        _pending_now(item)
+                    grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = dw.view(w_shape), dpar[0], dpar[1]
+                    if ctx.has_bias[i]:
+                        grads[4 * i + 3] = dpar[2]
+                    g, gmode = gp, 0
+                    continue
+                pf = int(_lib.pn2x_tg_wgrad_partial_floats(R, N, Kc))
+                partial = torch.empty(pf, dtype=_f32, device=dev)
                 np_ = _ci(0)
                 _native._check(_lib.pn2x_tg_wgrad2(R, N, Kc, *dy_args, yp.data_ptr(), yp.stride(0), svp[0].data_ptr(), svp[1].data_ptr(),
                                                    gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), partial.data_ptr(), pf, dw.data_ptr(),
@@ -230,7 +265,6 @@ class _Stack(torch.autograd.Function):
                 grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = dw, dpar[0], dpar[1]
                 if ctx.has_bias[i]:
                     grads[4 * i + 3] = dpar[2]  # zeros: the bias of a convolution in front of a BatchNorm has no gradient
-                gp = torch.empty((R, Kc), dtype=_f32, device=dev)
                 _native._check(_lib.pn2x_tg_dgrad(R, N, Kc, *dy_args, wc.data_ptr(), wc.stride(0), yp.data_ptr(), yp.stride(0),
                                                   svp[0].data_ptr(), svp[1].data_ptr(), gam(i - 1).data_ptr(), bet(i - 1).data_ptr(),
                                                   gp.data_ptr(), Kc, sums[i - 1].data_ptr(), st), "tg_dgrad")

@@ -458,6 +458,17 @@ int pn2x_tg_wgrad2(long rows, int n, int k, int gmode, const float *g, int ldg, 
 int pn2x_tg_reduce_multi(int count, const float *const *partial, const int *n_partials, const int *numel, float *const *dw,
                          const double *const *sums_bwd, const int *channels, float *const *dgamma, float *const *dbeta,
                          float *const *dbias, void *stream);
+/* The whole backward of fused layer i in one kernel (csrc/train_bwd.hip): g_{i-1} (gp, with the ReLU mask and the
+ * BatchNorm-backward sums of layer i-1, as pn2x_tg_dgrad) AND the weight-gradient partial tiles (as pn2x_tg_wgrad2 with
+ * n_partials) from one pass over g_i (pre-masked: gmode 0), Y_i and Y_{i-1}.  n = channels of layer i, k = channels of layer
+ * i-1; w (n x k).  pn2x_tg_bwd_supported(k, n): k in {32, 64, 128} and the instantiated n; pn2x_tg_bwd_partials = the number
+ * of (n x k) partial tiles written (partial_floats >= that * n * k), to be summed by pn2x_tg_reduce_multi.  dw is zeroed. */
+int pn2x_tg_bwd_supported(int c_in, int c_out);
+int pn2x_tg_bwd_partials(long rows, int c_out, int c_in);
+int pn2x_tg_bwd(long rows, int n, int k, const float *g, int ldg, const float *yi, int ldyi, const float *mean_i,
+                const float *invstd_i, const float *gamma_i, const double *sums_bwd_i, const float *w, int ldw, const float *yp,
+                int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p, float *gp, int ldgp,
+                double *sums_bwd_p, float *partial, long partial_floats, float *dw, void *stream);
 
 #ifdef __cplusplus
 }

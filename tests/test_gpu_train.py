@@ -379,6 +379,53 @@ def test_mlp_stack_second_backward_and_stale_workspace():
     assert out_b.shape == out.shape
 
 
+@pytest.mark.parametrize("R,widths,K", [
+    (16 * 4403, [64, 64, 128], 16),      # 1101 row tiles (the last one ragged) on <= 512 persistent workgroups
+    (32 * 1200, [32, 32, 64], 32),
+    (16 * 2000 + 16, [128, 128, 192], 16),
+    (8 * 777, [128, 128, 128, 64, 32], 8),
+])
+def test_mlp_stack_one_kernel_layer_backward_equals_two_kernel_backward(R, widths, K):
+    """csrc/train_bwd.hip (data + weight gradient of a layer from one pass) vs the tg_dgrad / tg_wgrad pair on the same
+    forward: same formulas, different summation orders."""
+    from hotrack_amd import train_stack
+    from hotrack_amd.train_ops import Workspace
+    g = torch.Generator(device="cuda").manual_seed(R)
+    convs = [torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])]
+    bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in widths]
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.copy_(1 + 0.3 * torch.randn(bn.weight.shape, device="cuda", generator=g))
+            bn.bias.copy_(0.2 * torch.randn(bn.bias.shape, device="cuda", generator=g))
+    params = [p for m in convs + bns for p in m.parameters()]
+    y1 = torch.randn(R, widths[0], device="cuda", generator=g) * 1.3 + 0.2
+    go = torch.randn(R // K, widths[-1], device="cuda", generator=g)
+    ws = Workspace("cuda")
+    for a, b in zip(widths[:-1], widths[1:]):
+        assert train_stack._lib.pn2x_tg_bwd_supported(a, b)
+
+    def run(fused):
+        old = train_stack.FUSED_BWD
+        train_stack.FUSED_BWD = fused
+        try:
+            for p in params:
+                p.grad = None
+            ws.reset()
+            y = y1.clone().requires_grad_(True)
+            layers = [train_stack.Layer(None, bns[0])] + [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(convs, bns[1:])]
+            train_stack.mlp_stack(y, layers, ws, max_over=K).backward(go)
+            return [y.grad.clone()] + [None if p.grad is None else p.grad.clone() for p in params]
+        finally:
+            train_stack.FUSED_BWD = old
+
+    one, two = run(True), run(False)
+    for a, b in zip(one, two):
+        assert (a is None) == (b is None)
+        if a is not None:
+            scale = max(1.0, float(b.abs().max()))
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * scale)
+
+
 def test_mlp_stack_deferred_weight_gradient_sums():
     """The weight-gradient reductions of all stacks run as ONE launch at the end of the autograd pass (train_stack._defer):
     same gradients as the immediate reductions; more layers in a pass than one kernel-argument pack holds; a second pass
