@@ -19,8 +19,9 @@
 // 32 x 32 (C_{i-1} = 32 NB); with fewer than 8 blocks the reduction over C_i is split across wave groups and summed in the
 // epilogue.  The C_i x C_{i-1} weight gradient is NB KB blocks (C_i = 32 KB): a wave owns NB KB / 8 of them (sharing the H
 // operand), or, with fewer than 8 blocks, a slice of the tile's 64 rows (one partial tile per slice).
-// Only the dense pre-masked gradient source (GMODE 0 of train_gemm.hip): the top layer's gradient is materialised by
-// bn_bwd_reduce_g, every lower one by this kernel.
+// Gradient sources: GMODE 0, the dense pre-masked g_i this kernel itself writes for the layer above; GMODE 2, the top layer of
+// a max-pooled stack, routed on load: g_i[row] = dout[row / K] where arg[row / K] == row % K, ReLU-masked from Y_i (dout / arg
+// are K times smaller than the activation and stay in L2: the layer reads Y_i and Y_{i-1} only).
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
@@ -35,9 +36,10 @@ __device__ __forceinline__ float relu_nan(float h) { return !(h <= 0.f) ? h : 0.
 
 struct BwdArgs {
     long R;
-    const float *G; int ldg;    // g_i = dH_i . [H_i > 0]   (R x C_i)
+    const float *G; int ldg;    // GMODE 0: g_i = dH_i . [H_i > 0] (R x C_i); GMODE 2: d(max over Kmax rows) (R / Kmax x C_i)
+    const int *arg; int Kmax, kshift;  // GMODE 2: arg-max row within the group (same stride as G); kshift >= 0: Kmax = 1 << kshift
     const float *Y; int ldy;    // pre-activations of layer i
-    const float *mean, *invstd, *gamma;
+    const float *mean, *invstd, *gamma, *beta;
     const double *sums_bwd;     // layer i: kBnRep copies of [sum(g) | sum(g xhat)]
     const float *W; int ldw;    // (C_i x C_{i-1})
     const float *Yp; int ldyp;  // pre-activations of layer i-1 (R x C_{i-1})
@@ -59,7 +61,7 @@ struct BwdArgs {
 #define TGB_ADD(slot, t1, t0)
 #endif
 
-template <int NB, int KB>
+template <int NB, int KB, int GMODE = 0>
 struct Plan {
     static constexpr int N = 32 * NB, Kd = 32 * KB;
     static constexpr int LDY = Kd + 1;   // odd: the 32 rows a data-gradient A read touches fall on 32 banks
@@ -75,21 +77,21 @@ struct Plan {
     static constexpr bool WLDS = NB <= 2;
     static constexpr int steps_d = (Kd / 2) / KS_D;      // matrix instructions of a wave's data-gradient block
     static constexpr int U = steps_d >= 32 ? 16 : steps_d / 2;  // W values per register buffer
-    static constexpr int lds_floats = 5 * Kd + 4 * N + BM * LDY + BM * LDX + KS_D * BM * LDX + (WLDS ? Kd * N : 0);
+    static constexpr int lds_floats = 7 * Kd + 4 * N + BM * LDY + BM * LDX + KS_D * BM * LDX + (WLDS ? Kd * N : 0);
     static_assert(WLDS || (steps_d % (2 * U) == 0 && U >= 1), "data-gradient batches come in pairs");
     static_assert(NB == 1 || NB == 2 || NB == 4, "C_{i-1} in {32, 64, 128}");
     static_assert(WBLK < 8 || WBLK % 8 == 0, "weight-gradient blocks must split evenly over 8 waves");
     static_assert(2 * RG * N <= KS_D * BM * LDX, "the final column-sum staging reuses the data-gradient staging");
 };
 
-template <int NB, int KB>
+template <int NB, int KB, int GMODE>
 __global__ void __launch_bounds__(kT, (NB == 1 && KB <= 2 ? 4 : 2))  // sa1's layers: two workgroups per CU (<= 128 registers)
 tg_bwd_kernel(BwdArgs a) {
-    using P = Plan<NB, KB>;
+    using P = Plan<NB, KB, GMODE>;
     constexpr int N = P::N, Kd = P::Kd, LDY = P::LDY, LDX = P::LDX;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *cA = lds;                        // [5][Kd]: mean, invstd, scale = gamma invstd, m1 = sum(g) / R, m2 = sum(g xhat) / R
-    float *cP = cA + 5 * Kd;                // [4][N]: mean, invstd, gamma, beta of layer i-1
+    float *cA = lds;                        // [7][Kd]: mean, invstd, scale = gamma invstd, m1 = sum(g) / R, m2 = sum(g xhat) / R, gamma, beta
+    float *cP = cA + 7 * Kd;                // [4][N]: mean, invstd, gamma, beta of layer i-1
     float *dYs = cP + 4 * N;                // [BM][LDY]
     float *Xs = dYs + BM * LDY;             // [BM][LDX]  xhat_{i-1}
     float *Gs = Xs + BM * LDX;              // [KS_D][BM][LDX]
@@ -111,6 +113,7 @@ tg_bwd_kernel(BwdArgs a) {
             const float is = a.invstd[c];
             cA[c] = a.mean[c]; cA[Kd + c] = is; cA[2 * Kd + c] = a.gamma[c] * is;
             cA[3 * Kd + c] = (float)sa * inv_r; cA[4 * Kd + c] = (float)sb * inv_r;
+            if constexpr (GMODE == 2) { cA[5 * Kd + c] = a.gamma[c]; cA[6 * Kd + c] = a.beta[c]; }
         }
         for (int c = tid; c < N; c += kT) {
             cP[c] = a.mean_p[c]; cP[N + c] = a.invstd_p[c]; cP[2 * N + c] = a.gamma_p[c]; cP[3 * N + c] = a.beta_p[c];
@@ -131,14 +134,26 @@ tg_bwd_kernel(BwdArgs a) {
     // Yp operands and the epilogue: thread = (column quad cq, row group rg), rows rg + RG i
     const int cq = tid % P::QN, rg = tid / P::QN;
     float4 pg[KB], py[KB], ph[NB];
+    int4 par[GMODE == 2 ? KB : 1];
+    // routed source on the 128-channel kernels: dout / arg are fetched by the commit itself (L2 hits: one row serves Kmax
+    // rows of the tile) instead of travelling a tile ahead in 48 more registers
+    constexpr bool kLateG = GMODE == 2 && NB == 4;
+    auto fetch_g = [&](long tile) {
+        long row = tile * BM + arow;
+        row = row < a.R ? row : a.R - 1;
+        const long grow = GMODE == 2 ? (a.kshift >= 0 ? ((int)row >> a.kshift) : ((int)row / a.Kmax)) : row;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            pg[i] = *reinterpret_cast<const float4 *>(a.G + grow * a.ldg + 4 * (8 * i + aq));
+            if constexpr (GMODE == 2) par[i] = *reinterpret_cast<const int4 *>(a.arg + grow * a.ldg + 4 * (8 * i + aq));
+        }
+    };
     auto prefetch = [&](long tile) {
         long row = tile * BM + arow;
         row = row < a.R ? row : a.R - 1;  // unconditional loads; the commit zeroes what lies beyond the problem
+        if constexpr (!kLateG) fetch_g(tile);
 #pragma unroll
-        for (int i = 0; i < KB; ++i) {
-            pg[i] = *reinterpret_cast<const float4 *>(a.G + row * a.ldg + 4 * (8 * i + aq));
-            py[i] = *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + 4 * (8 * i + aq));
-        }
+        for (int i = 0; i < KB; ++i) py[i] = *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + 4 * (8 * i + aq));
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             long r = tile * BM + rg + P::RG * i;
@@ -146,15 +161,21 @@ tg_bwd_kernel(BwdArgs a) {
             ph[i] = *reinterpret_cast<const float4 *>(a.Yp + r * a.ldyp + 4 * cq);
         }
     };
-    // this thread's four channels of layer i-1 (the same for every tile)
-    const float4 pm = *reinterpret_cast<const float4 *>(cP + 4 * cq), pis = *reinterpret_cast<const float4 *>(cP + N + 4 * cq);
-    const float4 pga = *reinterpret_cast<const float4 *>(cP + 2 * N + 4 * cq), pbe = *reinterpret_cast<const float4 *>(cP + 3 * N + 4 * cq);
+    // (this thread's four channels of layer i-1 are the same for every tile; their constants are re-read from LDS where they
+    // are used -- four ds_read_b128 per tile against sixteen registers held across both matrix phases)
     // xhat_{i-1} of this thread's elements: built by the commit, used again by the epilogue of the same tile (kept in registers
     // where there is room, re-read from LDS by the 128-channel kernels)
-    constexpr bool kKeepX = NB < 4;
+    constexpr bool kKeepX = NB < 4 && !(NB == 1 && GMODE == 2);
     float4 xh[kKeepX ? NB : 1];
     auto commit = [&](long tile) {
         const bool v = tile * BM + arow < a.R;
+        if constexpr (kLateG) fetch_g(tile);
+        int kk = 0;
+        if constexpr (GMODE == 2) {
+            const long row = tile * BM + arow;
+            const int rr = (int)(row < a.R ? row : a.R - 1);
+            kk = a.kshift >= 0 ? (rr & (a.Kmax - 1)) : (rr % a.Kmax);
+        }
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
             const int c = 4 * (8 * i + aq);
@@ -162,13 +183,24 @@ tg_bwd_kernel(BwdArgs a) {
             const float4 sc = *reinterpret_cast<const float4 *>(cA + 2 * Kd + c), m1 = *reinterpret_cast<const float4 *>(cA + 3 * Kd + c);
             const float4 m2 = *reinterpret_cast<const float4 *>(cA + 4 * Kd + c);
             float *dst = dYs + arow * LDY + c;
-            // same expression as train_gemm.hip's dy_value (GMODE 0)
-            const float d0 = sc.x * (pg[i].x - m1.x - ((py[i].x - mean.x) * is.x) * m2.x);
-            const float d1 = sc.y * (pg[i].y - m1.y - ((py[i].y - mean.y) * is.y) * m2.y);
-            const float d2 = sc.z * (pg[i].z - m1.z - ((py[i].z - mean.z) * is.z) * m2.z);
-            const float d3 = sc.w * (pg[i].w - m1.w - ((py[i].w - mean.w) * is.w) * m2.w);
+            // same expressions as train_gemm.hip's dy_value
+            const float x0 = (py[i].x - mean.x) * is.x, x1 = (py[i].y - mean.y) * is.y;
+            const float x2 = (py[i].z - mean.z) * is.z, x3 = (py[i].w - mean.w) * is.w;
+            float g0 = pg[i].x, g1 = pg[i].y, g2 = pg[i].z, g3 = pg[i].w;
+            if constexpr (GMODE == 2) {
+                const float4 ga = *reinterpret_cast<const float4 *>(cA + 5 * Kd + c), be = *reinterpret_cast<const float4 *>(cA + 6 * Kd + c);
+                g0 = (par[i].x == kk && x0 * ga.x + be.x > 0.f) ? g0 : 0.f;  // routed to the arg-max row, [relu(BN(y)) > 0]
+                g1 = (par[i].y == kk && x1 * ga.y + be.y > 0.f) ? g1 : 0.f;
+                g2 = (par[i].z == kk && x2 * ga.z + be.z > 0.f) ? g2 : 0.f;
+                g3 = (par[i].w == kk && x3 * ga.w + be.w > 0.f) ? g3 : 0.f;
+            }
+            const float d0 = sc.x * (g0 - m1.x - x0 * m2.x);
+            const float d1 = sc.y * (g1 - m1.y - x1 * m2.y);
+            const float d2 = sc.z * (g2 - m1.z - x2 * m2.z);
+            const float d3 = sc.w * (g3 - m1.w - x3 * m2.w);
             dst[0] = v ? d0 : 0.f; dst[1] = v ? d1 : 0.f; dst[2] = v ? d2 : 0.f; dst[3] = v ? d3 : 0.f;
         }
+        const float4 pm = *reinterpret_cast<const float4 *>(cP + 4 * cq), pis = *reinterpret_cast<const float4 *>(cP + N + 4 * cq);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int r = rg + P::RG * i;
@@ -271,6 +303,7 @@ tg_bwd_kernel(BwdArgs a) {
         TGB_T(t5);
         {
             const bool full = tile * BM + BM <= a.R;
+            const float4 pga = *reinterpret_cast<const float4 *>(cP + 2 * N + 4 * cq), pbe = *reinterpret_cast<const float4 *>(cP + 3 * N + 4 * cq);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int r = rg + P::RG * i;
@@ -346,6 +379,13 @@ struct Shape {
 template <int NB, int KB>
 static Shape shape_of() { return Shape{NB, KB, Plan<NB, KB>::KS_W, (size_t)Plan<NB, KB>::lds_floats * sizeof(float)}; }
 
+static int kshift_of(int k) {
+    if (k < 1 || (k & (k - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < k) ++s;
+    return s;
+}
+
 // the instantiated (C_{i-1} / 32, C_i / 32) pairs
 #define PN2_TGB_SHAPES(X) X(1, 1) X(1, 2) X(1, 4) X(2, 1) X(2, 2) X(2, 4) X(4, 2) X(4, 4) X(4, 6)
 
@@ -387,13 +427,17 @@ extern "C" int pn2x_tg_bwd_partials(long rows, int c_out, int c_in) {
     return grid_of(rows, s) * s.ks_w;
 }
 
-extern "C" int pn2x_tg_bwd(long rows, int n, int k, const float *g, int ldg, const float *yi, int ldyi, const float *mean_i,
-                           const float *invstd_i, const float *gamma_i, const double *sums_bwd_i, const float *w, int ldw,
+extern "C" int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi,
+                           int ldyi, const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i,
+                           const double *sums_bwd_i, const float *w, int ldw,
                            const float *yp, int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p,
                            const float *beta_p, float *gp, int ldgp, double *sums_bwd_p, float *partial, long partial_floats,
                            float *dw, void *stream) {
     Shape s;
-    if (rows < 1 || rows > 0x7fffffffL || !find_shape(k, n, s)) return PN2_EINVAL;
+    if (rows < 1 || rows > 0x7fffffffL || !find_shape(k, n, s) || (gmode != 0 && gmode != 2)) return PN2_EINVAL;
+    if (gmode == 2 && (kmax < 1 || rows % kmax)) return PN2_EINVAL;
+    if (gmode == 2 && (!arg || !beta_i)) return PN2_ENULL;
+    if ((uintptr_t)arg % 16) return PN2_EINVAL;
     if (ldg < n || ldg % 4 || ldyi < n || ldyi % 4 || ldw < k || ldyp < k || ldyp % 4 || ldgp < k || ldgp % 4) return PN2_EINVAL;
     if (!g || !yi || !mean_i || !invstd_i || !gamma_i || !sums_bwd_i || !w || !yp || !mean_p || !invstd_p || !gamma_p || !beta_p ||
         !gp || !sums_bwd_p || !partial || !dw)
@@ -401,7 +445,7 @@ extern "C" int pn2x_tg_bwd(long rows, int n, int k, const float *g, int ldg, con
     if (((uintptr_t)g | (uintptr_t)yi | (uintptr_t)yp | (uintptr_t)gp) % 16) return PN2_EINVAL;
     const int grid = grid_of(rows, s);
     if (partial_floats < (long)grid * s.ks_w * n * k) return PN2_ESCRATCH;
-    BwdArgs a{rows, g, ldg, yi, ldyi, mean_i, invstd_i, gamma_i, sums_bwd_i, w, ldw, yp, ldyp, mean_p, invstd_p, gamma_p, beta_p,
+    BwdArgs a{rows, g, ldg, arg, kmax, kshift_of(kmax), yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, w, ldw, yp, ldyp, mean_p, invstd_p, gamma_p, beta_p,
               gp, ldgp, sums_bwd_p, partial, dw
 #ifdef PN2_TGB_PROFILE
               , g_prof
@@ -409,15 +453,21 @@ extern "C" int pn2x_tg_bwd(long rows, int n, int k, const float *g, int ldg, con
     };
     hipStream_t st = (hipStream_t)stream;
     const int nb = k / 32, kb = n / 32;
-#define X(NB_, KB_)                                                                                                   \
-    if (nb == NB_ && kb == KB_) {                                                                                     \
+#define PN2_TGB_LAUNCH(NB_, KB_, GM_)                                                                                  \
+    do {                                                                                                              \
         static PerDeviceOnce once;                                                                                    \
         if (once.first_use())                                                                                         \
-            (void)hipFuncSetAttribute((const void *)tg_bwd_kernel<NB_, KB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void *)tg_bwd_kernel<NB_, KB_, GM_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)s.lds);                                                                    \
-        hipLaunchKernelGGL((tg_bwd_kernel<NB_, KB_>), dim3(grid), dim3(kT), s.lds, st, a);                            \
+        hipLaunchKernelGGL((tg_bwd_kernel<NB_, KB_, GM_>), dim3(grid), dim3(kT), s.lds, st, a);                       \
+    } while (0)
+#define X(NB_, KB_)                                                                                                   \
+    if (nb == NB_ && kb == KB_) {                                                                                     \
+        if (gmode == 0) PN2_TGB_LAUNCH(NB_, KB_, 0);                                                                  \
+        else PN2_TGB_LAUNCH(NB_, KB_, 2);                                                                             \
     }
     PN2_TGB_SHAPES(X)
 #undef X
+#undef PN2_TGB_LAUNCH
     return check_launch();
 }

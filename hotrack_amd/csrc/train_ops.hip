@@ -585,6 +585,60 @@ extern "C" int pn2x_bn_bwd_reduce_g(long rows, int c, const float *dh, int ldd, 
     return check_launch();
 }
 
+namespace pn2 {
+// The BatchNorm-backward sums of a max-pooled top layer from the arg-max rows ALONE: the routed gradient is non-zero in one row
+// per (group, channel), so sum(g) and sum(g xhat) need groups x C gathered pre-activations, not the rows x C tensor.
+__global__ void __launch_bounds__(kTT)
+bn_bwd_reduce_routed_kernel(long groups, int K, int C, const float *__restrict__ dout, int ldd, const int *__restrict__ arg,
+                            const float *__restrict__ y, int ldy, const float *__restrict__ mean, const float *__restrict__ invstd,
+                            const float *__restrict__ gamma, const float *__restrict__ beta, long groups_per_block,
+                            double *__restrict__ sums) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const long g0 = (long)blockIdx.x * groups_per_block;
+    const long g1 = (g0 + groups_per_block) < groups ? (g0 + groups_per_block) : groups;
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+        for (long g = g0 + gl; g < g1; g += 4) {
+            const int a = arg[g * ldd + c];
+            const float xhat = (y[(g * K + a) * (long)ldy + c] - m) * is;
+            const float gg = (xhat * ga + be > 0.f) ? dout[g * ldd + c] : 0.f;  // [relu(BN(y)) > 0], torch's evaluation order
+            s += gg;
+            q += gg * xhat;
+        }
+    }
+    red[0][gl][cl] = s;
+    red[1][gl][cl] = q;
+    __syncthreads();
+    if (gl == 0 && c < C) {
+        const double sd = (double)red[0][0][cl] + (double)red[0][1][cl] + (double)red[0][2][cl] + (double)red[0][3][cl];
+        const double qd = (double)red[1][0][cl] + (double)red[1][1][cl] + (double)red[1][2][cl] + (double)red[1][3][cl];
+        double *dst = sums + (size_t)(blockIdx.x % kBnRep) * 2 * C;
+        unsafeAtomicAdd(dst + c, sd);
+        unsafeAtomicAdd(dst + C + c, qd);
+    }
+}
+}  // namespace pn2
+
+extern "C" int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, const float *y, int ldy,
+                                         const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums,
+                                         void *stream) {
+    using namespace pn2;
+    if (groups < 1 || k < 1 || bad_c(c) || ldy < c || ldd < c || groups * k > 0x7fffffffL) return PN2_EINVAL;
+    if (!dout || !arg || !y || !mean || !invstd || !gamma || !beta || !sums) return PN2_ENULL;
+    const int ny = (c + 63) / 64;
+    long blocks = (4L * num_compute_units() + ny - 1) / ny;
+    long gpb = (groups + blocks - 1) / blocks;
+    gpb = (gpb + 3) / 4 * 4;
+    if (gpb < 16) gpb = 16;
+    blocks = (groups + gpb - 1) / gpb;
+    hipLaunchKernelGGL(bn_bwd_reduce_routed_kernel, dim3((unsigned)blocks, ny), dim3(kTT), 0, (hipStream_t)stream, groups, k, c, dout, ldd,
+                       arg, y, ldy, mean, invstd, gamma, beta, gpb, sums);
+    return check_launch();
+}
+
 extern "C" int pn2x_bn_bwd_apply(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean,
                                  const float *invstd, const float *gamma, const float *beta, int relu, const double *sums, float *dy,
                                  int ldo, float *dgamma, float *dbeta, float *dbias, void *stream) {

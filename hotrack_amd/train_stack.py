@@ -49,10 +49,13 @@ _lib.pn2x_tg_bwd_supported.argtypes = [_ci, _ci]
 _lib.pn2x_tg_bwd_supported.restype = _ci
 _lib.pn2x_tg_bwd_partials.argtypes = [_cl, _ci, _ci]
 _lib.pn2x_tg_bwd_partials.restype = _ci
-_lib.pn2x_tg_bwd.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci,
-                             _vp, _vp, _cl, _vp, _vp]
+_lib.pn2x_tg_bwd.argtypes = [_cl, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp,
+                             _vp, _vp, _ci, _vp, _vp, _cl, _vp, _vp]
+_lib.pn2x_bn_bwd_reduce_routed.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_bn_bwd_reduce_routed.restype = _ci
 _lib.pn2x_tg_bwd.restype = _ci
 FUSED_BWD = _os.environ.get("HOTRACK_STACK_FUSED_BWD", "1") != "0"  # data + weight gradient of a layer in one kernel (train_bwd.hip)
+ROUTE_ON_LOAD = _os.environ.get("HOTRACK_STACK_ROUTE_ON_LOAD", "1") != "0"  # max-pooled top: sums from the arg-max rows, routed on load
 _lib.pn2x_bn_bwd_reduce.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
 _lib.pn2x_bn_bwd_reduce.restype = _ci
 _lib.pn2x_bn_bwd_reduce_g.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp]
@@ -214,13 +217,23 @@ class _Stack(torch.autograd.Function):
             Cl = yl.shape[1]
             g, gmode = dout, (2 if K else 1)
             g_dense = None
-            if K and ROUTE_DENSE:
+            wl = tensors[4 * (L - 1)]
+            routed = (K and L > 1 and FUSED_BWD and ROUTE_ON_LOAD and _lib.pn2x_tg_bwd_supported(wl.shape[1], wl.shape[0]))
+            if routed:
+                # the routed gradient is non-zero in one row per (group, channel): the sums need the arg-max rows only, and the
+                # one-kernel layer backward below routes dout on load (no rows x C gradient tensor at all)
+                _native._check(_lib.pn2x_bn_bwd_reduce_routed(R // K, K, Cl, dout.data_ptr(), Cl, arg.data_ptr(), yl.data_ptr(),
+                                                              yl.stride(0), svl[0].data_ptr(), svl[1].data_ptr(), gam(L - 1).data_ptr(),
+                                                              bet(L - 1).data_ptr(), sums[L - 1].data_ptr(), st), "bn_bwd_reduce_routed")
+            elif K and ROUTE_DENSE:
                 # the reduction reads dout / arg / y_L anyway: it also writes the routed, masked gradient once (dense), and the two
                 # GEMMs of the top layer read that instead of routing through arg-max on every load (their slowest variant)
                 g_dense = torch.empty((R, Cl), dtype=_f32, device=dev)
-            _native._check(_lib.pn2x_bn_bwd_reduce_g(R, Cl, dout.data_ptr(), Cl, _p(arg), K if K else 1, yl.data_ptr(), yl.stride(0),
-                                                     svl[0].data_ptr(), svl[1].data_ptr(), gam(L - 1).data_ptr(), bet(L - 1).data_ptr(), 1,
-                                                     sums[L - 1].data_ptr(), _p(g_dense), Cl, st), "bn_bwd_reduce")
+            if not routed:
+                _native._check(_lib.pn2x_bn_bwd_reduce_g(R, Cl, dout.data_ptr(), Cl, _p(arg), K if K else 1, yl.data_ptr(), yl.stride(0),
+                                                         svl[0].data_ptr(), svl[1].data_ptr(), gam(L - 1).data_ptr(),
+                                                         bet(L - 1).data_ptr(), 1, sums[L - 1].data_ptr(), _p(g_dense), Cl, st),
+                               "bn_bwd_reduce")
             if g_dense is not None:
                 g, gmode = g_dense, 0
             for i in range(L - 1, 0, -1):
@@ -234,11 +247,13 @@ class _Stack(torch.autograd.Function):
                 dw = torch.empty((N, Kc), dtype=_f32, device=dev)
                 dpar = torch.empty((3, N), dtype=_f32, device=dev)
                 gp = torch.empty((R, Kc), dtype=_f32, device=dev)
-                if FUSED_BWD and gmode == 0 and _lib.pn2x_tg_bwd_supported(Kc, N):
+                if FUSED_BWD and (gmode == 0 or (gmode == 2 and routed)) and _lib.pn2x_tg_bwd_supported(Kc, N):
                     np_ = int(_lib.pn2x_tg_bwd_partials(R, N, Kc))
                     partial = torch.empty(np_ * N * Kc, dtype=_f32, device=dev)
-                    _native._check(_lib.pn2x_tg_bwd(R, N, Kc, g.data_ptr(), g.stride(0), yi.data_ptr(), yi.stride(0), svi[0].data_ptr(),
-                                                    svi[1].data_ptr(), gam(i).data_ptr(), sums[i].data_ptr(), wc.data_ptr(), wc.stride(0),
+                    _native._check(_lib.pn2x_tg_bwd(R, N, Kc, gmode, g.data_ptr(), g.stride(0), _p(arg) if gmode == 2 else None,
+                                                    K if gmode == 2 else 1, yi.data_ptr(), yi.stride(0), svi[0].data_ptr(),
+                                                    svi[1].data_ptr(), gam(i).data_ptr(), bet(i).data_ptr(), sums[i].data_ptr(),
+                                                    wc.data_ptr(), wc.stride(0),
                                                     yp.data_ptr(), yp.stride(0), svp[0].data_ptr(), svp[1].data_ptr(),
                                                     gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), gp.data_ptr(), Kc, sums[i - 1].data_ptr(),
                                                     partial.data_ptr(), partial.numel(), dw.data_ptr(), st), "tg_bwd")

@@ -362,6 +362,10 @@ int pn2x_bn_bwd_reduce(long rows, int c, const float *dh, int ldd, const int *ar
 int pn2x_bn_bwd_reduce_g(long rows, int c, const float *dh, int ldd, const int *arg, int k, const float *y, int ldy, const float *mean,
                          const float *invstd, const float *gamma, const float *beta, int relu, double *sums, float *g_out, int ldg,
                          void *stream);
+/* The same sums for a max-routed top layer from its arg-max rows only (groups x c gathered reads of y instead of rows x c):
+ * dout / arg (groups x c, row stride ldd), y ((groups * k) x c).  The layer below then routes on load (pn2x_tg_bwd, gmode 2). */
+int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, const float *y, int ldy,
+                              const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums, void *stream);
 int pn2x_bn_bwd_apply(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean, const float *invstd,
                       const float *gamma, const float *beta, int relu, const double *sums, float *dy, int ldo, float *dgamma,
                       float *dbeta, float *dbias, void *stream);
@@ -460,13 +464,15 @@ int pn2x_tg_reduce_multi(int count, const float *const *partial, const int *n_pa
                          float *const *dbias, void *stream);
 /* The whole backward of fused layer i in one kernel (csrc/train_bwd.hip): g_{i-1} (gp, with the ReLU mask and the
  * BatchNorm-backward sums of layer i-1, as pn2x_tg_dgrad) AND the weight-gradient partial tiles (as pn2x_tg_wgrad2 with
- * n_partials) from one pass over g_i (pre-masked: gmode 0), Y_i and Y_{i-1}.  n = channels of layer i, k = channels of layer
+ * n_partials) from one pass over g_i, Y_i and Y_{i-1}.  gmode 0: g pre-masked (rows x n); gmode 2: g = d(max over kmax
+ * rows) ((rows / kmax) x n) routed on load through arg (same shape / stride) and ReLU-masked from Y_i.  n = channels of layer i, k = channels of layer
  * i-1; w (n x k).  pn2x_tg_bwd_supported(k, n): k in {32, 64, 128} and the instantiated n; pn2x_tg_bwd_partials = the number
  * of (n x k) partial tiles written (partial_floats >= that * n * k), to be summed by pn2x_tg_reduce_multi.  dw is zeroed. */
 int pn2x_tg_bwd_supported(int c_in, int c_out);
 int pn2x_tg_bwd_partials(long rows, int c_out, int c_in);
-int pn2x_tg_bwd(long rows, int n, int k, const float *g, int ldg, const float *yi, int ldyi, const float *mean_i,
-                const float *invstd_i, const float *gamma_i, const double *sums_bwd_i, const float *w, int ldw, const float *yp,
+int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi, int ldyi,
+                const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i, const double *sums_bwd_i,
+                const float *w, int ldw, const float *yp,
                 int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p, float *gp, int ldgp,
                 double *sums_bwd_p, float *partial, long partial_floats, float *dw, void *stream);
 

@@ -384,6 +384,8 @@ def test_mlp_stack_second_backward_and_stale_workspace():
     (32 * 1200, [32, 32, 64], 32),
     (16 * 2000 + 16, [128, 128, 192], 16),
     (8 * 777, [128, 128, 128, 64, 32], 8),
+    (24 * 301, [64, 64, 128], 24),       # groups of 24 rows (not a power of two) straddle the 64-row tiles
+    (64 * 150, [128, 128, 192], 64),
 ])
 def test_mlp_stack_one_kernel_layer_backward_equals_two_kernel_backward(R, widths, K):
     """csrc/train_bwd.hip (data + weight gradient of a layer from one pass) vs the tg_dgrad / tg_wgrad pair on the same
