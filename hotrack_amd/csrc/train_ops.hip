@@ -622,6 +622,100 @@ bn_bwd_reduce_routed_kernel(long groups, int K, int C, const float *__restrict__
 }
 }  // namespace pn2
 
+namespace pn2 {
+// out (C x 3) = dy^T (C x rows) rel (rows x 3): the gradient of the xyz columns of a grouped layer-1 weight (a GEMM with a
+// 3-wide output and a 100k+ deep reduction: the library's split-K kernels take 27-49 us for what is one pass over dy).
+// Stage 1: per-workgroup partial sums (no atomics: a thousand workgroups on the same 3 C addresses serialise in L2);
+// stage 2: one workgroup sums the partials.
+__global__ void __launch_bounds__(kTT)
+rows_outer3_kernel(long rows, int C, const float *__restrict__ dy, int ldy, const float *__restrict__ rel, long rows_per_block,
+                   float *__restrict__ partial) {
+    __shared__ float red[12][kTT];
+    const int Q = C >> 2, q = threadIdx.x % Q, rl = threadIdx.x / Q, lanes = kTT / Q;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = (r0 + rows_per_block) < rows ? (r0 + rows_per_block) : rows;
+    float a[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    auto add = [&](float4 d, const float *e) {
+        const float e0 = e[0], e1 = e[1], e2 = e[2];
+        a[0][0] += d.x * e0; a[0][1] += d.x * e1; a[0][2] += d.x * e2;
+        a[1][0] += d.y * e0; a[1][1] += d.y * e1; a[1][2] += d.y * e2;
+        a[2][0] += d.z * e0; a[2][1] += d.z * e1; a[2][2] += d.z * e2;
+        a[3][0] += d.w * e0; a[3][1] += d.w * e1; a[3][2] += d.w * e2;
+    };
+    long r = r0 + rl;
+    for (; r + 3L * lanes < r1; r += 4L * lanes) {  // four independent 16-byte loads in flight per thread
+        const float *p = dy + r * ldy + 4 * q;
+        const float4 d0 = *reinterpret_cast<const float4 *>(p), d1 = *reinterpret_cast<const float4 *>(p + (long)lanes * ldy);
+        const float4 d2 = *reinterpret_cast<const float4 *>(p + 2L * lanes * ldy), d3 = *reinterpret_cast<const float4 *>(p + 3L * lanes * ldy);
+        add(d0, rel + r * 3); add(d1, rel + (r + lanes) * 3); add(d2, rel + (r + 2L * lanes) * 3); add(d3, rel + (r + 3L * lanes) * 3);
+    }
+    for (; r < r1; r += lanes) add(*reinterpret_cast<const float4 *>(dy + r * ldy + 4 * q), rel + r * 3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) red[e * 3 + t][threadIdx.x] = a[e][t];
+    __syncthreads();
+    if (rl == 0) {
+        float *o = partial + (size_t)blockIdx.x * 3 * C + 12 * q;  // out[c][t], c = 4 q + e
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            float s = red[k][q];
+            for (int l = 1; l < lanes; ++l) s += red[k][l * Q + q];
+            o[k] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kTT)
+rows_outer3_sum_kernel(int blocks, int n, const float *__restrict__ partial, float *__restrict__ out) {
+    __shared__ float red[16][16];
+    // one workgroup per 16 outputs: thread = (output, one of sixteen lanes over the partials), four loads in flight per lane
+    const int el = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < n) {
+        int p = pl;
+        for (; p + 48 < blocks; p += 64) {
+            s0 += partial[(size_t)p * n + e];
+            s1 += partial[(size_t)(p + 16) * n + e];
+            s2 += partial[(size_t)(p + 32) * n + e];
+            s3 += partial[(size_t)(p + 48) * n + e];
+        }
+        for (; p < blocks; p += 16) s0 += partial[(size_t)p * n + e];
+    }
+    red[pl][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (pl == 0 && e < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) s += red[l][el];
+        out[e] = s;
+    }
+}
+}  // namespace pn2
+
+extern "C" long pn2x_rows_outer3_scratch_floats(long rows, int c) {
+    if (rows < 1 || c < 1) return -1;
+    return 512L * 3 * c;
+}
+
+extern "C" int pn2x_rows_outer3(long rows, int c, const float *dy, int ldy, const float *rel, float *out, float *scratch,
+                                long scratch_floats, void *stream) {
+    using namespace pn2;
+    if (rows < 1 || c < 4 || c % 4 || kTT % (c / 4) || ldy < c || ldy % 4) return PN2_EINVAL;
+    if (!dy || !rel || !out || !scratch) return PN2_ENULL;
+    if ((uintptr_t)dy % 16) return PN2_EINVAL;
+    if (scratch_floats < 512L * 3 * c) return PN2_ESCRATCH;
+    long blocks = 512;
+    const int lanes = kTT / (c / 4);
+    long rpb = (rows + blocks - 1) / blocks;
+    rpb = (rpb + 4L * lanes - 1) / (4L * lanes) * (4L * lanes);
+    blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(rows_outer3_kernel, dim3((unsigned)blocks), dim3(kTT), 0, (hipStream_t)stream, rows, c, dy, ldy, rel, rpb, scratch);
+    hipLaunchKernelGGL(rows_outer3_sum_kernel, dim3((3 * c + 15) / 16), dim3(kTT), 0, (hipStream_t)stream, (int)blocks, 3 * c, scratch, out);
+    return check_launch();
+}
+
 extern "C" int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, const float *y, int ldy,
                                          const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums,
                                          void *stream) {

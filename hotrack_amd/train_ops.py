@@ -28,6 +28,10 @@ _lib.pn2x_three_interpolate_pm_grad.argtypes = [_ci, _ci, _ci, _ci, _vp, _ci, _v
 _lib.pn2x_sa_layer1.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_sa_layer1_ld.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_sa_layer1_ld.restype = _ci
+_lib.pn2x_rows_outer3.argtypes = [_cl, _ci, _vp, _ci, _vp, _vp, _vp, _cl, _vp]
+_lib.pn2x_rows_outer3.restype = _ci
+_lib.pn2x_rows_outer3_scratch_floats.argtypes = [_cl, _ci]
+_lib.pn2x_rows_outer3_scratch_floats.restype = _cl
 for _n in ("pn2x_bn_stats", "pn2x_bn_relu_apply", "pn2x_bn_relu_bwd", "pn2x_scatter_add_rows", "pn2x_three_interpolate_pm_grad",
            "pn2x_sa_layer1"):
     getattr(_lib, _n).restype = _ci
@@ -272,7 +276,15 @@ class _SaLayer1(torch.autograd.Function):
                 scatter_add_rows(dy, idx.view(B, SK), d_a1f[:, :, col:col + C1])
             if d_cadd is not None:
                 torch.sum(dy.view(B, S, SK // S, C1), dim=2, out=d_cadd[:, :, col:col + C1])
-            d_wx.append(torch.mm(dy.view(B * SK, C1).t(), rel.view(B * SK, 3)))
+            if C1 % 4 == 0 and 256 % (C1 // 4) == 0 and rel.is_contiguous():  # one pass over dy (csrc/train_ops.hip: rows_outer3)
+                dwx = torch.empty((C1, 3), dtype=_f32, device=dev)
+                scratch = torch.empty(int(_lib.pn2x_rows_outer3_scratch_floats(B * SK, C1)), dtype=_f32, device=dev)
+                with torch.cuda.device(dev):
+                    _native._check(_lib.pn2x_rows_outer3(B * SK, C1, dy.data_ptr(), C1, rel.data_ptr(), dwx.data_ptr(),
+                                                         scratch.data_ptr(), scratch.numel(), _native._stream(dy)), "rows_outer3")
+                d_wx.append(dwx)
+            else:
+                d_wx.append(torch.mm(dy.view(B * SK, C1).t(), rel.view(B * SK, 3)))
             col += C1
         return (d_a1f, d_cadd, None, None, None, *([None] * n), *d_wx)
 

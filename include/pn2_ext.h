@@ -366,6 +366,11 @@ int pn2x_bn_bwd_reduce_g(long rows, int c, const float *dh, int ldd, const int *
  * dout / arg (groups x c, row stride ldd), y ((groups * k) x c).  The layer below then routes on load (pn2x_tg_bwd, gmode 2). */
 int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, const float *y, int ldy,
                               const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums, void *stream);
+/* out (c x 3) = dy^T rel: dy (rows x c, row stride ldy), rel (rows x 3) -- the gradient of the three xyz columns of a grouped
+ * layer-1 weight.  c / 4 must divide 256; scratch of pn2x_rows_outer3_scratch_floats(rows, c) floats (per-workgroup partials). */
+long pn2x_rows_outer3_scratch_floats(long rows, int c);
+int pn2x_rows_outer3(long rows, int c, const float *dy, int ldy, const float *rel, float *out, float *scratch, long scratch_floats,
+                     void *stream);
 int pn2x_bn_bwd_apply(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean, const float *invstd,
                       const float *gamma, const float *beta, int relu, const double *sums, float *dy, int ldo, float *dgamma,
                       float *dbeta, float *dbias, void *stream);
