@@ -201,6 +201,107 @@ bn_relu_max_kernel(long groups, int K, int C, const float *__restrict__ Y, int l
     *reinterpret_cast<int4 *>(arg + grp * C + 4 * q) = make_int4(am[0], am[1], am[2], am[3]);
 }
 
+// The same reduction with the K rows of a group split over S lanes (S a power of two, 4 <= S <= 64): few groups x many rows per group
+// (sa3: 32 groups x 128 rows, the keypoint queries: 672 x 64) leave the one-thread-per-(group, quad) kernel with a few thousand
+// threads walking their rows one load after the other.  A workgroup takes 256 / S consecutive (group, quad) items; lane ks of an
+// item scans rows ks, ks + S, ...; the partial (max, first arg-max) pairs meet in LDS.  Same result as the serial scan: the
+// maximum, its FIRST row among equals, and a NaN sticks (with the last NaN row, as the serial update leaves it).  The channel
+// constants are computed once per workgroup (the serial kernel derives them per thread from the fp64 sums).
+__global__ void __launch_bounds__(kTT)
+bn_relu_max_split_kernel(long groups, int K, int C, int S, const float *__restrict__ Y, int ldy, const double *__restrict__ sums,
+                         const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ conv_bias, float eps,
+                         float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
+                         float *__restrict__ save_mean, float *__restrict__ save_invstd, float *__restrict__ out, int *__restrict__ arg) {
+    __shared__ float cst[4][kTT];        // mean, invstd, gamma, beta of the channels this workgroup touches (<= 256: 64 quads)
+    __shared__ float pm[kTT][4];
+    __shared__ int pa[kTT][4];
+    const int Q = C >> 2;
+    const int ipb = kTT / S;             // items per workgroup
+    const long rows = groups * K;
+    const long item0 = (long)blockIdx.x * ipb;
+    // channels of this workgroup: items item0 .. item0 + ipb - 1 -> quads (item % Q): ipb >= Q covers all C channels (C <= 256),
+    // else the ipb consecutive quads starting at item0 % Q (wrapping)
+    const int nq = ipb < Q ? ipb : Q;
+    const int q0 = ipb < Q ? (int)(item0 % Q) : 0;
+    for (int t = threadIdx.x; t < 4 * nq; t += kTT) {
+        const int c = (4 * q0 + t) % C;
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < kRep; ++r) {
+            s1 += sums[(size_t)r * 2 * C + c];
+            s2 += sums[(size_t)r * 2 * C + C + c];
+        }
+        const double m = s1 / (double)rows;
+        double v = s2 / (double)rows - m * m;
+        v = v > 0.0 ? v : 0.0;
+        const float mean = (float)m, invstd = (float)(1.0 / sqrt(v + (double)eps));
+        cst[0][t] = mean; cst[1][t] = invstd; cst[2][t] = gamma[c]; cst[3][t] = beta[c];
+    }
+    if (blockIdx.x == 0) {  // the consumer finalises the producer's statistics: saved mean / invstd, running estimates
+        for (int c = threadIdx.x; c < C; c += kTT) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int r = 0; r < kRep; ++r) {
+                s1 += sums[(size_t)r * 2 * C + c];
+                s2 += sums[(size_t)r * 2 * C + C + c];
+            }
+            const double m = s1 / (double)rows;
+            double v = s2 / (double)rows - m * m;
+            v = v > 0.0 ? v : 0.0;
+            const float mean = (float)m;
+            save_mean[c] = mean;
+            save_invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+            if (running_mean) {
+                const float bm = mean + (conv_bias ? conv_bias[c] : 0.f);
+                const float bv = (float)(rows > 1 ? v * ((double)rows / (double)(rows - 1)) : v);
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * bm;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * bv;
+            }
+        }
+        if (threadIdx.x == 0 && nbt) *nbt += 1;
+    }
+    __syncthreads();
+    const int il = threadIdx.x % ipb, ks = threadIdx.x / ipb;
+    const long item = item0 + il;
+    const bool live = item < groups * Q;
+    const int q = (int)(item % Q);
+    const long grp = item / Q;
+    float m[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    int am[4] = {0, 0, 0, 0};
+    if (live) {
+        const int t0 = ipb < Q ? 4 * ((q - q0 + Q) % Q) : 4 * q;
+        BnCh k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { k.mean[i] = cst[0][t0 + i]; k.invstd[i] = cst[1][t0 + i]; k.g[i] = cst[2][t0 + i]; k.b[i] = cst[3][t0 + i]; }
+        const float *__restrict__ y = Y + grp * K * ldy + 4 * q;
+        for (int kk = ks; kk < K; kk += S) {
+            const float4 v = *reinterpret_cast<const float4 *>(y + (long)kk * ldy);
+            const float h[4] = {bn_act(v.x, k, 0), bn_act(v.y, k, 1), bn_act(v.z, k, 2), bn_act(v.w, k, 3)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (h[i] > m[i] || h[i] != h[i]) { m[i] = h[i]; am[i] = kk; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pm[threadIdx.x][i] = m[i]; pa[threadIdx.x][i] = am[i]; }
+    __syncthreads();
+    if (ks == 0 && live) {
+        for (int l = 1; l < S; ++l) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float o = pm[l * ipb + il][i];
+                const int oa = pa[l * ipb + il][i];
+                const bool on = o != o, mn = m[i] != m[i];
+                if (on || mn) {                       // a NaN wins; among NaNs the last row (the serial update's result)
+                    if (on && (!mn || oa > am[i])) { m[i] = o; am[i] = oa; }
+                } else if (o > m[i] || (o == m[i] && oa < am[i])) {  // the first row among equal maxima
+                    m[i] = o; am[i] = oa;
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(out + grp * C + 4 * q) = make_float4(relu_nan(m[0]), relu_nan(m[1]), relu_nan(m[2]), relu_nan(m[3]));
+        *reinterpret_cast<int4 *>(arg + grp * C + 4 * q) = make_int4(am[0], am[1], am[2], am[3]);
+    }
+}
+
 struct BnSaved {
     float mean[4], invstd[4], g[4], b[4];
 };
@@ -755,6 +856,15 @@ extern "C" int pn2x_bn_relu_max(long groups, int k, int c, const float *y, int l
     if (!y || !sums || !gamma || !beta || !save_mean || !save_invstd || !out || !arg) return PN2_ENULL;
     if (((uintptr_t)y | (uintptr_t)out | (uintptr_t)arg) % 16) return PN2_EINVAL;
     const long items = groups * (c / 4);
+    int split = 1;  // rows of a group over `split` lanes while that keeps fewer than ~128k threads busy
+    while (split < 64 && 2 * split <= k && items * split < 131072) split *= 2;
+    if (split >= 4) {
+        const int ipb = kTT / split;
+        hipLaunchKernelGGL(bn_relu_max_split_kernel, dim3((unsigned)((items + ipb - 1) / ipb)), dim3(kTT), 0, (hipStream_t)stream, groups, k, c,
+                           split, y, ldy, sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, num_batches_tracked,
+                           save_mean, save_invstd, out, arg);
+        return check_launch();
+    }
     hipLaunchKernelGGL(bn_relu_max_kernel, dim3((unsigned)((items + kTT - 1) / kTT)), dim3(kTT), 0, (hipStream_t)stream, groups, k, c, y, ldy,
                        sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd,
                        out, arg);

@@ -214,13 +214,18 @@ def test_fast_train_path_equals_module_path():
             torch.testing.assert_close(bb[k], ba[k], rtol=1e-4, atol=3e-5, msg=lambda m: f"{k}: {m}")
 
 
-@pytest.mark.parametrize("G,K,C", [(300, 32, 64), (21 * 5, 16, 192), (64, 128, 512), (7, 3, 4)])
-def test_bn_relu_max_matches_unfused(G, K, C):
+@pytest.mark.parametrize("G,K,C,ties", [(300, 32, 64, False), (21 * 5, 16, 192, False), (64, 128, 512, False), (7, 3, 4, False),
+                                         (32 * 21, 64, 192, True), (32, 128, 512, True), (9000, 32, 64, True), (50, 24, 128, True)])
+def test_bn_relu_max_matches_unfused(G, K, C, ties):
     """Fused BatchNorm + ReLU + max over K rows (forward, arg-max routing of the gradient, running statistics) vs
-    bn_relu followed by torch.max."""
+    bn_relu followed by torch.max -- through the one-thread-per-(group, quad) kernel (many groups) and the one that splits a
+    group's rows over lanes (few groups); `ties`: pre-activations on a coarse lattice, so equal maxima are common and the
+    FIRST row must win in both."""
     from hotrack_amd.train_ops import Workspace, bn_relu, bn_relu_max
     g = torch.Generator(device="cuda").manual_seed(G + K)
     y0 = torch.randn(G * K, C, device="cuda", generator=g) * 1.5 - 0.2
+    if ties:
+        y0 = torch.round(y0 * 2) / 2
     go = torch.randn(G, C, device="cuda", generator=g)
     bias = torch.randn(C, device="cuda", generator=g)
     res = []
