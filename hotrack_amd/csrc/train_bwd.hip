@@ -102,32 +102,6 @@ tg_bwd_kernel(BwdArgs a) {
 #endif
     TGB_T(t_start);
 
-    {
-        const float inv_r = (float)(1.0 / (double)a.R);
-        for (int c = tid; c < Kd; c += kT) {
-            double sa = 0.0, sb = 0.0;
-            for (int r = 0; r < kBnRep; ++r) {
-                sa += a.sums_bwd[(size_t)r * 2 * Kd + c];
-                sb += a.sums_bwd[(size_t)r * 2 * Kd + Kd + c];
-            }
-            const float is = a.invstd[c];
-            cA[c] = a.mean[c]; cA[Kd + c] = is; cA[2 * Kd + c] = a.gamma[c] * is;
-            cA[3 * Kd + c] = (float)sa * inv_r; cA[4 * Kd + c] = (float)sb * inv_r;
-            if constexpr (GMODE == 2) { cA[5 * Kd + c] = a.gamma[c]; cA[6 * Kd + c] = a.beta[c]; }
-        }
-        for (int c = tid; c < N; c += kT) {
-            cP[c] = a.mean_p[c]; cP[N + c] = a.invstd_p[c]; cP[2 * N + c] = a.gamma_p[c]; cP[3 * N + c] = a.beta_p[c];
-        }
-        if (blockIdx.x == 0)
-            for (int e = tid; e < Kd * N; e += kT) a.dW[e] = 0.f;
-        if constexpr (P::WLDS)
-            for (int e = tid; e < Kd * N / 4; e += kT) {
-                const int kd = e / (N / 4), q = e % (N / 4);
-                *reinterpret_cast<float4 *>(Ws + kd * N + 4 * q) = *reinterpret_cast<const float4 *>(a.W + (size_t)kd * a.ldw + 4 * q);
-            }
-    }
-    __syncthreads();
-
     const long T = (a.R + BM - 1) / BM;
     // dY operands: a wave fetches 8 rows x 8 float4 (128 contiguous bytes per row) per step; KB steps cover its 8 rows
     const int arow = 8 * wave + (lane >> 3), aq = lane & 7;
@@ -161,6 +135,35 @@ tg_bwd_kernel(BwdArgs a) {
             ph[i] = *reinterpret_cast<const float4 *>(a.Yp + r * a.ldyp + 4 * cq);
         }
     };
+    long tile = blockIdx.x;
+    if (tile < T) prefetch(tile);  // the first tile's operands travel while the constants (and W_i) are set up
+
+    {
+        const float inv_r = (float)(1.0 / (double)a.R);
+        for (int c = tid; c < Kd; c += kT) {
+            double sa = 0.0, sb = 0.0;
+            for (int r = 0; r < kBnRep; ++r) {
+                sa += a.sums_bwd[(size_t)r * 2 * Kd + c];
+                sb += a.sums_bwd[(size_t)r * 2 * Kd + Kd + c];
+            }
+            const float is = a.invstd[c];
+            cA[c] = a.mean[c]; cA[Kd + c] = is; cA[2 * Kd + c] = a.gamma[c] * is;
+            cA[3 * Kd + c] = (float)sa * inv_r; cA[4 * Kd + c] = (float)sb * inv_r;
+            if constexpr (GMODE == 2) { cA[5 * Kd + c] = a.gamma[c]; cA[6 * Kd + c] = a.beta[c]; }
+        }
+        for (int c = tid; c < N; c += kT) {
+            cP[c] = a.mean_p[c]; cP[N + c] = a.invstd_p[c]; cP[2 * N + c] = a.gamma_p[c]; cP[3 * N + c] = a.beta_p[c];
+        }
+        if (blockIdx.x == 0)
+            for (int e = tid; e < Kd * N; e += kT) a.dW[e] = 0.f;
+        if constexpr (P::WLDS)
+            for (int e = tid; e < Kd * N / 4; e += kT) {
+                const int kd = e / (N / 4), q = e % (N / 4);
+                *reinterpret_cast<float4 *>(Ws + kd * N + 4 * q) = *reinterpret_cast<const float4 *>(a.W + (size_t)kd * a.ldw + 4 * q);
+            }
+    }
+    __syncthreads();
+
     // (this thread's four channels of layer i-1 are the same for every tile; their constants are re-read from LDS where they
     // are used -- four ds_read_b128 per tile against sixteen registers held across both matrix phases)
     // xhat_{i-1} of this thread's elements: built by the commit, used again by the epilogue of the same tile (kept in registers
@@ -238,8 +241,6 @@ tg_bwd_kernel(BwdArgs a) {
         for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
     float cs[4] = {0.f, 0.f, 0.f, 0.f}, cqs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    long tile = blockIdx.x;
-    if (tile < T) prefetch(tile);
     TGB_T(t_pro);
     TGB_ADD(0, t_pro, t_start);
     while (tile < T) {

@@ -1,0 +1,272 @@
+// train_fwd.hip -- the forward of a fused [Conv 1x1 + BatchNorm + ReLU] layer for 64- and 128-channel inputs (gfx950).
+//
+// Same mathematics and interface as train_gemm.hip's tg_fwd (Y_i = relu(BN_{i-1}(Y_{i-1})) W_i^T, statistics of Y_i in the
+// epilogue, the consumer finalises its producer's running statistics), different schedule.  tg_fwd walks the reduction in
+// chunks of 32 through one LDS buffer (two barriers per chunk), rebuilds the normalised A operand once per 64/128-column
+// block of the output and takes 128-row tiles -- 336 of them for the 43008-row keypoint-query layers, on 256 CUs.  Here:
+//   * W_i (this workgroup's 64 / 128 / 192 output channels x all K input channels) sits in LDS for the whole kernel,
+//     k-minor with an odd row stride (both MFMA operands are then conflict-free ds_read_b32);
+//   * a persistent workgroup takes 64-row tiles: the normalised + ReLU'd tile H (64 x K) is built ONCE in LDS from operands
+//     fetched a tile ahead, then every wave runs the whole reduction for its own 32 x 32 output block (2 row blocks x
+//     2 / 4 / 6 column blocks = 4 / 8 / 12 waves) without a barrier in between: two barriers per TILE;
+//   * outputs go from the accumulators to HBM (two 128-byte segments per store instruction), their per-channel
+//     sum / sum of squares stay in two registers per lane for all tiles of the workgroup.
+// v_mfma_f32_32x32x2_f32.  Layers with 32 or 256 input channels keep tg_fwd (the former are HBM-bound there already).
+#include "pn2_common.h"
+#include "../../include/pn2_ext.h"
+
+namespace pn2 {
+namespace tgf {
+
+constexpr int BM = 64;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float relu_nan(float h) { return !(h <= 0.f) ? h : 0.f; }  // propagates NaN like torch
+
+struct FwdArgs {
+    long R;
+    int N;                     // all output channels (row stride of the statistics)
+    const float *X; int ldx;   // pre-activations of the previous layer (R x K)
+    const float *W; int ldw;   // (N x K)
+    float *Y; int ldy;         // (R x N)
+    const double *sums_in;     // previous layer's forward sums
+    const float *gamma, *beta, *conv_bias;
+    float eps, momentum;
+    float *running_mean, *running_var;
+    long long *nbt;
+    float *save_mean, *save_invstd;  // written by workgroup (0, 0)
+    double *sums_out;                // this layer's forward sums (may be null)
+};
+
+template <int KB, int NBLK>
+struct Plan {
+    static constexpr int K = 32 * KB, NW = 32 * NBLK, WAVES = 2 * NBLK, T = 64 * WAVES;
+    static constexpr int LDK = K + 1;
+    static constexpr int GROUPS = WAVES >= 8 ? 1 : 8 / WAVES;  // 8-row groups of the tile a wave commits
+    static constexpr int lds_floats = 4 * K + BM * LDK + NW * LDK + WAVES * 64;
+};
+
+template <int KB, int NBLK>
+__global__ void __launch_bounds__(128 * NBLK)
+tgf_kernel(FwdArgs a) {
+    using P = Plan<KB, NBLK>;
+    constexpr int K = P::K, NW = P::NW, LDK = P::LDK, T = P::T;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *cst = lds;              // [4][K]: mean, invstd, gamma, beta of the input channels
+    float *Hs = cst + 4 * K;       // [BM][LDK]
+    float *Ws = Hs + BM * LDK;     // [NW][LDK]
+    float *red = Ws + NW * LDK;    // [WAVES][2][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.y * NW;
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    const long tiles = (a.R + BM - 1) / BM;
+    // tile operands: a wave fetches 8 rows x 8 float4 (128 contiguous bytes per row) per step; the first 8 waves (all of
+    // them where there are fewer) cover the tile's eight 8-row groups
+    const int arow = lane >> 3, aq = lane & 7;
+    const bool loader = wave < 8;
+    float4 px[P::GROUPS * KB];
+    auto prefetch = [&](long tile) {
+        if (!loader) return;
+#pragma unroll
+        for (int g = 0; g < P::GROUPS; ++g) {
+            long row = tile * BM + 8 * (wave + g * P::WAVES) + arow;
+            row = row < a.R ? row : a.R - 1;  // unconditional loads; the commit zeroes what lies beyond the problem
+#pragma unroll
+            for (int i = 0; i < KB; ++i) px[g * KB + i] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + 4 * (8 * i + aq));
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile < tiles) prefetch(tile);  // the first tile's operands travel while the constants and W_i are set up
+    for (int k = tid; k < K; k += T) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < kBnRep; ++r) {
+            s1 += a.sums_in[(size_t)r * 2 * K + k];
+            s2 += a.sums_in[(size_t)r * 2 * K + K + k];
+        }
+        const double m = s1 / (double)a.R;
+        double v = s2 / (double)a.R - m * m;
+        v = v > 0.0 ? v : 0.0;
+        const float mean = (float)m, invstd = (float)(1.0 / sqrt(v + (double)a.eps));  // same arithmetic as train_ops.hip's bn_consts
+        cst[k] = mean; cst[K + k] = invstd; cst[2 * K + k] = a.gamma[k]; cst[3 * K + k] = a.beta[k];
+        if (first) {
+            a.save_mean[k] = mean;
+            a.save_invstd[k] = invstd;
+            if (a.running_mean) {  // torch: running = (1 - m) running + m batch, the variance unbiased
+                const float bm = mean + (a.conv_bias ? a.conv_bias[k] : 0.f);  // the GEMM output excludes the conv bias (cancels in BN)
+                const float bv = (float)(a.R > 1 ? v * ((double)a.R / (double)(a.R - 1)) : v);
+                a.running_mean[k] = (1.f - a.momentum) * a.running_mean[k] + a.momentum * bm;
+                a.running_var[k] = (1.f - a.momentum) * a.running_var[k] + a.momentum * bv;
+            }
+        }
+    }
+    if (first && tid == 0 && a.nbt) *a.nbt += 1;
+    for (int e = tid; e < NW * (K / 4); e += T) {
+        const int n = e / (K / 4), q = e % (K / 4);
+        const float4 w = *reinterpret_cast<const float4 *>(a.W + (size_t)(n0 + n) * a.ldw + 4 * q);
+        float *dst = Ws + n * LDK + 4 * q;
+        dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+    }
+    __syncthreads();
+
+    auto commit = [&](long tile) {
+        if (!loader) return;
+#pragma unroll
+        for (int g = 0; g < P::GROUPS; ++g) {
+            const int r = 8 * (wave + g * P::WAVES) + arow;
+            const bool v = tile * BM + r < a.R;
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+                const int c = 4 * (8 * i + aq);
+                const float4 mean = *reinterpret_cast<const float4 *>(cst + c), is = *reinterpret_cast<const float4 *>(cst + K + c);
+                const float4 ga = *reinterpret_cast<const float4 *>(cst + 2 * K + c), be = *reinterpret_cast<const float4 *>(cst + 3 * K + c);
+                const float4 x = px[g * KB + i];
+                float *dst = Hs + r * LDK + c;
+                const float h0 = relu_nan(((x.x - mean.x) * is.x) * ga.x + be.x);  // torch's evaluation order
+                const float h1 = relu_nan(((x.y - mean.y) * is.y) * ga.y + be.y);
+                const float h2 = relu_nan(((x.z - mean.z) * is.z) * ga.z + be.z);
+                const float h3 = relu_nan(((x.w - mean.w) * is.w) * ga.w + be.w);
+                dst[0] = v ? h0 : 0.f; dst[1] = v ? h1 : 0.f; dst[2] = v ? h2 : 0.f; dst[3] = v ? h3 : 0.f;
+            }
+        }
+    };
+
+    const int rblk = wave / NBLK, nb = wave % NBLK;
+    const float *ap = Hs + (rblk * 32 + l31) * LDK + kh;
+    const float *bp = Ws + (nb * 32 + l31) * LDK + kh;
+    float cs = 0.f, cq = 0.f;
+    while (tile < tiles) {
+        commit(tile);
+        __syncthreads();
+        const long ntile = tile + gridDim.x;
+        if (ntile < tiles) prefetch(ntile);  // nothing else of this tile reads global memory
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            // operands of the next U matrix instructions are requested from LDS while the current U issue (left to itself the
+            // compiler waits for each pair of ds_reads right in front of the two instructions that use them)
+            constexpr int U = 8, NBATCH = (K / 2) / U;
+            static_assert(NBATCH % 2 == 0, "batches come in pairs");
+            float a0[U], b0[U], a1[U], b1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a0[u] = ap[2 * u]; b0[u] = bp[2 * u]; }
+#pragma unroll
+            for (int bt = 0; bt < NBATCH; bt += 2) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { a1[u] = ap[2 * ((bt + 1) * U + u)]; b1[u] = bp[2 * ((bt + 1) * U + u)]; }
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the reads back in front of their uses)
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (bt + 2 < NBATCH) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { a0[u] = ap[2 * ((bt + 2) * U + u)]; b0[u] = bp[2 * ((bt + 2) * U + u)]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // every wave is done with Hs: the next commit may overwrite it while the stores below drain
+        {
+            const long row0 = tile * BM + rblk * 32 + 4 * kh;
+            float *dst = a.Y + n0 + nb * 32 + l31;
+            if (tile * BM + BM <= a.R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(row0 + (r & 3) + 8 * (r >> 2)) * a.ldy] = acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = row0 + (r & 3) + 8 * (r >> 2);
+                    if (row < a.R) dst[row * a.ldy] = acc[r];
+                }
+            }
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // rows beyond R are exact zeros
+                s += acc[r];
+                q += acc[r] * acc[r];
+            }
+            cs += s;
+            cq += q;
+        }
+        tile = ntile;
+    }
+    if (a.sums_out) {
+        const float s = cs + __shfl_xor(cs, 32), q = cq + __shfl_xor(cq, 32);  // lanes l and l ^ 32 hold the same column
+        if (lane < 32) {
+            red[wave * 64 + lane] = s;
+            red[wave * 64 + 32 + lane] = q;
+        }
+        __syncthreads();
+        if (tid < NW) {
+            const int b = tid >> 5, c = tid & 31;  // column block b: waves b (rows 0..31) and NBLK + b (rows 32..63)
+            const double sd = (double)red[b * 64 + c] + (double)red[(NBLK + b) * 64 + c];
+            const double qd = (double)red[b * 64 + 32 + c] + (double)red[(NBLK + b) * 64 + 32 + c];
+            double *dst = a.sums_out + (size_t)((blockIdx.x + blockIdx.y) % kBnRep) * 2 * a.N;
+            unsafeAtomicAdd(dst + n0 + tid, sd);
+            unsafeAtomicAdd(dst + a.N + n0 + tid, qd);
+        }
+    }
+}
+
+// column blocks per workgroup for n output channels: 6 (192 columns) where that divides n and 128 does not leave fewer
+// workgroup columns, 4 (128), 2 (64); 0 = not covered
+static int blocks_for(int n) {
+    if (n % 192 == 0 && n % 128 != 0) return 6;
+    if (n % 128 == 0) return 4;
+    if (n % 192 == 0) return 6;
+    if (n == 64) return 2;
+    return 0;
+}
+
+}  // namespace tgf
+}  // namespace pn2
+
+using namespace pn2;
+using namespace pn2::tgf;
+
+extern "C" int pn2x_tg_fwd2_supported(int c_in, int c_out) { return ((c_in == 64 || c_in == 128) && blocks_for(c_out) != 0) ? 1 : 0; }
+
+extern "C" int pn2x_tg_fwd2(long rows, int k, int n, const float *x, int ldx, const float *w, int ldw, float *y, int ldy,
+                            const double *sums_in, const float *gamma, const float *beta, const float *conv_bias, float eps,
+                            float momentum, float *running_mean, float *running_var, long long *num_batches_tracked,
+                            float *save_mean, float *save_invstd, double *sums_out, void *stream) {
+    if (rows < 1 || !pn2x_tg_fwd2_supported(k, n) || ldx < k || ldx % 4 || ldw < k || ldw % 4 || ldy < n) return PN2_EINVAL;
+    if (!x || !w || !y || !sums_in || !gamma || !beta || !save_mean || !save_invstd) return PN2_ENULL;
+    if (((uintptr_t)x | (uintptr_t)w) % 16) return PN2_EINVAL;
+    FwdArgs a{rows, n, x, ldx, w, ldw, y, ldy, sums_in, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
+              num_batches_tracked, save_mean, save_invstd, sums_out};
+    const int nblk = blocks_for(n), kb = k / 32;
+    const int ny = n / (32 * nblk);
+    const long tiles = (rows + BM - 1) / BM;
+    hipStream_t st = (hipStream_t)stream;
+#define PN2_TGF_LAUNCH(KB_, NBLK_)                                                                                      \
+    do {                                                                                                              \
+        using P = Plan<KB_, NBLK_>;                                                                                   \
+        const size_t lds = (size_t)P::lds_floats * sizeof(float);                                                     \
+        static PerDeviceOnce once;                                                                                    \
+        if (once.first_use())                                                                                         \
+            (void)hipFuncSetAttribute((const void *)tgf_kernel<KB_, NBLK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        /* persistent workgroups: as many per CU as the LDS footprint admits (at most 2), shared among the column groups */ \
+        long per_cu = (long)(160 * 1024 / lds);                                                                       \
+        if (per_cu > 2) per_cu = 2;                                                                                   \
+        if (per_cu < 1) per_cu = 1;                                                                                   \
+        long gx = (long)num_compute_units() * per_cu / ny;  /* never more workgroups than slots: a straggler doubles the time */ \
+        if (gx < 1) gx = 1;                                                                                           \
+        if (gx > tiles) gx = tiles;                                                                                   \
+        hipLaunchKernelGGL((tgf_kernel<KB_, NBLK_>), dim3((unsigned)gx, ny), dim3(P::T), lds, st, a);                 \
+    } while (0)
+    if (kb == 4) {
+        if (nblk == 6) PN2_TGF_LAUNCH(4, 6);
+        else if (nblk == 4) PN2_TGF_LAUNCH(4, 4);
+        else PN2_TGF_LAUNCH(4, 2);
+    } else {
+        if (nblk == 6) PN2_TGF_LAUNCH(2, 6);
+        else if (nblk == 4) PN2_TGF_LAUNCH(2, 4);
+        else PN2_TGF_LAUNCH(2, 2);
+    }
+#undef PN2_TGF_LAUNCH
+    return check_launch();
+}

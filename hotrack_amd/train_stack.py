@@ -32,6 +32,11 @@ _lib.pn2x_tg_supported.argtypes = [_ci, _ci]
 _lib.pn2x_tg_supported.restype = _ci
 _lib.pn2x_tg_fwd.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_tg_fwd.restype = _ci
+_lib.pn2x_tg_fwd2.argtypes = _lib.pn2x_tg_fwd.argtypes
+_lib.pn2x_tg_fwd2.restype = _ci
+_lib.pn2x_tg_fwd2_supported.argtypes = [_ci, _ci]
+_lib.pn2x_tg_fwd2_supported.restype = _ci
+FWD2 = _os.environ.get("HOTRACK_STACK_FWD2", "1") != "0"  # 64- / 128-channel inputs: the W-resident forward (csrc/train_fwd.hip)
 _DY = [_ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]  # gmode, g, ldg, arg, kmax, yi, ldyi, mean, invstd, gamma, beta, sums_bwd
 _lib.pn2x_tg_dgrad.argtypes = [_cl, _ci, _ci] + _DY + [_vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
 _lib.pn2x_tg_dgrad.restype = _ci
@@ -150,7 +155,8 @@ class _Stack(torch.autograd.Function):
                 y = torch.empty((R, N), dtype=_f32, device=dev)
                 sv = torch.empty((2, Kc), dtype=_f32, device=dev)
                 x = ys[-1]
-                _native._check(_lib.pn2x_tg_fwd(R, Kc, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), N,
+                fwd = _lib.pn2x_tg_fwd2 if (FWD2 and _lib.pn2x_tg_fwd2_supported(Kc, N)) else _lib.pn2x_tg_fwd
+                _native._check(fwd(R, Kc, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), N,
                                                 ws_f[i - 1].data_ptr(), gamma_p.data_ptr(), beta_p.data_ptr(), _p(bias_p), float(eps),
                                                 float(mom), _p(rm), _p(rv), _p(nbt), sv[0].data_ptr(), sv[1].data_ptr(),
                                                 ws_f[i].data_ptr(), st), "tg_fwd")

@@ -467,6 +467,14 @@ int pn2x_tg_wgrad2(long rows, int n, int k, int gmode, const float *g, int ldg, 
 int pn2x_tg_reduce_multi(int count, const float *const *partial, const int *n_partials, const int *numel, float *const *dw,
                          const double *const *sums_bwd, const int *channels, float *const *dgamma, float *const *dbeta,
                          float *const *dbias, void *stream);
+/* pn2x_tg_fwd with a different schedule for 64- / 128-channel inputs (csrc/train_fwd.hip: W_i resident in LDS, 64-row tiles whose
+ * normalised operand is built once, one 32 x 32 output block per wave).  Same arguments and results (up to summation order). */
+int pn2x_tg_fwd2_supported(int c_in, int c_out);
+int pn2x_tg_fwd2(long rows, int k, int n, const float *x, int ldx, const float *w, int ldw, float *y, int ldy, const double *sums_in,
+                 const float *gamma, const float *beta, const float *conv_bias, float eps, float momentum, float *running_mean,
+                 float *running_var, long long *num_batches_tracked, float *save_mean, float *save_invstd, double *sums_out,
+                 void *stream);
+
 /* The whole backward of fused layer i in one kernel (csrc/train_bwd.hip): g_{i-1} (gp, with the ReLU mask and the
  * BatchNorm-backward sums of layer i-1, as pn2x_tg_dgrad) AND the weight-gradient partial tiles (as pn2x_tg_wgrad2 with
  * n_partials) from one pass over g_i, Y_i and Y_{i-1}.  gmode 0: g pre-masked (rows x n); gmode 2: g = d(max over kmax
