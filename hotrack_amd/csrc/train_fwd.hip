@@ -1,4 +1,4 @@
-// train_fwd.hip -- the forward of a fused [Conv 1x1 + BatchNorm + ReLU] layer for 64- and 128-channel inputs (gfx950).
+// train_fwd.hip -- the forward of a fused [Conv 1x1 + BatchNorm + ReLU] layer for 64- / 128- / 256-channel inputs (gfx950).
 //
 // Same mathematics and interface as train_gemm.hip's tg_fwd (Y_i = relu(BN_{i-1}(Y_{i-1})) W_i^T, statistics of Y_i in the
 // epilogue, the consumer finalises its producer's running statistics), different schedule.  tg_fwd walks the reduction in
@@ -11,7 +11,8 @@
 //     2 / 4 / 6 column blocks = 4 / 8 / 12 waves) without a barrier in between: two barriers per TILE;
 //   * outputs go from the accumulators to HBM (two 128-byte segments per store instruction), their per-channel
 //     sum / sum of squares stay in two registers per lane for all tiles of the workgroup.
-// v_mfma_f32_32x32x2_f32.  Layers with 32 or 256 input channels keep tg_fwd (the former are HBM-bound there already).
+// v_mfma_f32_32x32x2_f32.  Layers with 32 input channels keep tg_fwd (HBM-bound there already); 256 input channels (the two small
+// feature-propagation stacks) take 64 output columns per workgroup so that W_i's slice still fits next to the operand tile.
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
@@ -227,7 +228,12 @@ static int blocks_for(int n) {
 using namespace pn2;
 using namespace pn2::tgf;
 
-extern "C" int pn2x_tg_fwd2_supported(int c_in, int c_out) { return ((c_in == 64 || c_in == 128) && blocks_for(c_out) != 0) ? 1 : 0; }
+// 256 input channels: 64 output columns per workgroup (W_i slice 66 KiB next to the 66 KiB operand tile), four waves
+static int blocks_for_k(int k, int n) { return k == 256 ? (n % 64 == 0 ? 2 : 0) : blocks_for(n); }
+
+extern "C" int pn2x_tg_fwd2_supported(int c_in, int c_out) {
+    return ((c_in == 64 || c_in == 128 || c_in == 256) && blocks_for_k(c_in, c_out) != 0) ? 1 : 0;
+}
 
 extern "C" int pn2x_tg_fwd2(long rows, int k, int n, const float *x, int ldx, const float *w, int ldw, float *y, int ldy,
                             const double *sums_in, const float *gamma, const float *beta, const float *conv_bias, float eps,
@@ -238,7 +244,7 @@ extern "C" int pn2x_tg_fwd2(long rows, int k, int n, const float *x, int ldx, co
     if (((uintptr_t)x | (uintptr_t)w) % 16) return PN2_EINVAL;
     FwdArgs a{rows, n, x, ldx, w, ldw, y, ldy, sums_in, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
               num_batches_tracked, save_mean, save_invstd, sums_out};
-    const int nblk = blocks_for(n), kb = k / 32;
+    const int nblk = blocks_for_k(k, n), kb = k / 32;
     const int ny = n / (32 * nblk);
     const long tiles = (rows + BM - 1) / BM;
     hipStream_t st = (hipStream_t)stream;
@@ -258,7 +264,9 @@ extern "C" int pn2x_tg_fwd2(long rows, int k, int n, const float *x, int ldx, co
         if (gx > tiles) gx = tiles;                                                                                   \
         hipLaunchKernelGGL((tgf_kernel<KB_, NBLK_>), dim3((unsigned)gx, ny), dim3(P::T), lds, st, a);                 \
     } while (0)
-    if (kb == 4) {
+    if (kb == 8) {
+        PN2_TGF_LAUNCH(8, 2);
+    } else if (kb == 4) {
         if (nblk == 6) PN2_TGF_LAUNCH(4, 6);
         else if (nblk == 4) PN2_TGF_LAUNCH(4, 4);
         else PN2_TGF_LAUNCH(4, 2);
