@@ -611,6 +611,53 @@ rows_segment_sum_kernel(int n_dst, int m_src, int Q, const float *__restrict__ d
     *dst = acc;
 }
 
+// The same sums with a destination's segment split over EL lanes (EL a power of two, Q * EL divides 256): ball-query padding
+// repeats a ball's first index up to nsample times, so some destinations receive hundreds of rows while most receive a few --
+// with one thread per (destination, quad) the launch waits for those threads (59 us for 33 MB at sa2).
+template <int T>
+__global__ void __launch_bounds__(kTT)
+rows_segment_sum_split_kernel(int n_dst, int m_src, int Q, int EL, const float *__restrict__ dOut, int ldo,
+                              const int *__restrict__ offsets_all, const int *__restrict__ order_all,
+                              const float *__restrict__ weight_all, float *__restrict__ dIn, int ldi, int accumulate) {
+    __shared__ float4 red[kTT];
+    const int b = blockIdx.y;
+    const int dpb = kTT / (Q * EL);  // destinations per workgroup
+    const int q = threadIdx.x % Q, el = (threadIdx.x / Q) % EL, dl = threadIdx.x / (Q * EL);
+    const int i = blockIdx.x * dpb + dl;
+    const int *__restrict__ offsets = offsets_all + (size_t)b * (n_dst + 1);
+    const int *__restrict__ order = order_all + (size_t)b * m_src * T;
+    const float *__restrict__ src = dOut + (size_t)b * m_src * ldo + 4 * q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n_dst) {
+        const int p1 = offsets[i + 1];
+        for (int p = offsets[i] + el; p < p1; p += EL) {
+            const int e = order[p];
+            const int j = T == 1 ? e : e / T;
+            const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)j * ldo);
+            if constexpr (T == 1) {
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            } else {
+                const float w = weight_all[(size_t)b * m_src * T + e];
+                acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+            }
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (el == 0 && i < n_dst) {
+        for (int l = 1; l < EL; ++l) {
+            const float4 o = red[(dl * EL + l) * Q + q];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        float4 *dst = reinterpret_cast<float4 *>(dIn + ((size_t)b * n_dst + i) * ldi + 4 * q);
+        if (accumulate) {
+            const float4 d = *dst;
+            acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+        }
+        *dst = acc;
+    }
+}
+
 static int rows_per_block_for(long rows, int C) {
     const int rpp = kTT / (C >> 2);
     long rpb = (rows + 1023) / 1024;  // ~1024 workgroups on a large problem
@@ -976,6 +1023,21 @@ extern "C" int pn2x_rows_segment_sum(int b, int n_dst, int m_src, int t, int c, 
     if (!dout || !offsets || !order || !din || (t == 3 && !weight)) return PN2_ENULL;
     if (((uintptr_t)dout | (uintptr_t)din) % 16) return PN2_EINVAL;
     const int Q = c / 4;
+    // long segments on average (>= 4 entries per destination) and a quad count that divides 256: split every segment over lanes
+    int el = 1;
+    if ((long)m_src * t >= 4L * n_dst && Q <= 64 && kTT % Q == 0) {
+        el = kTT / Q;
+        if (el > 16) el = 16;
+    }
+    if (el > 1) {
+        const int dpb = kTT / (Q * el);
+        const dim3 sgrid((unsigned)((n_dst + dpb - 1) / dpb), b);
+        if (t == 1)
+            hipLaunchKernelGGL(rows_segment_sum_split_kernel<1>, sgrid, dim3(kTT), 0, (hipStream_t)stream, n_dst, m_src, Q, el, dout, ldo, offsets, order, weight, din, ldi, accumulate);
+        else
+            hipLaunchKernelGGL(rows_segment_sum_split_kernel<3>, sgrid, dim3(kTT), 0, (hipStream_t)stream, n_dst, m_src, Q, el, dout, ldo, offsets, order, weight, din, ldi, accumulate);
+        return check_launch();
+    }
     const long total = (long)n_dst * Q;
     const dim3 grid((unsigned)((total + kTT - 1) / kTT), b);
     if (t == 1)

@@ -148,6 +148,31 @@ def test_sa_layer1_matches_grouped_reference(with_feat, with_centre, Ks, oracle)
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
 
 
+@pytest.mark.parametrize("C,weighted", [(64, False), (128, True), (256, False), (32, False), (192, False)])
+def test_rows_segment_sum_with_long_skewed_segments(C, weighted):
+    """The owner-computes row scatter (backward of the layer-1 gather / of three-NN interpolation) where some destinations
+    receive hundreds of rows (ball-query padding repeats a ball's first index): the split-segment kernel (C / 4 dividing 256,
+    >= 4 entries per destination on average) and the one-thread-per-(destination, quad) kernel vs index_add in fp64."""
+    from hotrack_amd.train_ops import inverse_index, rows_segment_sum
+    B, n_dst, M = 3, 100, 4096
+    g = torch.Generator(device="cuda").manual_seed(C)
+    t = 3 if weighted else 1
+    idx = torch.randint(0, n_dst, (B, M * t), device="cuda", generator=g, dtype=torch.int32)
+    idx[:, : M * t // 2] = idx[:, : M * t // 2] % 3          # half of all entries land on three destinations
+    idx[0, :] = 7                                             # one cloud: a single destination receives everything
+    dout = torch.randn(B, M, C, device="cuda", generator=g)
+    w = torch.rand(B, M * t, device="cuda", generator=g) if weighted else None
+    din = torch.full((B, n_dst, C), float("nan"), device="cuda")
+    rows_segment_sum(dout, inverse_index(idx, n_dst), n_dst, din, weight=w)
+    ref = torch.zeros(B, n_dst, C, device="cuda", dtype=torch.float64)
+    src = dout.double().repeat_interleave(t, dim=1)
+    if weighted:
+        src = src * w.double().unsqueeze(-1)
+    for b in range(B):
+        ref[b].index_add_(0, idx[b].long(), src[b])
+    torch.testing.assert_close(din.double(), ref, rtol=1e-5, atol=1e-3)
+
+
 def test_interpolate_rows_matches_operator_api():
     from hotrack_amd import pointnet2_utils as ops
     from hotrack_amd.train_ops import interpolate_rows
