@@ -231,7 +231,8 @@ class _SaLayer1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a1f, cadd, xyz, cxyz, n_scales, *rest):
-        idxs, wxs = rest[:n_scales], rest[n_scales:]
+        # rest: idx_i (n_scales), wx_i (n_scales), then optionally the inverted neighbour lists (offsets_i, order_i) per scale
+        idxs, wxs, invs = rest[:n_scales], rest[n_scales:2 * n_scales], rest[2 * n_scales:]
         B, N, _ = xyz.shape
         S = cxyz.shape[1]
         outs, rels = [], []
@@ -253,25 +254,26 @@ class _SaLayer1(torch.autograd.Function):
             outs.append(out)
             rels.append(rel)
             col += C1
-        ctx.save_for_backward(*idxs, *rels)
+        ctx.save_for_backward(*idxs, *rels, *invs)
         ctx.meta = (n_scales, None if a1f is None else tuple(a1f.shape), None if cadd is None else tuple(cadd.shape), S)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
         n, a1f_shape, cadd_shape, S = ctx.meta
-        idxs, rels = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        idxs, rels, invs = ctx.saved_tensors[:n], ctx.saved_tensors[n:2 * n], ctx.saved_tensors[2 * n:]
         dev = douts[0].device
         fits = a1f_shape is not None and a1f_shape[1] <= INVERSE_MAX_ROWS
         d_a1f = (torch.empty if fits else torch.zeros)(a1f_shape, dtype=_f32, device=dev) if a1f_shape is not None else None
         d_cadd = torch.empty(cadd_shape, dtype=_f32, device=dev) if cadd_shape is not None else None
         d_wx = []
         col = 0
-        for dy, idx, rel in zip(douts, idxs, rels):
+        for i, (dy, idx, rel) in enumerate(zip(douts, idxs, rels)):
             dy = dy.contiguous()
             B, SK, C1 = dy.shape
             if d_a1f is not None and fits:  # owner-computes segment sum over the inverted neighbour lists: no atomics, no pre-zeroing
-                rows_segment_sum(dy, inverse_index(idx.view(B, SK), a1f_shape[1]), a1f_shape[1], d_a1f[:, :, col:col + C1])
+                inv = (invs[2 * i], invs[2 * i + 1]) if invs else inverse_index(idx.view(B, SK), a1f_shape[1])
+                rows_segment_sum(dy, inv, a1f_shape[1], d_a1f[:, :, col:col + C1])
             elif d_a1f is not None:
                 scatter_add_rows(dy, idx.view(B, SK), d_a1f[:, :, col:col + C1])
             if d_cadd is not None:
@@ -286,14 +288,17 @@ class _SaLayer1(torch.autograd.Function):
             else:
                 d_wx.append(torch.mm(dy.view(B * SK, C1).t(), rel.view(B * SK, 3)))
             col += C1
-        return (d_a1f, d_cadd, None, None, None, *([None] * n), *d_wx)
+        return (d_a1f, d_cadd, None, None, None, *([None] * n), *d_wx, *([None] * len(invs)))
 
 
-def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs):
+def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs, invs=None):
     """Layer-1 pre-activations of every scale of one SA module: list of (B, S*K_i, C1_i).
     a1f (B,N,sum C1) per-point feature terms [scale 0 | scale 1 ...] or None; cadd (B,S,sum C1) per-centroid terms or None;
-    xyz (B,N,3), cxyz (B,S,3) (no gradient); idxs[i] (B,S,K_i) int32; wxs[i] (C1_i, 3)."""
-    return list(_SaLayer1.apply(a1f, cadd, xyz, cxyz, len(idxs), *idxs, *wxs))
+    xyz (B,N,3), cxyz (B,S,3) (no gradient); idxs[i] (B,S,K_i) int32; wxs[i] (C1_i, 3).
+    invs[i] = inverse_index(idxs[i].view(B, -1), N), computed by a caller that feeds the same neighbour lists to several modules
+    (the backward inverts them itself otherwise)."""
+    extra = [t for inv in invs for t in inv] if invs else []
+    return list(_SaLayer1.apply(a1f, cadd, xyz, cxyz, len(idxs), *idxs, *wxs, *extra))
 
 
 class _InterpRows(torch.autograd.Function):
