@@ -19,9 +19,13 @@
 // 32 x 32 (C_{i-1} = 32 NB); with fewer than 8 blocks the reduction over C_i is split across wave groups and summed in the
 // epilogue.  The C_i x C_{i-1} weight gradient is NB KB blocks (C_i = 32 KB): a wave owns NB KB / 8 of them (sharing the H
 // operand), or, with fewer than 8 blocks, a slice of the tile's 64 rows (one partial tile per slice).
-// Gradient sources: GMODE 0, the dense pre-masked g_i this kernel itself writes for the layer above; GMODE 2, the top layer of
+// Gradient sources: GMODE 0, the dense pre-masked g_i this kernel itself writes for the layer above; GMODE 1, the dense gradient
+// of a materialised top layer (ReLU mask recomputed from Y_i on load); GMODE 2, the top layer of
 // a max-pooled stack, routed on load: g_i[row] = dout[row / K] where arg[row / K] == row % K, ReLU-masked from Y_i (dout / arg
 // are K times smaller than the activation and stay in L2: the layer reads Y_i and Y_{i-1} only).
+// A layer wider than the instantiated C_i (fp1's 128 -> 384 top, sa3's 128 -> 512) runs as 2 - 4 launches over column slices of
+// layer i: every slice owns its rows of dW_i completely; the data gradient is a sum over the slices, so all but the last launch
+// write their raw partial product (raw_out) and the next one adds it (Gadd, in place) before the mask and the sums.
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
@@ -40,7 +44,10 @@ struct BwdArgs {
     const int *arg; int Kmax, kshift;  // GMODE 2: arg-max row within the group (same stride as G); kshift >= 0: Kmax = 1 << kshift
     const float *Y; int ldy;    // pre-activations of layer i
     const float *mean, *invstd, *gamma, *beta;
-    const double *sums_bwd;     // layer i: kBnRep copies of [sum(g) | sum(g xhat)]
+    const double *sums_bwd;     // layer i: kBnRep copies of [sum(g) | sum(g xhat)], each half sums_ld wide (>= C_i: a column slice)
+    int sums_ld;
+    const float *Gadd; int ldga; // partial data gradient of the other column slices of layer i, added before the mask (or null)
+    int raw_out;                 // 1: Gp receives the unmasked partial product, no sums (a later slice finishes the layer)
     const float *W; int ldw;    // (C_i x C_{i-1})
     const float *Yp; int ldyp;  // pre-activations of layer i-1 (R x C_{i-1})
     const float *mean_p, *invstd_p, *gamma_p, *beta_p;
@@ -143,13 +150,13 @@ tg_bwd_kernel(BwdArgs a) {
         for (int c = tid; c < Kd; c += kT) {
             double sa = 0.0, sb = 0.0;
             for (int r = 0; r < kBnRep; ++r) {
-                sa += a.sums_bwd[(size_t)r * 2 * Kd + c];
-                sb += a.sums_bwd[(size_t)r * 2 * Kd + Kd + c];
+                sa += a.sums_bwd[(size_t)r * 2 * a.sums_ld + c];
+                sb += a.sums_bwd[(size_t)r * 2 * a.sums_ld + a.sums_ld + c];
             }
             const float is = a.invstd[c];
             cA[c] = a.mean[c]; cA[Kd + c] = is; cA[2 * Kd + c] = a.gamma[c] * is;
             cA[3 * Kd + c] = (float)sa * inv_r; cA[4 * Kd + c] = (float)sb * inv_r;
-            if constexpr (GMODE == 2) { cA[5 * Kd + c] = a.gamma[c]; cA[6 * Kd + c] = a.beta[c]; }
+            if constexpr (GMODE != 0) { cA[5 * Kd + c] = a.gamma[c]; cA[6 * Kd + c] = a.beta[c]; }
         }
         for (int c = tid; c < N; c += kT) {
             cP[c] = a.mean_p[c]; cP[N + c] = a.invstd_p[c]; cP[2 * N + c] = a.gamma_p[c]; cP[3 * N + c] = a.beta_p[c];
@@ -196,6 +203,13 @@ tg_bwd_kernel(BwdArgs a) {
                 g1 = (par[i].y == kk && x1 * ga.y + be.y > 0.f) ? g1 : 0.f;
                 g2 = (par[i].z == kk && x2 * ga.z + be.z > 0.f) ? g2 : 0.f;
                 g3 = (par[i].w == kk && x3 * ga.w + be.w > 0.f) ? g3 : 0.f;
+            }
+            if constexpr (GMODE == 1) {
+                const float4 ga = *reinterpret_cast<const float4 *>(cA + 5 * Kd + c), be = *reinterpret_cast<const float4 *>(cA + 6 * Kd + c);
+                g0 = (x0 * ga.x + be.x > 0.f) ? g0 : 0.f;  // [relu(BN(y)) > 0], torch's evaluation order
+                g1 = (x1 * ga.y + be.y > 0.f) ? g1 : 0.f;
+                g2 = (x2 * ga.z + be.z > 0.f) ? g2 : 0.f;
+                g3 = (x3 * ga.w + be.w > 0.f) ? g3 : 0.f;
             }
             const float d0 = sc.x * (g0 - m1.x - x0 * m2.x);
             const float d1 = sc.y * (g1 - m1.y - x1 * m2.y);
@@ -314,6 +328,19 @@ tg_bwd_kernel(BwdArgs a) {
                     const float4 t = *reinterpret_cast<const float4 *>(Gs + (k * BM + r) * LDX + 4 * cq);
                     g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
                 }
+                const long row = tile * BM + r;
+                if (a.raw_out) {  // (workgroup-uniform) a column slice of a wider layer: the next slice finishes these rows
+                    if (a.Gadd && (full || row < a.R)) {
+                        const float4 t = *reinterpret_cast<const float4 *>(a.Gadd + row * a.ldga + 4 * cq);
+                        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                    }
+                    if (full || row < a.R) *reinterpret_cast<float4 *>(a.Gp + row * a.ldgp + 4 * cq) = g;
+                    continue;
+                }
+                if (a.Gadd && (full || row < a.R)) {
+                    const float4 t = *reinterpret_cast<const float4 *>(a.Gadd + row * a.ldga + 4 * cq);
+                    g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                }
                 float4 x;
                 if constexpr (kKeepX) x = xh[i];
                 else x = *reinterpret_cast<const float4 *>(Xs + r * LDX + 4 * cq);
@@ -323,7 +350,6 @@ tg_bwd_kernel(BwdArgs a) {
                 g.w = (x.w * pga.w + pbe.w > 0.f) ? g.w : 0.f;
                 cs[0] += g.x; cs[1] += g.y; cs[2] += g.z; cs[3] += g.w;   // rows beyond R: dY == 0 -> g == 0, xhat == 0
                 cqs[0] += g.x * x.x; cqs[1] += g.y * x.y; cqs[2] += g.z * x.z; cqs[3] += g.w * x.w;
-                const long row = tile * BM + r;
                 if (full || row < a.R) *reinterpret_cast<float4 *>(a.Gp + row * a.ldgp + 4 * cq) = g;
             }
         }
@@ -347,6 +373,7 @@ tg_bwd_kernel(BwdArgs a) {
             }
     }
     // BatchNorm-backward sums of layer i-1
+    if (a.raw_out) return;  // (workgroup-uniform)
     __syncthreads();
     float *redS = Gs, *redQ = Gs + P::RG * N;
 #pragma unroll
@@ -434,10 +461,25 @@ extern "C" int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, i
                            const float *yp, int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p,
                            const float *beta_p, float *gp, int ldgp, double *sums_bwd_p, float *partial, long partial_floats,
                            float *dw, void *stream) {
+    return pn2x_tg_bwd_slice(rows, n, k, gmode, g, ldg, arg, kmax, yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, n, w, ldw, yp,
+                             ldyp, mean_p, invstd_p, gamma_p, beta_p, gp, ldgp, sums_bwd_p, partial, partial_floats, dw, nullptr, 0, 0,
+                             stream);
+}
+
+// One column slice [c0, c0 + n) of a layer with sums_ld >= n channels: the caller passes g / yi / the per-channel vectors / sums_bwd_i /
+// w / dw already offset to the slice.  g_add (row stride ldga, may alias gp): the data-gradient partial of earlier slices; raw_out: leave
+// mask and sums to a later slice.
+extern "C" int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi,
+                                 int ldyi, const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i,
+                                 const double *sums_bwd_i, int sums_ld, const float *w, int ldw, const float *yp, int ldyp,
+                                 const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p, float *gp,
+                                 int ldgp, double *sums_bwd_p, float *partial, long partial_floats, float *dw, const float *g_add,
+                                 int ldga, int raw_out, void *stream) {
     Shape s;
-    if (rows < 1 || rows > 0x7fffffffL || !find_shape(k, n, s) || (gmode != 0 && gmode != 2)) return PN2_EINVAL;
+    if (rows < 1 || rows > 0x7fffffffL || !find_shape(k, n, s) || gmode < 0 || gmode > 2 || sums_ld < n) return PN2_EINVAL;
     if (gmode == 2 && (kmax < 1 || rows % kmax)) return PN2_EINVAL;
-    if (gmode == 2 && (!arg || !beta_i)) return PN2_ENULL;
+    if ((gmode == 2 && !arg) || (gmode != 0 && !beta_i)) return PN2_ENULL;
+    if (g_add && (ldga < k || ldga % 4 || (uintptr_t)g_add % 16)) return PN2_EINVAL;
     if ((uintptr_t)arg % 16) return PN2_EINVAL;
     if (ldg < n || ldg % 4 || ldyi < n || ldyi % 4 || ldw < k || ldyp < k || ldyp % 4 || ldgp < k || ldgp % 4) return PN2_EINVAL;
     if (!g || !yi || !mean_i || !invstd_i || !gamma_i || !sums_bwd_i || !w || !yp || !mean_p || !invstd_p || !gamma_p || !beta_p ||
@@ -446,7 +488,7 @@ extern "C" int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, i
     if (((uintptr_t)g | (uintptr_t)yi | (uintptr_t)yp | (uintptr_t)gp) % 16) return PN2_EINVAL;
     const int grid = grid_of(rows, s);
     if (partial_floats < (long)grid * s.ks_w * n * k) return PN2_ESCRATCH;
-    BwdArgs a{rows, g, ldg, arg, kmax, kshift_of(kmax), yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, w, ldw, yp, ldyp, mean_p, invstd_p, gamma_p, beta_p,
+    BwdArgs a{rows, g, ldg, arg, kmax, kshift_of(kmax), yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, sums_ld, g_add, ldga, raw_out ? 1 : 0, w, ldw, yp, ldyp, mean_p, invstd_p, gamma_p, beta_p,
               gp, ldgp, sums_bwd_p, partial, dw
 #ifdef PN2_TGB_PROFILE
               , g_prof
@@ -465,6 +507,7 @@ extern "C" int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, i
 #define X(NB_, KB_)                                                                                                   \
     if (nb == NB_ && kb == KB_) {                                                                                     \
         if (gmode == 0) PN2_TGB_LAUNCH(NB_, KB_, 0);                                                                  \
+        else if (gmode == 1) PN2_TGB_LAUNCH(NB_, KB_, 1);                                                             \
         else PN2_TGB_LAUNCH(NB_, KB_, 2);                                                                             \
     }
     PN2_TGB_SHAPES(X)

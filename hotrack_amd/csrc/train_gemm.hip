@@ -640,7 +640,7 @@ struct ReduceMulti {
     float *dW[kRmMax];
     const double *sums[kRmMax];
     float *dgamma[kRmMax], *dbeta[kRmMax], *dbias[kRmMax];
-    int P[kRmMax], numel[kRmMax], N[kRmMax], ps[kRmMax];
+    int P[kRmMax], numel[kRmMax], N[kRmMax], ps[kRmMax], sld[kRmMax];  // sld: channels of the whole layer (N: of this column slice)
     int block_start[kRmMax + 1];
     int n;
 };
@@ -676,9 +676,10 @@ tg_reduce_multi_kernel(ReduceMulti a) {
     const int c = bx * kT + threadIdx.x;
     if (by == 0 && c < N && a.sums[t]) {
         double sa = 0.0, sb = 0.0;
+        const int sld = a.sld[t];
         for (int r = 0; r < kBnRep; ++r) {
-            sa += a.sums[t][(size_t)r * 2 * N + c];
-            sb += a.sums[t][(size_t)r * 2 * N + N + c];
+            sa += a.sums[t][(size_t)r * 2 * sld + c];
+            sb += a.sums[t][(size_t)r * 2 * sld + sld + c];
         }
         a.dbeta[t][c] = (float)sa;
         a.dgamma[t][c] = (float)sb;
@@ -850,6 +851,14 @@ extern "C" int pn2x_tg_wgrad2(long rows, int n, int k, int gmode, const float *g
 extern "C" int pn2x_tg_reduce_multi(int count, const float *const *partial, const int *n_partials, const int *numel, float *const *dw,
                                     const double *const *sums_bwd, const int *channels, float *const *dgamma, float *const *dbeta,
                                     float *const *dbias, void *stream) {
+    return pn2x_tg_reduce_multi2(count, partial, n_partials, numel, dw, sums_bwd, channels, nullptr, dgamma, dbeta, dbias, stream);
+}
+
+// sums_ld (may be NULL: = channels): entry j is a column slice of a layer with sums_ld[j] channels (sums_bwd[j], dgamma[j], dbeta[j],
+// dbias[j], dw[j] already offset to the slice)
+extern "C" int pn2x_tg_reduce_multi2(int count, const float *const *partial, const int *n_partials, const int *numel, float *const *dw,
+                                     const double *const *sums_bwd, const int *channels, const int *sums_ld, float *const *dgamma,
+                                     float *const *dbeta, float *const *dbias, void *stream) {
     if (count < 0) return PN2_EINVAL;
     if (count == 0) return PN2_OK;
     if (!partial || !n_partials || !numel || !dw || !sums_bwd || !channels || !dgamma || !dbeta || !dbias) return PN2_ENULL;
@@ -864,6 +873,8 @@ extern "C" int pn2x_tg_reduce_multi(int count, const float *const *partial, cons
             a.partial[i] = partial[j]; a.dW[i] = dw[j]; a.sums[i] = sums_bwd[j];
             a.dgamma[i] = dgamma[j]; a.dbeta[i] = dbeta[j]; a.dbias[i] = dbias[j];
             a.P[i] = n_partials[j]; a.numel[i] = numel[j]; a.N[i] = channels[j];
+            a.sld[i] = sums_ld ? sums_ld[j] : channels[j];
+            if (a.sld[i] < channels[j]) return PN2_EINVAL;
             int ps = a.P[i] / 32;
             if (ps < 1) ps = 1;
             if (ps > 64) ps = 64;

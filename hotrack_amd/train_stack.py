@@ -56,6 +56,26 @@ _lib.pn2x_tg_bwd_partials.argtypes = [_cl, _ci, _ci]
 _lib.pn2x_tg_bwd_partials.restype = _ci
 _lib.pn2x_tg_bwd.argtypes = [_cl, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp,
                              _vp, _vp, _ci, _vp, _vp, _cl, _vp, _vp]
+_lib.pn2x_tg_bwd_slice.argtypes = [_cl, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp,
+                                   _vp, _vp, _vp, _ci, _vp, _vp, _cl, _vp, _vp, _ci, _ci, _vp]
+_lib.pn2x_tg_bwd_slice.restype = _ci
+_lib.pn2x_tg_reduce_multi2.argtypes = [_ci, ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_vp),
+                                       ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_vp),
+                                       ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]
+_lib.pn2x_tg_reduce_multi2.restype = _ci
+
+
+def _bwd_slices(c_in: int, c_out: int):
+    """Column slices [(offset, width)] of layer i the one-kernel backward runs as (one slice where (c_in, c_out) is instantiated,
+    2 - 4 slices of 192 / 128 columns for wider layers), or None."""
+    if _lib.pn2x_tg_bwd_supported(c_in, c_out):
+        return [(0, c_out)]
+    for w in (192, 128):
+        if c_out % w == 0 and 2 <= c_out // w <= 4 and _lib.pn2x_tg_bwd_supported(c_in, w):
+            return [(j * w, w) for j in range(c_out // w)]
+    return None
+
+
 _lib.pn2x_bn_bwd_reduce_routed.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_bn_bwd_reduce_routed.restype = _ci
 _lib.pn2x_tg_bwd.restype = _ci
@@ -99,16 +119,18 @@ def _reduce_items(items):
     n = len(items)
     arr = lambda: (_vp * n)()
     part, dw, sm, dg, db, dbi = arr(), arr(), arr(), arr(), arr(), arr()
-    P, numel, ch = (_ci * n)(), (_ci * n)(), (_ci * n)()
-    for j, (partial, np_, dwt, sums, dpar, _st) in enumerate(items):
+    P, numel, ch, sld = (_ci * n)(), (_ci * n)(), (_ci * n)(), (_ci * n)()
+    for j, it in enumerate(items):
+        partial, np_, dwt, sums, dpar, _st = it[:6]
         part[j], dw[j], sm[j] = partial.data_ptr(), dwt.data_ptr(), sums.data_ptr()
         dg[j], db[j], dbi[j] = dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr()
         P[j], numel[j], ch[j] = np_, dwt.numel(), dwt.shape[0]
+        sld[j] = it[6] if len(it) > 6 else dwt.shape[0]  # channels of the whole layer when dwt is a column slice of it
     st = items[0][5]
     if any(it[5] != st for it in items):
         raise RuntimeError("train_stack: deferred reductions recorded on different streams")
     with torch.cuda.device(items[0][2].device):
-        _native._check(_lib.pn2x_tg_reduce_multi(n, part, P, numel, dw, sm, ch, dg, db, dbi, st), "tg_reduce_multi")
+        _native._check(_lib.pn2x_tg_reduce_multi2(n, part, P, numel, dw, sm, ch, sld, dg, db, dbi, st), "tg_reduce_multi")
 
 
 _lib.pn2x_bn_bwd_apply.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
@@ -224,7 +246,7 @@ class _Stack(torch.autograd.Function):
             g, gmode = dout, (2 if K else 1)
             g_dense = None
             wl = tensors[4 * (L - 1)]
-            routed = (K and L > 1 and FUSED_BWD and ROUTE_ON_LOAD and _lib.pn2x_tg_bwd_supported(wl.shape[1], wl.shape[0]))
+            routed = bool(K and L > 1 and FUSED_BWD and ROUTE_ON_LOAD and _bwd_slices(wl.shape[1], wl.shape[0]))
             if routed:
                 # the routed gradient is non-zero in one row per (group, channel): the sums need the arg-max rows only, and the
                 # one-kernel layer backward below routes dout on load (no rows x C gradient tensor at all)
@@ -253,21 +275,25 @@ class _Stack(torch.autograd.Function):
                 dw = torch.empty((N, Kc), dtype=_f32, device=dev)
                 dpar = torch.empty((3, N), dtype=_f32, device=dev)
                 gp = torch.empty((R, Kc), dtype=_f32, device=dev)
-                if FUSED_BWD and (gmode == 0 or (gmode == 2 and routed)) and _lib.pn2x_tg_bwd_supported(Kc, N):
-                    np_ = int(_lib.pn2x_tg_bwd_partials(R, N, Kc))
-                    partial = torch.empty(np_ * N * Kc, dtype=_f32, device=dev)
-                    _native._check(_lib.pn2x_tg_bwd(R, N, Kc, gmode, g.data_ptr(), g.stride(0), _p(arg) if gmode == 2 else None,
-                                                    K if gmode == 2 else 1, yi.data_ptr(), yi.stride(0), svi[0].data_ptr(),
-                                                    svi[1].data_ptr(), gam(i).data_ptr(), bet(i).data_ptr(), sums[i].data_ptr(),
-                                                    wc.data_ptr(), wc.stride(0),
-                                                    yp.data_ptr(), yp.stride(0), svp[0].data_ptr(), svp[1].data_ptr(),
-                                                    gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), gp.data_ptr(), Kc, sums[i - 1].data_ptr(),
-                                                    partial.data_ptr(), partial.numel(), dw.data_ptr(), st), "tg_bwd")
-                    item = (partial, np_, dw, sums[i], dpar, st)
-                    if defer:
-                        _defer(item)
-                    else:
-                        _pending_now(item)
+                slices = _bwd_slices(Kc, N) if (FUSED_BWD and (gmode != 2 or routed)) else None
+                if slices:
+                    for j, (off, wd) in enumerate(slices):  # (one slice unless the layer is wider than the instantiated kernels)
+                        np_ = int(_lib.pn2x_tg_bwd_partials(R, wd, Kc))
+                        partial = torch.empty(np_ * wd * Kc, dtype=_f32, device=dev)
+                        o4 = 4 * off
+                        _native._check(_lib.pn2x_tg_bwd_slice(
+                            R, wd, Kc, gmode, g.data_ptr() + o4, g.stride(0), (arg.data_ptr() + o4) if gmode == 2 else None,
+                            K if gmode == 2 else 1, yi.data_ptr() + o4, yi.stride(0), svi[0].data_ptr() + o4, svi[1].data_ptr() + o4,
+                            gam(i).data_ptr() + o4, bet(i).data_ptr() + o4, sums[i].data_ptr() + 8 * off, N,
+                            wc.data_ptr() + o4 * wc.stride(0), wc.stride(0), yp.data_ptr(), yp.stride(0), svp[0].data_ptr(),
+                            svp[1].data_ptr(), gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), gp.data_ptr(), Kc, sums[i - 1].data_ptr(),
+                            partial.data_ptr(), partial.numel(), dw.data_ptr() + o4 * Kc, gp.data_ptr() if j else None, Kc,
+                            1 if j + 1 < len(slices) else 0, st), "tg_bwd")
+                        item = (partial, np_, dw[off:off + wd], sums[i][off:], dpar[:, off:off + wd], st, N)
+                        if defer:
+                            _defer(item)
+                        else:
+                            _pending_now(item)
                     grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = dw.view(w_shape), dpar[0], dpar[1]
                     if ctx.has_bias[i]:
                         grads[4 * i + 3] = dpar[2]

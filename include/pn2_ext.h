@@ -467,6 +467,10 @@ int pn2x_tg_wgrad2(long rows, int n, int k, int gmode, const float *g, int ldg, 
 int pn2x_tg_reduce_multi(int count, const float *const *partial, const int *n_partials, const int *numel, float *const *dw,
                          const double *const *sums_bwd, const int *channels, float *const *dgamma, float *const *dbeta,
                          float *const *dbias, void *stream);
+/* ... with entries that are column slices of a wider layer: sums_ld[j] = channels of the whole layer (NULL: = channels[j]) */
+int pn2x_tg_reduce_multi2(int count, const float *const *partial, const int *n_partials, const int *numel, float *const *dw,
+                          const double *const *sums_bwd, const int *channels, const int *sums_ld, float *const *dgamma,
+                          float *const *dbeta, float *const *dbias, void *stream);
 /* pn2x_tg_fwd with a different schedule for 64- / 128-channel inputs (csrc/train_fwd.hip: W_i resident in LDS, 64-row tiles whose
  * normalised operand is built once, one 32 x 32 output block per wave).  Same arguments and results (up to summation order). */
 int pn2x_tg_fwd2_supported(int c_in, int c_out);
@@ -477,10 +481,18 @@ int pn2x_tg_fwd2(long rows, int k, int n, const float *x, int ldx, const float *
 
 /* The whole backward of fused layer i in one kernel (csrc/train_bwd.hip): g_{i-1} (gp, with the ReLU mask and the
  * BatchNorm-backward sums of layer i-1, as pn2x_tg_dgrad) AND the weight-gradient partial tiles (as pn2x_tg_wgrad2 with
- * n_partials) from one pass over g_i, Y_i and Y_{i-1}.  gmode 0: g pre-masked (rows x n); gmode 2: g = d(max over kmax
+ * n_partials) from one pass over g_i, Y_i and Y_{i-1}.  gmode 0: g pre-masked (rows x n); gmode 1: g dense, ReLU-masked from Y_i on load; gmode 2: g = d(max over kmax
  * rows) ((rows / kmax) x n) routed on load through arg (same shape / stride) and ReLU-masked from Y_i.  n = channels of layer i, k = channels of layer
  * i-1; w (n x k).  pn2x_tg_bwd_supported(k, n): k in {32, 64, 128} and the instantiated n; pn2x_tg_bwd_partials = the number
  * of (n x k) partial tiles written (partial_floats >= that * n * k), to be summed by pn2x_tg_reduce_multi.  dw is zeroed. */
+/* pn2x_tg_bwd_slice: one column slice [c0, c0 + n) of a layer with sums_ld channels (all layer-i pointers offset to the slice by the
+ * caller).  A wider layer runs as consecutive slices: raw_out = 1 leaves the unmasked partial data gradient in gp, the next slice
+ * passes it as g_add (may alias gp) and the last one applies the mask and accumulates the sums.  gmode 1: dense g, masked from Y_i. */
+int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi, int ldyi,
+                      const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i, const double *sums_bwd_i,
+                      int sums_ld, const float *w, int ldw, const float *yp, int ldyp, const float *mean_p, const float *invstd_p,
+                      const float *gamma_p, const float *beta_p, float *gp, int ldgp, double *sums_bwd_p, float *partial,
+                      long partial_floats, float *dw, const float *g_add, int ldga, int raw_out, void *stream);
 int pn2x_tg_bwd_supported(int c_in, int c_out);
 int pn2x_tg_bwd_partials(long rows, int c_out, int c_in);
 int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi, int ldyi,

@@ -416,6 +416,9 @@ def test_mlp_stack_second_backward_and_stale_workspace():
     (8 * 777, [128, 128, 128, 64, 32], 8),
     (24 * 301, [64, 64, 128], 24),       # groups of 24 rows (not a power of two) straddle the 64-row tiles
     (64 * 150, [128, 128, 192], 64),
+    (5000, [128, 128, 384], 0),          # dense top (mask recomputed on load), 384 = two column slices of 192
+    (128 * 40, [128, 128, 512], 128),    # routed top over four column slices of 128
+    (3000, [64, 64, 128], 0),
 ])
 def test_mlp_stack_one_kernel_layer_backward_equals_two_kernel_backward(R, widths, K):
     """csrc/train_bwd.hip (data + weight gradient of a layer from one pass) vs the tg_dgrad / tg_wgrad pair on the same
@@ -431,10 +434,10 @@ def test_mlp_stack_one_kernel_layer_backward_equals_two_kernel_backward(R, width
             bn.bias.copy_(0.2 * torch.randn(bn.bias.shape, device="cuda", generator=g))
     params = [p for m in convs + bns for p in m.parameters()]
     y1 = torch.randn(R, widths[0], device="cuda", generator=g) * 1.3 + 0.2
-    go = torch.randn(R // K, widths[-1], device="cuda", generator=g)
+    go = torch.randn(R // K if K else R, widths[-1], device="cuda", generator=g)
     ws = Workspace("cuda")
     for a, b in zip(widths[:-1], widths[1:]):
-        assert train_stack._lib.pn2x_tg_bwd_supported(a, b)
+        assert train_stack._bwd_slices(a, b)
 
     def run(fused):
         old = train_stack.FUSED_BWD
