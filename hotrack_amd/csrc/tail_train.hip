@@ -282,6 +282,82 @@ tail_relu_drop_bwd_kernel(long rows, int c, const float *__restrict__ z, const f
 
 static int epl_of(int c) { return c <= 128 ? 2 : (c <= 256 ? 4 : (c <= 512 ? 8 : (c <= 1024 ? 16 : 0))); }
 
+// ---- the last Conv1d of final_mlp + residual on the initial keypoints + de-canonicalisation (hand_network.py:141-147) ---------
+// forward: one wave per token (b, j).  kp_hand[b, :, j] = h[tok] . w^T + bias + xyz1[b, :, j]  (B, 3, J), channel-major as the
+// reference's tensors; kp_cam[b, j, :] = scale[b] R_b kp_hand[b, :, j] + t_b  (B, J, 3).  Replaces a GEMM with a 3-wide output, the
+// residual add, a batched 3 x 3 matmul, scale / translate and two layout copies (8 launches); the same for its backward (6).
+__global__ void __launch_bounds__(256)
+pose_head_fwd_kernel(int tokens, int j, int c, const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ bias,
+                     const float *__restrict__ xyz1, const float *__restrict__ R, const float *__restrict__ t,
+                     const float *__restrict__ scale, float *__restrict__ kp_hand, float *__restrict__ kp_cam) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= tokens) return;
+    const int lane = threadIdx.x & 63;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int ch = lane; ch < c; ch += 64) {
+        const float hv = h[(size_t)tok * c + ch];
+        a0 = fmaf(hv, w[ch], a0);
+        a1 = fmaf(hv, w[c + ch], a1);
+        a2 = fmaf(hv, w[2 * c + ch], a2);
+    }
+    a0 = wsum(a0); a1 = wsum(a1); a2 = wsum(a2);
+    if (lane == 0) {
+        const int b = tok / j, jj = tok - b * j;
+        const float *x = xyz1 + (size_t)b * 3 * j + jj;
+        float *o = kp_hand + (size_t)b * 3 * j + jj;
+        const float px = a0 + bias[0] + x[0], py = a1 + bias[1] + x[j], pz = a2 + bias[2] + x[2 * j];
+        o[0] = px; o[j] = py; o[2 * j] = pz;
+        const float *Rb = R + 9 * b, *tb = t + 3 * b;
+        const float sc = scale[b];
+        kp_cam[3 * tok] = sc * (Rb[0] * px + Rb[1] * py + Rb[2] * pz) + tb[0];  // scale * (R p) + t, decanonicalize's order
+        kp_cam[3 * tok + 1] = sc * (Rb[3] * px + Rb[4] * py + Rb[5] * pz) + tb[1];
+        kp_cam[3 * tok + 2] = sc * (Rb[6] * px + Rb[7] * py + Rb[8] * pz) + tb[2];
+    }
+}
+
+// backward: g = d kp_hand (B, 3, J) [+ scale R^T d kp_cam].  A workgroup takes 32 tokens, a thread one input channel:
+// dh[tok, ch] = sum_i g_i w[i, ch];  dw[i, ch] += sum_tok g_i h[tok, ch], dbias[i] += sum_tok g_i  (zero-filled accumulators).
+__global__ void __launch_bounds__(256)
+pose_head_bwd_kernel(int tokens, int j, int c, const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ g_hand,
+                     const float *__restrict__ g_cam, const float *__restrict__ R, const float *__restrict__ scale,
+                     float *__restrict__ dh, float *__restrict__ dw, float *__restrict__ dbias) {
+    __shared__ float gs[32][3];
+    const int tok0 = blockIdx.x * 32;
+    if (threadIdx.x < 96) {
+        const int tl = threadIdx.x / 3, i = threadIdx.x % 3, tok = tok0 + tl;
+        float g = 0.f;
+        if (tok < tokens) {
+            const int b = tok / j, jj = tok - b * j;
+            g = g_hand ? g_hand[(size_t)b * 3 * j + (size_t)i * j + jj] : 0.f;
+            if (g_cam) {
+                const float *Rb = R + 9 * b, *gc = g_cam + 3 * (size_t)tok;
+                g += scale[b] * (Rb[i] * gc[0] + Rb[3 + i] * gc[1] + Rb[6 + i] * gc[2]);
+            }
+        }
+        gs[tl][i] = g;
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        const float w0 = w[ch], w1 = w[c + ch], w2 = w[2 * c + ch];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int tl = 0; tl < 32 && tok0 + tl < tokens; ++tl) {
+            const float g0 = gs[tl][0], g1 = gs[tl][1], g2 = gs[tl][2];
+            const size_t o = (size_t)(tok0 + tl) * c + ch;
+            dh[o] = g0 * w0 + g1 * w1 + g2 * w2;
+            const float hv = h[o];
+            a0 += g0 * hv; a1 += g1 * hv; a2 += g2 * hv;
+        }
+        atomicAdd(dw + ch, a0);
+        atomicAdd(dw + c + ch, a1);
+        atomicAdd(dw + 2 * c + ch, a2);
+    }
+    if (threadIdx.x < 3) {
+        float s = 0.f;
+        for (int tl = 0; tl < 32; ++tl) s += gs[tl][threadIdx.x];
+        atomicAdd(dbias + threadIdx.x, s);
+    }
+}
+
 }  // namespace tt
 }  // namespace pn2
 
@@ -349,5 +425,27 @@ extern "C" int pn2x_tail_relu_drop_bwd(long rows, int c, const float *z, const f
     if (((uintptr_t)z | (uintptr_t)dh | (uintptr_t)dz | (uintptr_t)bias) % 16) return PN2_EINVAL;
     hipLaunchKernelGGL(tail_relu_drop_bwd_kernel, dim3((unsigned)((rows + 15) / 16), (unsigned)((c + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        rows, c, z, bias, p, (unsigned)site, seed_in, dh, dz, dbias);
+    return check_launch();
+}
+
+extern "C" int pn2x_tail_pose_head_fwd(int b, int j, int c, const float *h, const float *w, const float *bias, const float *xyz1,
+                                       const float *R, const float *t, const float *scale, float *kp_hand, float *kp_cam, void *stream) {
+    if (b < 0 || j < 1 || c < 1) return PN2_EINVAL;
+    if (b == 0) return PN2_OK;
+    if (!h || !w || !bias || !xyz1 || !R || !t || !scale || !kp_hand || !kp_cam) return PN2_ENULL;
+    const int tokens = b * j;
+    hipLaunchKernelGGL(pose_head_fwd_kernel, dim3((tokens + 3) / 4), dim3(256), 0, (hipStream_t)stream, tokens, j, c, h, w, bias, xyz1, R,
+                       t, scale, kp_hand, kp_cam);
+    return check_launch();
+}
+
+extern "C" int pn2x_tail_pose_head_bwd(int b, int j, int c, const float *h, const float *w, const float *g_hand, const float *g_cam,
+                                       const float *R, const float *scale, float *dh, float *dw, float *dbias, void *stream) {
+    if (b < 0 || j < 1 || c < 1) return PN2_EINVAL;
+    if (b == 0) return PN2_OK;
+    if (!h || !w || !dh || !dw || !dbias || (!g_hand && !g_cam) || (g_cam && (!R || !scale))) return PN2_ENULL;
+    const int tokens = b * j;
+    hipLaunchKernelGGL(pose_head_bwd_kernel, dim3((tokens + 31) / 32), dim3(256), 0, (hipStream_t)stream, tokens, j, c, h, w, g_hand, g_cam,
+                       R, scale, dh, dw, dbias);
     return check_launch();
 }

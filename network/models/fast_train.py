@@ -271,7 +271,7 @@ class FastTail:
         if self.seed is None or self.seed.device != dev:
             self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
         seed_used = torch.empty(1, dtype=torch.int64, device=dev)
-        grads = T.TailGrads(dev, 14 * C + 2 * H + Hf)
+        grads = T.TailGrads(dev, 14 * C + 2 * H + Hf + 3 * Hf + 3)
         pd = lambda m: float(m.p) if m.training else 0.0
         h = T.ln(rows, s11.norm1, c11.norm1, grads, seed_dev=self.seed, seed_out=seed_used)
         d = T.relu_dropout(F.linear(h, c11.linear1.weight), c11.linear1.bias, pd(c11.dropout2), 1, seed_used, grads)
@@ -279,6 +279,6 @@ class FastTail:
         d2 = T.relu_dropout(F.linear(h2, c3.linear1.weight), c3.linear1.bias, pd(c3.dropout2), 3, seed_used, grads)
         h3 = T.ln(h2, c3.norm2, None, grads, y=F.linear(d2, c3.linear2.weight), bias=c3.linear2.bias, p=pd(c3.dropout3), site=4, seed_in=seed_used)
         hf = T.relu_dropout(F.linear(h3, net.final_mlp[0].weight.squeeze(-1)), net.final_mlp[0].bias, 0.0, 0, None, grads)
-        delta = F.linear(hf, net.final_mlp[2].weight.squeeze(-1), net.final_mlp[2].bias)     # (B*J, 3)
-        pred_hf = delta.view(B, J, 3).transpose(1, 2) + xyz1
-        return pred_hf, decanonicalize(pred_hf, canon_pose).transpose(2, 1)
+        # last Conv1d + residual on the initial keypoints + de-canonicalisation: one launch per direction
+        return T.pose_head(hf, net.final_mlp[2].weight.squeeze(-1), net.final_mlp[2].bias, xyz1, canon_pose["rotation"],
+                           canon_pose["translation"], canon_pose["scale"], grads)

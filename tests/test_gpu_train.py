@@ -695,7 +695,8 @@ def test_fast_tail_equals_module_tail():
     B, J, C = 5, 21, 384
     rows = torch.randn(B * J, C, device="cuda", generator=g)
     xyz1 = torch.randn(B, 3, J, device="cuda", generator=g)
-    canon = {"scale": 0.2 * torch.ones(1, device="cuda"), "rotation": torch.eye(3, device="cuda").repeat(B, 1, 1), "translation": torch.randn(B, 3, 1, device="cuda", generator=g)}
+    rot = torch.linalg.qr(torch.randn(B, 3, 3, device="cuda", generator=g))[0]
+    canon = {"scale": 0.2 * torch.ones(1, device="cuda"), "rotation": rot, "translation": torch.randn(B, 3, 1, device="cuda", generator=g)}
     assert FastTail.supported(net)
     res = {}
     for fast in (True, False):
@@ -710,7 +711,8 @@ def test_fast_tail_equals_module_tail():
             lin = lambda conv, x: F.linear(x.transpose(1, 2), conv.weight.squeeze(-1), conv.bias).transpose(1, 2)
             hf = lin(net.final_mlp[2], F.relu(lin(net.final_mlp[0], fused))) + xyz1
             kp = decanonicalize(hf, canon).transpose(2, 1)
-        ((hf * torch.cos(torch.arange(hf.numel(), device="cuda").view_as(hf) * 0.1)).sum() + kp.sum()).backward()
+        ((hf * torch.cos(torch.arange(hf.numel(), device="cuda").view_as(hf) * 0.1)).sum()
+         + (kp * torch.sin(torch.arange(kp.numel(), device="cuda").view_as(kp) * 0.3)).sum()).backward()
         res[fast] = (hf.detach(), kp.detach(), r_.grad, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
     a, b = res[True], res[False]
     torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-5)
