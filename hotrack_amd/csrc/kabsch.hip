@@ -203,7 +203,8 @@ constexpr int kHlChunk = 128;  // clouds per pass of the single workgroup
 __global__ void __launch_bounds__(1024)
 hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const float *__restrict__ init_hf, const float *__restrict__ gt_kp,
                      const float *__restrict__ pred_kp, const float *__restrict__ Rc, const float *__restrict__ tc, float s,
-                     const float *__restrict__ palm, float *__restrict__ out, float *__restrict__ saved) {
+                     const float *__restrict__ palm, float *__restrict__ out, float *__restrict__ saved,
+                     const float *__restrict__ weights) {
     // saved per cloud: [0:63) gt_s (3,21 channel-major) | [63:72) R | [72:75) t | [75:84) R_gt | [84:87) t_gt
     // One workgroup of 16 waves, clouds in passes of 128: (1) a wave per cloud with lanes 0..20 = the keypoints (all loads of a cloud
     // in flight together), palm points to LDS; (2) 2 x 128 threads each solve ONE rigid fit (ground truth / predicted) -- all fits of a
@@ -286,18 +287,34 @@ hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const flo
     __syncthreads();
     if (threadIdx.x < 9) {
         const float denom[9] = {(float)B * 63.f, (float)B * 9.f, (float)B * 3.f, (float)B * 21.f, (float)B * 21.f, (float)B, (float)B, (float)B, (float)B};
-        out[threadIdx.x] = acc[threadIdx.x] / denom[threadIdx.x];
+        const float v = acc[threadIdx.x] / denom[threadIdx.x];
+        out[threadIdx.x] = v;
+        if (weights) acc[threadIdx.x] = v * weights[threadIdx.x];
+    }
+    if (weights) {  // out[9] = sum_i weights[i] out[i]: the trainer's weighted total (trainer.py:157-165) without further launches
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+            for (int i = 0; i < 9; ++i) tot += acc[i];
+            out[9] = tot;
+        }
     }
 }
 
 // d(sum_i w_i out[i], i < 3) / d pred_hf, w = (dL/d kp_loss, dL/d r_loss, dL/d t_loss) read from the device (grad (3,))
 __global__ void __launch_bounds__(64)
 hand_loss_bwd_kernel(int B, int pb, const float *__restrict__ pred_hf, float s, const float *__restrict__ palm,
-                     const float *__restrict__ saved, const float *__restrict__ grad, float *__restrict__ d_pred_hf) {
+                     const float *__restrict__ saved, const float *__restrict__ grad, float *__restrict__ d_pred_hf,
+                     const float *__restrict__ grad_total, const float *__restrict__ weights) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
     const float *sv = saved + 87 * (size_t)b;
-    const float wk = grad[0] / ((float)B * 63.f), wr = grad[1] / ((float)B * 9.f), wt = grad[2] / ((float)B * 3.f);
+    // dL/d out[i] = grad[i] (+ dL/d total * weights[i])
+    const float gt_ = grad_total ? grad_total[0] : 0.f;
+    const float g0 = (grad ? grad[0] : 0.f) + (grad_total ? gt_ * weights[0] : 0.f);
+    const float g1 = (grad ? grad[1] : 0.f) + (grad_total ? gt_ * weights[1] : 0.f);
+    const float g2 = (grad ? grad[2] : 0.f) + (grad_total ? gt_ * weights[2] : 0.f);
+    const float wk = g0 / ((float)B * 63.f), wr = g1 / ((float)B * 9.f), wt = g2 / ((float)B * 3.f);
     float *d = d_pred_hf + (size_t)b * 63;
     auto sgn = [](float v) { return (float)((v > 0.f) - (v < 0.f)); };
     for (int e = 0; e < 63; ++e) d[e] = wk * sgn(pred_hf[(size_t)b * 63 + e] * s - sv[e]) * s;
@@ -388,19 +405,33 @@ extern "C" int pn2x_kabsch_backward(int b, int xb, int num, const float *x, cons
 
 extern "C" int pn2x_hand_losses(int b, int pb, const float *pred_hf, const float *init_hf, const float *gt_kp, const float *pred_kp,
                                 const float *R, const float *t, float scale, const float *palm, float *out, float *saved, void *stream) {
+    return pn2x_hand_losses2(b, pb, pred_hf, init_hf, gt_kp, pred_kp, R, t, scale, palm, out, saved, nullptr, stream);
+}
+
+// weights (9) != NULL: out has TEN entries, out[9] = sum_i weights[i] out[i]
+extern "C" int pn2x_hand_losses2(int b, int pb, const float *pred_hf, const float *init_hf, const float *gt_kp, const float *pred_kp,
+                                 const float *R, const float *t, float scale, const float *palm, float *out, float *saved,
+                                 const float *weights, void *stream) {
     if (b < 1 || !(pb == 1 || pb == b) || !(scale > 0.f)) return PN2_EINVAL;
     if (!pred_hf || !init_hf || !gt_kp || !pred_kp || !R || !t || !palm || !out || !saved) return PN2_ENULL;
     hipLaunchKernelGGL(pn2::hand_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, b, pb, pred_hf, init_hf, gt_kp, pred_kp, R, t,
-                       scale, palm, out, saved);
+                       scale, palm, out, saved, weights);
     return pn2::check_launch();
 }
 
 extern "C" int pn2x_hand_losses_backward(int b, int pb, const float *pred_hf, float scale, const float *palm, const float *saved,
                                          const float *grad3, float *d_pred_hf, void *stream) {
+    return pn2x_hand_losses_backward2(b, pb, pred_hf, scale, palm, saved, grad3, nullptr, nullptr, d_pred_hf, stream);
+}
+
+// dL/d out[i] = grad3[i] (grad3 may be NULL) + grad_total[0] * weights[i] (grad_total may be NULL; weights as given to the forward)
+extern "C" int pn2x_hand_losses_backward2(int b, int pb, const float *pred_hf, float scale, const float *palm, const float *saved,
+                                          const float *grad3, const float *grad_total, const float *weights, float *d_pred_hf,
+                                          void *stream) {
     if (b < 1 || !(pb == 1 || pb == b) || !(scale > 0.f)) return PN2_EINVAL;
-    if (!pred_hf || !palm || !saved || !grad3 || !d_pred_hf) return PN2_ENULL;
+    if (!pred_hf || !palm || !saved || !d_pred_hf || (!grad3 && !grad_total) || (grad_total && !weights)) return PN2_ENULL;
     hipLaunchKernelGGL(pn2::hand_loss_bwd_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, b, pb, pred_hf, scale, palm, saved,
-                       grad3, d_pred_hf);
+                       grad3, d_pred_hf, grad_total, weights);
     return pn2::check_launch();
 }
 

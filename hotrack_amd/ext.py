@@ -485,6 +485,10 @@ _lib.pn2x_hand_losses.argtypes = [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, ctypes
 _lib.pn2x_hand_losses.restype = _ci
 _lib.pn2x_hand_losses_backward.argtypes = [_ci, _ci, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_hand_losses_backward.restype = _ci
+_lib.pn2x_hand_losses2.argtypes = _lib.pn2x_hand_losses.argtypes[:-1] + [_vp, _vp]
+_lib.pn2x_hand_losses2.restype = _ci
+_lib.pn2x_hand_losses_backward2.argtypes = [_ci, _ci, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_hand_losses_backward2.restype = _ci
 HAND_LOSS_NAMES = ("hand_pred_kp_loss", "hand_pred_r_loss", "hand_pred_t_loss", "hand_pred_kp_diff", "hand_init_kp_diff",
                    "hand_init_r_diff", "hand_init_t_diff", "hand_pred_r_diff", "hand_pred_t_diff")
 
@@ -495,33 +499,45 @@ class HandLosses(torch.autograd.Function):
     fit -- the closed-form Kabsch gradient), the rest are metrics."""
 
     @staticmethod
-    def forward(ctx, pred_hf, init_hf, gt_kp, pred_kp, R, t, scale, palm):
+    def forward(ctx, pred_hf, init_hf, gt_kp, pred_kp, R, t, scale, palm, weights=None):
+        # weights (9,) on the device: also returns sum_i weights[i] out[i] as a second (0-dim) output (the trainer's weighted
+        # total, trainer.py:157-165) -- no multiply / sum launches, and its gradient goes straight into the backward kernel
         f32 = torch.float32
         B = pred_hf.shape[0]
+        ctx.set_materialize_grads(False)
         pred_hf = pred_hf.contiguous()
         palm = palm.contiguous().float()
         if palm.dim() == 2:
             palm = palm.unsqueeze(0)
         args = [x.detach().contiguous().float() for x in (init_hf, gt_kp, pred_kp, R, t)]
-        out = torch.empty(9, dtype=f32, device=pred_hf.device)
+        out = torch.empty(10, dtype=f32, device=pred_hf.device)
         saved = torch.empty((B, 87), dtype=f32, device=pred_hf.device)
+        wptr = None if weights is None else _native._ptr(weights, "weights", f32, 9)
         with torch.cuda.device(pred_hf.device):
-            _native._check(_lib.pn2x_hand_losses(B, palm.shape[0], _native._ptr(pred_hf, "pred_hf", f32, B * 63), _native._ptr(args[0], "init_hf", f32, B * 63),
-                                                 _native._ptr(args[1], "gt_kp", f32, B * 63), _native._ptr(args[2], "pred_kp", f32, B * 63),
-                                                 _native._ptr(args[3], "R", f32, B * 9), _native._ptr(args[4], "t", f32, B * 3), float(scale),
-                                                 _native._ptr(palm, "palm", f32, palm.shape[0] * 18), out.data_ptr(), saved.data_ptr(),
-                                                 _native._stream(pred_hf)), "hand_losses")
-        ctx.save_for_backward(pred_hf, palm, saved)
+            _native._check(_lib.pn2x_hand_losses2(B, palm.shape[0], _native._ptr(pred_hf, "pred_hf", f32, B * 63), _native._ptr(args[0], "init_hf", f32, B * 63),
+                                                  _native._ptr(args[1], "gt_kp", f32, B * 63), _native._ptr(args[2], "pred_kp", f32, B * 63),
+                                                  _native._ptr(args[3], "R", f32, B * 9), _native._ptr(args[4], "t", f32, B * 3), float(scale),
+                                                  _native._ptr(palm, "palm", f32, palm.shape[0] * 18), out.data_ptr(), saved.data_ptr(), wptr,
+                                                  _native._stream(pred_hf)), "hand_losses")
+        ctx.save_for_backward(pred_hf, palm, saved, *([weights] if weights is not None else []))
         ctx.scale = float(scale)
-        return out
+        if weights is None:
+            return out[:9]
+        return out[:9], out[9]
 
     @staticmethod
-    def backward(ctx, grad):
-        pred_hf, palm, saved = ctx.saved_tensors
+    def backward(ctx, grad, grad_total=None):
+        pred_hf, palm, saved = ctx.saved_tensors[:3]
+        weights = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
         B = pred_hf.shape[0]
-        g3 = grad[:3].contiguous().float()
+        if grad is None and grad_total is None:
+            return (None,) * 9
+        g3 = None if grad is None else grad[:3].contiguous().float()
+        gt = None if grad_total is None else grad_total.contiguous().float()
         d = torch.empty_like(pred_hf)
         with torch.cuda.device(pred_hf.device):
-            _native._check(_lib.pn2x_hand_losses_backward(B, palm.shape[0], pred_hf.data_ptr(), ctx.scale, palm.data_ptr(), saved.data_ptr(),
-                                                          g3.data_ptr(), d.data_ptr(), _native._stream(pred_hf)), "hand_losses_backward")
-        return d, None, None, None, None, None, None, None
+            _native._check(_lib.pn2x_hand_losses_backward2(B, palm.shape[0], pred_hf.data_ptr(), ctx.scale, palm.data_ptr(), saved.data_ptr(),
+                                                           None if g3 is None else g3.data_ptr(), None if gt is None else gt.data_ptr(),
+                                                           None if weights is None else weights.data_ptr(), d.data_ptr(),
+                                                           _native._stream(pred_hf)), "hand_losses_backward")
+        return d, None, None, None, None, None, None, None, None

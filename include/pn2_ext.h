@@ -423,6 +423,12 @@ int pn2x_hand_losses(int b, int pb, const float *pred_hf, const float *init_hf, 
                      const float *R, const float *t, float scale, const float *palm, float *out, float *saved, void *stream);
 int pn2x_hand_losses_backward(int b, int pb, const float *pred_hf, float scale, const float *palm, const float *saved,
                               const float *grad3, float *d_pred_hf, void *stream);
+/* ... with the caller's weighted total folded in: weights (9) -> out has ten entries, out[9] = sum_i weights[i] out[i]; the backward
+ * takes dL/d out[0..2] (grad3, may be NULL) and / or dL/d out[9] (grad_total, one float on the device, may be NULL). */
+int pn2x_hand_losses2(int b, int pb, const float *pred_hf, const float *init_hf, const float *gt_kp, const float *pred_kp, const float *R,
+                      const float *t, float scale, const float *palm, float *out, float *saved, const float *weights, void *stream);
+int pn2x_hand_losses_backward2(int b, int pb, const float *pred_hf, float scale, const float *palm, const float *saved, const float *grad3,
+                               const float *grad_total, const float *weights, float *d_pred_hf, void *stream);
 
 /*
  * The 21-token tail in TRAINING mode (csrc/tail_train.hip; reference transformer.py:65-67, hand_network.py:139-147 with

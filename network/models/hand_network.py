@@ -77,6 +77,8 @@ class LossDict(dict):
     """The loss dictionary, plus (attribute, not an entry) the (9,) tensor all its values are views of when they come from the
     fused loss kernel -- Trainer.summarize_losses then forms the weighted total with one dot product."""
     fused_values = None
+    fused_total = None          # sum_i w_i value_i formed inside the loss kernel (when the Trainer handed its weights to the model)
+    fused_total_weights = None  # ... and the (9,) weight tensor it was formed with
 
 
 class HandTrackNet(nn.Module):
@@ -239,14 +241,20 @@ class HandTrackNet(nn.Module):
             gt = input["gt_hand_kp"].to(dev).float()
             palm = input["gt_hand_pose"]["palm_template"].to(dev).float()
             s = float(0.2)  # _hand_frame / fast paths: the constant hand-frame scale (hand_network.py:95)
-            vals = ext.HandLosses.apply(ret_dict["pred_kp_handframe"], ret_dict["init_kp_handframe"], gt, ret_dict["pred_kp"], canon_pose["rotation"],
-                                        canon_pose["translation"].reshape(-1, 3), s, palm)
+            # fused_loss_weights (9,), set by the Trainer: the weighted total comes out of the same launch
+            wts = getattr(self, "fused_loss_weights", None)
+            if wts is not None and (wts.device != ret_dict["pred_kp"].device or wts.numel() != 9):
+                wts = None
+            res = ext.HandLosses.apply(ret_dict["pred_kp_handframe"], ret_dict["init_kp_handframe"], gt, ret_dict["pred_kp"], canon_pose["rotation"],
+                                       canon_pose["translation"].reshape(-1, 3), s, palm, wts)
+            vals, total = res if wts is not None else (res, None)
             ret_dict["gt_kp_handframe"] = canonicalize(gt.transpose(-1, -2), canon_pose) if flag_dict.get("save_flag") else None
             loss = {k: vals[i] for i, k in enumerate(ext.HAND_LOSS_NAMES)}
             order = ["hand_pred_kp_loss", "hand_pred_kp_diff", "hand_init_kp_diff", "hand_pred_r_loss", "hand_pred_t_loss", "hand_init_r_diff",
                      "hand_init_t_diff", "hand_pred_r_diff", "hand_pred_t_diff"]
             loss = LossDict((k, loss[k]) for k in order)
-            loss.fused_values = vals  # (9,) in ext.HAND_LOSS_NAMES order: lets the trainer form the weighted total with one dot product
+            loss.fused_values = vals  # (9,) in ext.HAND_LOSS_NAMES order: lets the trainer form the weighted total in one go
+            loss.fused_total, loss.fused_total_weights = total, wts
             return loss, ret_dict
         gt_kp = input["gt_hand_kp"].to(dev).float().transpose(-1, -2)  # (B,3,kp)
         pred_kp = ret_dict["pred_kp"].transpose(-1, -2)

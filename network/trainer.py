@@ -154,13 +154,22 @@ class Trainer(nn.Module):
 
     def summarize_losses(self, loss_dict):
         vals = getattr(loss_dict, "fused_values", None)
-        if vals is not None:  # all terms live in one (9,) tensor (hotrack_amd.ext.HandLosses): the weighted total is ONE dot product
+        if vals is not None and getattr(loss_dict, "fused_total", None) is not None and \
+                loss_dict.fused_total_weights is getattr(self, "_wvec", None):
+            loss_dict["total_loss"] = loss_dict.fused_total  # formed inside the loss kernel with this trainer's weights
+            return loss_dict
+        if vals is not None:  # all terms live in one (9,) tensor (hotrack_amd.ext.HandLosses): the weighted total is one multiply + one sum
             from hotrack_amd.ext import HAND_LOSS_NAMES
             key = (vals.device, tuple(sorted(self.loss_weights.items())))
             if getattr(self, "_wvec_key", None) != key:
                 self._wvec = torch.tensor([float(self.loss_weights.get(k, 0.0)) for k in HAND_LOSS_NAMES], dtype=vals.dtype, device=vals.device)
                 self._wvec_key = key
-            loss_dict["total_loss"] = torch.dot(vals, self._wvec)
+                net = self.model if isinstance(self.model, HandTrackNet) else getattr(self.model, "handnet", None)
+                if net is not None:
+                    net.fused_loss_weights = self._wvec  # later steps: the total comes out of the loss kernel itself
+            # (not torch.dot: rocBLAS returns its device-pointer result through a memcpy node, which costs ~40 us of idle
+            # time inside a replayed graph)
+            loss_dict["total_loss"] = (vals * self._wvec).sum()
             return loss_dict
         total = 0
         for key, w in self.loss_weights.items():

@@ -604,6 +604,19 @@ def test_fused_hand_losses_match_the_torch_composition():
         assert abs(la[k] - lb[k]) <= 2e-5 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
     ga, gb = res[True][1], res[False][1]
     assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-7, float((ga - gb).abs().max())
+    # the weighted total formed inside the loss kernel (what the Trainer uses once it has handed its weights to the model)
+    from hotrack_amd.ext import HAND_LOSS_NAMES
+    model.use_fused_losses = True
+    model.fused_loss_weights = torch.tensor([weights.get(k, 0.0) for k in HAND_LOSS_NAMES], device="cuda")
+    p = base.clone().requires_grad_(True)
+    ret = {"canon_pose": canon, "pred_kp_handframe": p, "init_kp_handframe": init_hf,
+           "pred_kp": (0.2 * (Rc @ p) + canon["translation"]).transpose(1, 2)}
+    loss, _ = model.compute_loss(data, ret, dict(flags))
+    assert loss.fused_total is not None and loss.fused_total_weights is model.fused_loss_weights
+    ref_total = sum(lb[k] * w_ for k, w_ in weights.items())
+    assert abs(float(loss.fused_total) - ref_total) <= 2e-5 * max(1.0, abs(ref_total))
+    (gt_,) = torch.autograd.grad(loss.fused_total, p)
+    assert float((gt_ - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-7
 
 
 # ---- the 21-token tail in training mode (csrc/tail_train.hip, hotrack_amd/tail_train.py) ----------------------------------------
