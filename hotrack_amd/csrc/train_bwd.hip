@@ -41,7 +41,7 @@ __device__ __forceinline__ float relu_nan(float h) { return !(h <= 0.f) ? h : 0.
 struct BwdArgs {
     long R;
     const float *G; int ldg;    // GMODE 0: g_i = dH_i . [H_i > 0] (R x C_i); GMODE 2: d(max over Kmax rows) (R / Kmax x C_i)
-    const int *arg; int Kmax, kshift;  // GMODE 2: arg-max row within the group (same stride as G); kshift >= 0: Kmax = 1 << kshift
+    const int *arg; int ldarg, Kmax, kshift;  // GMODE 2: arg-max row within the group (row stride ldarg); kshift >= 0: Kmax = 1 << kshift
     const float *Y; int ldy;    // pre-activations of layer i
     const float *mean, *invstd, *gamma, *beta;
     const double *sums_bwd;     // layer i: kBnRep copies of [sum(g) | sum(g xhat)], each half sums_ld wide (>= C_i: a column slice)
@@ -126,7 +126,7 @@ tg_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
             pg[i] = *reinterpret_cast<const float4 *>(a.G + grow * a.ldg + 4 * (8 * i + aq));
-            if constexpr (GMODE == 2) par[i] = *reinterpret_cast<const int4 *>(a.arg + grow * a.ldg + 4 * (8 * i + aq));
+            if constexpr (GMODE == 2) par[i] = *reinterpret_cast<const int4 *>(a.arg + grow * a.ldarg + 4 * (8 * i + aq));
         }
     };
     auto prefetch = [&](long tile) {
@@ -461,15 +461,15 @@ extern "C" int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, i
                            const float *yp, int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p,
                            const float *beta_p, float *gp, int ldgp, double *sums_bwd_p, float *partial, long partial_floats,
                            float *dw, void *stream) {
-    return pn2x_tg_bwd_slice(rows, n, k, gmode, g, ldg, arg, kmax, yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, n, w, ldw, yp,
+    return pn2x_tg_bwd_slice(rows, n, k, gmode, g, ldg, arg, ldg, kmax, yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, n, w, ldw, yp,
                              ldyp, mean_p, invstd_p, gamma_p, beta_p, gp, ldgp, sums_bwd_p, partial, partial_floats, dw, nullptr, 0, 0,
                              stream);
 }
 
 // One column slice [c0, c0 + n) of a layer with sums_ld >= n channels: the caller passes g / yi / the per-channel vectors / sums_bwd_i /
-// w / dw already offset to the slice.  g_add (row stride ldga, may alias gp): the data-gradient partial of earlier slices; raw_out: leave
+// w / dw already offset to the slice; arg (gmode 2) has its own row stride ldarg (g may be a column block of a wider tensor).  g_add (row stride ldga, may alias gp): the data-gradient partial of earlier slices; raw_out: leave
 // mask and sums to a later slice.
-extern "C" int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi,
+extern "C" int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int ldarg, int kmax, const float *yi,
                                  int ldyi, const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i,
                                  const double *sums_bwd_i, int sums_ld, const float *w, int ldw, const float *yp, int ldyp,
                                  const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p, float *gp,
@@ -477,7 +477,7 @@ extern "C" int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float
                                  int ldga, int raw_out, void *stream) {
     Shape s;
     if (rows < 1 || rows > 0x7fffffffL || !find_shape(k, n, s) || gmode < 0 || gmode > 2 || sums_ld < n) return PN2_EINVAL;
-    if (gmode == 2 && (kmax < 1 || rows % kmax)) return PN2_EINVAL;
+    if (gmode == 2 && (kmax < 1 || rows % kmax || ldarg < n || ldarg % 4)) return PN2_EINVAL;
     if ((gmode == 2 && !arg) || (gmode != 0 && !beta_i)) return PN2_ENULL;
     if (g_add && (ldga < k || ldga % 4 || (uintptr_t)g_add % 16)) return PN2_EINVAL;
     if ((uintptr_t)arg % 16) return PN2_EINVAL;
@@ -488,7 +488,7 @@ extern "C" int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float
     if (((uintptr_t)g | (uintptr_t)yi | (uintptr_t)yp | (uintptr_t)gp) % 16) return PN2_EINVAL;
     const int grid = grid_of(rows, s);
     if (partial_floats < (long)grid * s.ks_w * n * k) return PN2_ESCRATCH;
-    BwdArgs a{rows, g, ldg, arg, kmax, kshift_of(kmax), yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, sums_ld, g_add, ldga, raw_out ? 1 : 0, w, ldw, yp, ldyp, mean_p, invstd_p, gamma_p, beta_p,
+    BwdArgs a{rows, g, ldg, arg, ldarg, kmax, kshift_of(kmax), yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, sums_ld, g_add, ldga, raw_out ? 1 : 0, w, ldw, yp, ldyp, mean_p, invstd_p, gamma_p, beta_p,
               gp, ldgp, sums_bwd_p, partial, dw
 #ifdef PN2_TGB_PROFILE
               , g_prof

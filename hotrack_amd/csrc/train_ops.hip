@@ -737,7 +737,7 @@ namespace pn2 {
 // The BatchNorm-backward sums of a max-pooled top layer from the arg-max rows ALONE: the routed gradient is non-zero in one row
 // per (group, channel), so sum(g) and sum(g xhat) need groups x C gathered pre-activations, not the rows x C tensor.
 __global__ void __launch_bounds__(kTT)
-bn_bwd_reduce_routed_kernel(long groups, int K, int C, const float *__restrict__ dout, int ldd, const int *__restrict__ arg,
+bn_bwd_reduce_routed_kernel(long groups, int K, int C, const float *__restrict__ dout, int ldd, const int *__restrict__ arg, int lda,
                             const float *__restrict__ y, int ldy, const float *__restrict__ mean, const float *__restrict__ invstd,
                             const float *__restrict__ gamma, const float *__restrict__ beta, long groups_per_block,
                             double *__restrict__ sums) {
@@ -750,7 +750,7 @@ bn_bwd_reduce_routed_kernel(long groups, int K, int C, const float *__restrict__
     if (c < C) {
         const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
         for (long g = g0 + gl; g < g1; g += 4) {
-            const int a = arg[g * ldd + c];
+            const int a = arg[g * lda + c];
             const float xhat = (y[(g * K + a) * (long)ldy + c] - m) * is;
             const float gg = (xhat * ga + be > 0.f) ? dout[g * ldd + c] : 0.f;  // [relu(BN(y)) > 0], torch's evaluation order
             s += gg;
@@ -864,11 +864,11 @@ extern "C" int pn2x_rows_outer3(long rows, int c, const float *dy, int ldy, cons
     return check_launch();
 }
 
-extern "C" int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, const float *y, int ldy,
+extern "C" int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, int lda, const float *y, int ldy,
                                          const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums,
                                          void *stream) {
     using namespace pn2;
-    if (groups < 1 || k < 1 || bad_c(c) || ldy < c || ldd < c || groups * k > 0x7fffffffL) return PN2_EINVAL;
+    if (groups < 1 || k < 1 || bad_c(c) || ldy < c || ldd < c || lda < c || groups * k > 0x7fffffffL) return PN2_EINVAL;
     if (!dout || !arg || !y || !mean || !invstd || !gamma || !beta || !sums) return PN2_ENULL;
     const int ny = (c + 63) / 64;
     long blocks = (4L * num_compute_units() + ny - 1) / ny;
@@ -877,7 +877,7 @@ extern "C" int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float 
     if (gpb < 16) gpb = 16;
     blocks = (groups + gpb - 1) / gpb;
     hipLaunchKernelGGL(bn_bwd_reduce_routed_kernel, dim3((unsigned)blocks, ny), dim3(kTT), 0, (hipStream_t)stream, groups, k, c, dout, ldd,
-                       arg, y, ldy, mean, invstd, gamma, beta, gpb, sums);
+                       arg, lda, y, ldy, mean, invstd, gamma, beta, gpb, sums);
     return check_launch();
 }
 

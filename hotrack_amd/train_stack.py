@@ -56,7 +56,7 @@ _lib.pn2x_tg_bwd_partials.argtypes = [_cl, _ci, _ci]
 _lib.pn2x_tg_bwd_partials.restype = _ci
 _lib.pn2x_tg_bwd.argtypes = [_cl, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp,
                              _vp, _vp, _ci, _vp, _vp, _cl, _vp, _vp]
-_lib.pn2x_tg_bwd_slice.argtypes = [_cl, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp,
+_lib.pn2x_tg_bwd_slice.argtypes = [_cl, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp,
                                    _vp, _vp, _vp, _ci, _vp, _vp, _cl, _vp, _vp, _ci, _ci, _vp]
 _lib.pn2x_tg_bwd_slice.restype = _ci
 _lib.pn2x_tg_reduce_multi2.argtypes = [_ci, ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_vp),
@@ -76,7 +76,7 @@ def _bwd_slices(c_in: int, c_out: int):
     return None
 
 
-_lib.pn2x_bn_bwd_reduce_routed.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_bn_bwd_reduce_routed.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_bn_bwd_reduce_routed.restype = _ci
 _lib.pn2x_tg_bwd.restype = _ci
 FUSED_BWD = _os.environ.get("HOTRACK_STACK_FUSED_BWD", "1") != "0"  # data + weight gradient of a layer in one kernel (train_bwd.hip)
@@ -223,7 +223,10 @@ class _Stack(torch.autograd.Function):
             off += 1
         tensors = t[off:]
         dev = dout.device
-        dout = dout.contiguous()
+        # a column block of a wider gradient (the concatenated scales of a query module) is read in place where the kernels
+        # take a row stride (the routed path); everything else gets a contiguous copy
+        strided_ok = (dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0)
+        dout_c = dout if dout.is_contiguous() else None
         R = ys[0].shape[0]
         st = _native._stream(dout)
         # backward accumulators: this forward's slices while they are fresh, zeros otherwise (train_ops.Workspace)
@@ -247,10 +250,15 @@ class _Stack(torch.autograd.Function):
             g_dense = None
             wl = tensors[4 * (L - 1)]
             routed = bool(K and L > 1 and FUSED_BWD and ROUTE_ON_LOAD and _bwd_slices(wl.shape[1], wl.shape[0]))
+            if not (routed and strided_ok) and dout_c is None:
+                dout_c = dout.contiguous()
+            if dout_c is not None:
+                dout = dout_c
+            g, gmode = dout, (2 if K else 1)
             if routed:
                 # the routed gradient is non-zero in one row per (group, channel): the sums need the arg-max rows only, and the
                 # one-kernel layer backward below routes dout on load (no rows x C gradient tensor at all)
-                _native._check(_lib.pn2x_bn_bwd_reduce_routed(R // K, K, Cl, dout.data_ptr(), Cl, arg.data_ptr(), yl.data_ptr(),
+                _native._check(_lib.pn2x_bn_bwd_reduce_routed(R // K, K, Cl, dout.data_ptr(), dout.stride(0), arg.data_ptr(), Cl, yl.data_ptr(),
                                                               yl.stride(0), svl[0].data_ptr(), svl[1].data_ptr(), gam(L - 1).data_ptr(),
                                                               bet(L - 1).data_ptr(), sums[L - 1].data_ptr(), st), "bn_bwd_reduce_routed")
             elif K and ROUTE_DENSE:
@@ -283,7 +291,7 @@ class _Stack(torch.autograd.Function):
                         o4 = 4 * off
                         _native._check(_lib.pn2x_tg_bwd_slice(
                             R, wd, Kc, gmode, g.data_ptr() + o4, g.stride(0), (arg.data_ptr() + o4) if gmode == 2 else None,
-                            K if gmode == 2 else 1, yi.data_ptr() + o4, yi.stride(0), svi[0].data_ptr() + o4, svi[1].data_ptr() + o4,
+                            arg.stride(0) if gmode == 2 else 4, K if gmode == 2 else 1, yi.data_ptr() + o4, yi.stride(0), svi[0].data_ptr() + o4, svi[1].data_ptr() + o4,
                             gam(i).data_ptr() + o4, bet(i).data_ptr() + o4, sums[i].data_ptr() + 8 * off, N,
                             wc.data_ptr() + o4 * wc.stride(0), wc.stride(0), yp.data_ptr(), yp.stride(0), svp[0].data_ptr(),
                             svp[1].data_ptr(), gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), gp.data_ptr(), Kc, sums[i - 1].data_ptr(),

@@ -363,8 +363,8 @@ int pn2x_bn_bwd_reduce_g(long rows, int c, const float *dh, int ldd, const int *
                          const float *invstd, const float *gamma, const float *beta, int relu, double *sums, float *g_out, int ldg,
                          void *stream);
 /* The same sums for a max-routed top layer from its arg-max rows only (groups x c gathered reads of y instead of rows x c):
- * dout / arg (groups x c, row stride ldd), y ((groups * k) x c).  The layer below then routes on load (pn2x_tg_bwd, gmode 2). */
-int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, const float *y, int ldy,
+ * dout (groups x c, row stride ldd: may be a column block of a wider gradient), arg (groups x c, row stride lda), y ((groups * k) x c).  The layer below then routes on load (pn2x_tg_bwd, gmode 2). */
+int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, int lda, const float *y, int ldy,
                               const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums, void *stream);
 /* out (c x 3) = dy^T rel: dy (rows x c, row stride ldy), rel (rows x 3) -- the gradient of the three xyz columns of a grouped
  * layer-1 weight.  c / 4 must divide 256; scratch of pn2x_rows_outer3_scratch_floats(rows, c) floats (per-workgroup partials). */
@@ -502,7 +502,7 @@ int pn2x_tg_fwd2(long rows, int k, int n, const float *x, int ldx, const float *
 /* pn2x_tg_bwd_slice: one column slice [c0, c0 + n) of a layer with sums_ld channels (all layer-i pointers offset to the slice by the
  * caller).  A wider layer runs as consecutive slices: raw_out = 1 leaves the unmasked partial data gradient in gp, the next slice
  * passes it as g_add (may alias gp) and the last one applies the mask and accumulates the sums.  gmode 1: dense g, masked from Y_i. */
-int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi, int ldyi,
+int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int ldarg, int kmax, const float *yi, int ldyi,
                       const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i, const double *sums_bwd_i,
                       int sums_ld, const float *w, int ldw, const float *yp, int ldyp, const float *mean_p, const float *invstd_p,
                       const float *gamma_p, const float *beta_p, float *gp, int ldgp, double *sums_bwd_p, float *partial,
