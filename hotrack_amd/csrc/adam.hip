@@ -55,6 +55,22 @@ adam_kernel(Pack a, double lr_d, double beta1_d, double beta2_d, double eps_d, d
     const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
     long i = off + 4L * threadIdx.x;
     if (vec) {
+        // two quads per thread and step: eight 16-byte loads in flight before the first dependent store
+        for (; i + 4L * kT + 3 < end; i += 8L * kT) {
+            const long k = i + 4L * kT;
+            float4 p0 = *reinterpret_cast<float4 *>(p + i), m0 = *reinterpret_cast<float4 *>(m + i), v0 = *reinterpret_cast<float4 *>(v + i);
+            const float4 g0 = *reinterpret_cast<const float4 *>(g + i);
+            float4 p1 = *reinterpret_cast<float4 *>(p + k), m1 = *reinterpret_cast<float4 *>(m + k), v1 = *reinterpret_cast<float4 *>(v + k);
+            const float4 g1 = *reinterpret_cast<const float4 *>(g + k);
+            upd(p0.x, g0.x, m0.x, v0.x); upd(p0.y, g0.y, m0.y, v0.y); upd(p0.z, g0.z, m0.z, v0.z); upd(p0.w, g0.w, m0.w, v0.w);
+            upd(p1.x, g1.x, m1.x, v1.x); upd(p1.y, g1.y, m1.y, v1.y); upd(p1.z, g1.z, m1.z, v1.z); upd(p1.w, g1.w, m1.w, v1.w);
+            *reinterpret_cast<float4 *>(p + i) = p0;
+            *reinterpret_cast<float4 *>(m + i) = m0;
+            *reinterpret_cast<float4 *>(v + i) = v0;
+            *reinterpret_cast<float4 *>(p + k) = p1;
+            *reinterpret_cast<float4 *>(m + k) = m1;
+            *reinterpret_cast<float4 *>(v + k) = v1;
+        }
         for (; i + 3 < end; i += 4L * kT) {
             float4 pp = *reinterpret_cast<float4 *>(p + i), mm = *reinterpret_cast<float4 *>(m + i), vv = *reinterpret_cast<float4 *>(v + i);
             const float4 gg = *reinterpret_cast<const float4 *>(g + i);
