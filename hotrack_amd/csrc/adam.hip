@@ -92,6 +92,11 @@ __global__ void adam_step_kernel(Pack a) {
     if (t < a.n) a.step[t][0] += 1.f;
 }
 
+__global__ void adam_advance_kernel(float *__restrict__ steps, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) steps[t] += 1.f;
+}
+
 }  // namespace adam
 }  // namespace pn2
 
@@ -99,6 +104,22 @@ __global__ void adam_step_kernel(Pack a) {
 // counter per tensor, torch's `state['step']` of a capturable optimiser); numel: host array of n element counts.
 extern "C" int pn2x_adam_multi(int n, void *const *p, const void *const *g, void *const *m, void *const *v, void *const *step,
                                const long *numel, double lr, double beta1, double beta2, double eps, double weight_decay, void *stream) {
+    return pn2x_adam_multi2(n, p, g, m, v, step, numel, lr, beta1, beta2, eps, weight_decay, 1, stream);
+}
+
+// All step counters of an optimiser in ONE contiguous buffer (views of it as the per-parameter `step` tensors): advanced by one
+// launch after the update kernels (pn2x_adam_multi2 with advance = 0) instead of one launch per 64 tensors.
+extern "C" int pn2x_adam_advance(float *steps, int n, void *stream) {
+    if (n < 0) return PN2_EINVAL;
+    if (n == 0) return PN2_OK;
+    if (!steps) return PN2_ENULL;
+    hipLaunchKernelGGL(pn2::adam::adam_advance_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, steps, n);
+    return pn2::check_launch();
+}
+
+extern "C" int pn2x_adam_multi2(int n, void *const *p, const void *const *g, void *const *m, void *const *v, void *const *step,
+                                const long *numel, double lr, double beta1, double beta2, double eps, double weight_decay, int advance,
+                                void *stream) {
     using namespace pn2;
     using namespace pn2::adam;
     if (n < 0 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return PN2_EINVAL;
@@ -120,7 +141,7 @@ extern "C" int pn2x_adam_multi(int n, void *const *p, const void *const *g, void
         a.chunk_start[a.n] = chunks;
         if (chunks > 0) hipLaunchKernelGGL(adam_kernel, dim3(chunks), dim3(kT), 0, st, a, lr, beta1, beta2, eps, weight_decay);
     }
-    for (int t0 = 0; t0 < n; t0 += kMaxT) {  // after ALL update kernels: they read the old counters
+    for (int t0 = 0; advance && t0 < n; t0 += kMaxT) {  // after ALL update kernels: they read the old counters
         Pack a;
         a.n = (n - t0) < kMaxT ? (n - t0) : kMaxT;
         for (int i = 0; i < a.n; ++i) a.step[i] = (float *)step[t0 + i];

@@ -20,6 +20,10 @@ _vp = ctypes.c_void_p
 _lib.pn2x_adam_multi.argtypes = [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                  ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_long)] + [ctypes.c_double] * 5 + [_vp]
 _lib.pn2x_adam_multi.restype = ctypes.c_int
+_lib.pn2x_adam_multi2.argtypes = _lib.pn2x_adam_multi.argtypes[:-1] + [ctypes.c_int, _vp]
+_lib.pn2x_adam_multi2.restype = ctypes.c_int
+_lib.pn2x_adam_advance.argtypes = [_vp, ctypes.c_int, _vp]
+_lib.pn2x_adam_advance.restype = ctypes.c_int
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -27,15 +31,32 @@ class FusedAdam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("FusedAdam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # the per-parameter `step` tensors are 0-dim views of one buffer per device: one launch advances them all
+        self._step_bufs = {}
+
+    def _new_step(self, device):
+        n_total = sum(len(g["params"]) for g in self.param_groups)
+        buf, used = self._step_bufs.get(device, (None, 0))
+        if buf is None or used >= buf.numel():
+            buf, used = torch.zeros(max(n_total, 1), dtype=torch.float32, device=device), 0
+        self._step_bufs[device] = (buf, used + 1)
+        return buf[used]
 
     def _init_state(self, p):
         st = self.state[p]
         if len(st) == 0:
-            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)  # torch's capturable layout: a device scalar
+            st["step"] = self._new_step(p.device)  # torch's capturable layout: a device scalar (here a view of the shared buffer)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        elif not st["step"].is_cuda:  # a state dict written by a non-capturable torch.optim.Adam (host counters)
-            st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+        else:
+            stp = st["step"]
+            buf = self._step_bufs.get(p.device, (None, 0))[0]
+            if (not torch.is_tensor(stp) or not stp.is_cuda or buf is None
+                    or stp.untyped_storage().data_ptr() != buf.untyped_storage().data_ptr()):
+                # a loaded state dict (torch.optim.Adam's or ours; host counters if it was not capturable): re-home the counter
+                new = self._new_step(p.device)
+                new.fill_(float(stp))
+                st["step"] = new
         return st
 
     @torch.no_grad()
@@ -44,6 +65,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        stepped = []
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -65,6 +87,26 @@ class FusedAdam(torch.optim.Optimizer):
             lr = group["lr"]
             lr = float(lr.item()) if torch.is_tensor(lr) else float(lr)
             with torch.cuda.device(ps[0].device):
-                _native._check(_lib.pn2x_adam_multi(n, P, G, M, V, S, N, lr, float(b1), float(b2), float(group["eps"]),
-                                                    float(group["weight_decay"]), _native._stream(ps[0])), "adam_multi")
+                _native._check(_lib.pn2x_adam_multi2(n, P, G, M, V, S, N, lr, float(b1), float(b2), float(group["eps"]),
+                                                     float(group["weight_decay"]), 0, _native._stream(ps[0])), "adam_multi")
+            stepped += [self.state[p]["step"] for p in ps]
+        self._advance(stepped)
         return loss
+
+    def _advance(self, steps):
+        """step += 1 for every parameter updated in this call: one launch where their counters are exactly the used prefix of the
+        shared buffer (the usual case: the same parameters receive gradients every step), else one launch per run of counters."""
+        by_dev = {}
+        for s in steps:
+            by_dev.setdefault(s.device, []).append(s)
+        for dev, ss in by_dev.items():
+            buf, used = self._step_bufs.get(dev, (None, 0))
+            with torch.cuda.device(dev):
+                st = _native._stream(ss[0])
+                base = None if buf is None else buf.data_ptr()
+                ptrs = sorted(s.data_ptr() for s in ss)
+                if buf is not None and len(ptrs) == used and ptrs == [base + 4 * i for i in range(used)]:
+                    _native._check(_lib.pn2x_adam_advance(base, used, st), "adam_advance")
+                else:  # counters from a loaded state dict, or a parameter that got no gradient this time
+                    for s in ss:
+                        s.add_(1.0)

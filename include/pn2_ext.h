@@ -470,6 +470,11 @@ int pn2x_tail_pose_head_bwd(int b, int j, int c, const float *h, const float *w,
  */
 int pn2x_adam_multi(int n, void *const *p, const void *const *g, void *const *m, void *const *v, void *const *step,
                     const long *numel, double lr, double beta1, double beta2, double eps, double weight_decay, void *stream);
+/* advance = 0: the counters are left alone (the caller keeps them in one contiguous buffer and advances them all with
+ * pn2x_adam_advance AFTER every pn2x_adam_multi2 of the step: the update kernels read the old values) */
+int pn2x_adam_multi2(int n, void *const *p, const void *const *g, void *const *m, void *const *v, void *const *step, const long *numel,
+                     double lr, double beta1, double beta2, double eps, double weight_decay, int advance, void *stream);
+int pn2x_adam_advance(float *steps, int n, void *stream);
 /* pn2x_tg_wgrad with the reduction deferred: n_partials != NULL -> only the partial tiles are written (dw zeroed) and their count
  * returned; pn2x_tg_reduce_multi then sums the partial tiles of SEVERAL layers (host arrays of `count` entries) and emits their
  * dgamma / dbeta (/ zero dbias) in one launch -- the weight gradients are not needed before the optimiser step. */

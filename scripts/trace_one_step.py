@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One training step, kernel by kernel, from a rocprofv3 --kernel-trace CSV of `bench_train.py --graph`: the launches between
 the last two fused-Adam kernels, in start order, with their duration and the idle gap in front of them.
-usage: trace_one_step.py <kernel_trace.csv> [--marker adam_step_kernel]  -> CSV on stdout."""
+usage: trace_one_step.py <kernel_trace.csv> [--marker adam_advance_kernel]  -> CSV on stdout."""
 import argparse
 import csv
 import sys
@@ -13,7 +13,7 @@ from trace_window import short  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
-    ap.add_argument("--marker", default="adam_step_kernel", help="kernel that ends a step (hotrack_amd.optim.FusedAdam: adam_step_kernel; torch's fused Adam: multi_tensor_apply_kernel)")
+    ap.add_argument("--marker", default="adam_advance_kernel", help="kernel that ends a step (hotrack_amd.optim.FusedAdam: adam_advance_kernel; torch's fused Adam: multi_tensor_apply_kernel)")
     a = ap.parse_args()
     rows = []
     with open(a.trace, newline="") as f:
