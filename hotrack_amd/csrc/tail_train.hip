@@ -289,7 +289,7 @@ static int epl_of(int c) { return c <= 128 ? 2 : (c <= 256 ? 4 : (c <= 512 ? 8 :
 __global__ void __launch_bounds__(256)
 pose_head_fwd_kernel(int tokens, int j, int c, const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ bias,
                      const float *__restrict__ xyz1, const float *__restrict__ R, const float *__restrict__ t,
-                     const float *__restrict__ scale, float *__restrict__ kp_hand, float *__restrict__ kp_cam) {
+                     const float *__restrict__ scale, int sstride, float *__restrict__ kp_hand, float *__restrict__ kp_cam) {
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= tokens) return;
     const int lane = threadIdx.x & 63;
@@ -308,7 +308,7 @@ pose_head_fwd_kernel(int tokens, int j, int c, const float *__restrict__ h, cons
         const float px = a0 + bias[0] + x[0], py = a1 + bias[1] + x[j], pz = a2 + bias[2] + x[2 * j];
         o[0] = px; o[j] = py; o[2 * j] = pz;
         const float *Rb = R + 9 * b, *tb = t + 3 * b;
-        const float sc = scale[b];
+        const float sc = scale[(size_t)b * sstride];  // sstride 0: one scale for every cloud
         kp_cam[3 * tok] = sc * (Rb[0] * px + Rb[1] * py + Rb[2] * pz) + tb[0];  // scale * (R p) + t, decanonicalize's order
         kp_cam[3 * tok + 1] = sc * (Rb[3] * px + Rb[4] * py + Rb[5] * pz) + tb[1];
         kp_cam[3 * tok + 2] = sc * (Rb[6] * px + Rb[7] * py + Rb[8] * pz) + tb[2];
@@ -319,7 +319,7 @@ pose_head_fwd_kernel(int tokens, int j, int c, const float *__restrict__ h, cons
 // dh[tok, ch] = sum_i g_i w[i, ch];  dw[i, ch] += sum_tok g_i h[tok, ch], dbias[i] += sum_tok g_i  (zero-filled accumulators).
 __global__ void __launch_bounds__(256)
 pose_head_bwd_kernel(int tokens, int j, int c, const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ g_hand,
-                     const float *__restrict__ g_cam, const float *__restrict__ R, const float *__restrict__ scale,
+                     const float *__restrict__ g_cam, const float *__restrict__ R, const float *__restrict__ scale, int sstride,
                      float *__restrict__ dh, float *__restrict__ dw, float *__restrict__ dbias) {
     __shared__ float gs[32][3];
     const int tok0 = blockIdx.x * 32;
@@ -331,7 +331,7 @@ pose_head_bwd_kernel(int tokens, int j, int c, const float *__restrict__ h, cons
             g = g_hand ? g_hand[(size_t)b * 3 * j + (size_t)i * j + jj] : 0.f;
             if (g_cam) {
                 const float *Rb = R + 9 * b, *gc = g_cam + 3 * (size_t)tok;
-                g += scale[b] * (Rb[i] * gc[0] + Rb[3 + i] * gc[1] + Rb[6 + i] * gc[2]);
+                g += scale[(size_t)b * sstride] * (Rb[i] * gc[0] + Rb[3 + i] * gc[1] + Rb[6 + i] * gc[2]);
             }
         }
         gs[tl][i] = g;
@@ -429,23 +429,25 @@ extern "C" int pn2x_tail_relu_drop_bwd(long rows, int c, const float *z, const f
 }
 
 extern "C" int pn2x_tail_pose_head_fwd(int b, int j, int c, const float *h, const float *w, const float *bias, const float *xyz1,
-                                       const float *R, const float *t, const float *scale, float *kp_hand, float *kp_cam, void *stream) {
+                                       const float *R, const float *t, const float *scale, int scale_stride, float *kp_hand,
+                                       float *kp_cam, void *stream) {
     if (b < 0 || j < 1 || c < 1) return PN2_EINVAL;
     if (b == 0) return PN2_OK;
     if (!h || !w || !bias || !xyz1 || !R || !t || !scale || !kp_hand || !kp_cam) return PN2_ENULL;
     const int tokens = b * j;
     hipLaunchKernelGGL(pose_head_fwd_kernel, dim3((tokens + 3) / 4), dim3(256), 0, (hipStream_t)stream, tokens, j, c, h, w, bias, xyz1, R,
-                       t, scale, kp_hand, kp_cam);
+                       t, scale, scale_stride ? 1 : 0, kp_hand, kp_cam);
     return check_launch();
 }
 
 extern "C" int pn2x_tail_pose_head_bwd(int b, int j, int c, const float *h, const float *w, const float *g_hand, const float *g_cam,
-                                       const float *R, const float *scale, float *dh, float *dw, float *dbias, void *stream) {
+                                       const float *R, const float *scale, int scale_stride, float *dh, float *dw, float *dbias,
+                                       void *stream) {
     if (b < 0 || j < 1 || c < 1) return PN2_EINVAL;
     if (b == 0) return PN2_OK;
     if (!h || !w || !dh || !dw || !dbias || (!g_hand && !g_cam) || (g_cam && (!R || !scale))) return PN2_ENULL;
     const int tokens = b * j;
     hipLaunchKernelGGL(pose_head_bwd_kernel, dim3((tokens + 31) / 32), dim3(256), 0, (hipStream_t)stream, tokens, j, c, h, w, g_hand, g_cam,
-                       R, scale, dh, dw, dbias);
+                       R, scale, scale_stride ? 1 : 0, dh, dw, dbias);
     return check_launch();
 }

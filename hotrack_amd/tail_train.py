@@ -25,9 +25,9 @@ _lib.pn2x_tail_relu_drop_fwd.argtypes = [_cl, _ci, _vp, _vp, _cf, _ci, _vp, _vp,
 _lib.pn2x_tail_relu_drop_fwd.restype = _ci
 _lib.pn2x_tail_relu_drop_bwd.argtypes = [_cl, _ci, _vp, _vp, _cf, _ci, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_tail_relu_drop_bwd.restype = _ci
-_lib.pn2x_tail_pose_head_fwd.argtypes = [_ci, _ci, _ci] + [_vp] * 10
+_lib.pn2x_tail_pose_head_fwd.argtypes = [_ci, _ci, _ci] + [_vp] * 7 + [_ci] + [_vp] * 3
 _lib.pn2x_tail_pose_head_fwd.restype = _ci
-_lib.pn2x_tail_pose_head_bwd.argtypes = [_ci, _ci, _ci] + [_vp] * 10
+_lib.pn2x_tail_pose_head_bwd.argtypes = [_ci, _ci, _ci] + [_vp] * 6 + [_ci] + [_vp] * 4
 _lib.pn2x_tail_pose_head_bwd.restype = _ci
 _f32 = torch.float32
 
@@ -144,7 +144,8 @@ class _PoseHead(torch.autograd.Function):
         kp_cam = torch.empty((B, J, 3), dtype=_f32, device=h.device)
         with torch.cuda.device(h.device):
             _native._check(_lib.pn2x_tail_pose_head_fwd(B, J, C, h.data_ptr(), w.data_ptr(), bias.data_ptr(), xyz1.data_ptr(), R.data_ptr(),
-                                                        t.data_ptr(), scale.data_ptr(), kp_hand.data_ptr(), kp_cam.data_ptr(),
+                                                        t.data_ptr(), scale.data_ptr(), 1 if scale.numel() > 1 else 0, kp_hand.data_ptr(),
+                                                        kp_cam.data_ptr(),
                                                         _native._stream(h)), "tail_pose_head_fwd")
         ctx.save_for_backward(h, w, R, scale)
         ctx.acc, ctx.J = acc, J
@@ -162,7 +163,8 @@ class _PoseHead(torch.autograd.Function):
             return torch.zeros_like(h), None, None, None, None, None, None, None
         with torch.cuda.device(h.device):
             _native._check(_lib.pn2x_tail_pose_head_bwd(rows // ctx.J, ctx.J, C, h.data_ptr(), w.data_ptr(), _p(g_hand), _p(g_cam), R.data_ptr(),
-                                                        scale.data_ptr(), dh.data_ptr(), acc.data_ptr(), acc.data_ptr() + 4 * 3 * C,
+                                                        scale.data_ptr(), 1 if scale.numel() > 1 else 0, dh.data_ptr(), acc.data_ptr(),
+                                                        acc.data_ptr() + 4 * 3 * C,
                                                         _native._stream(h)), "tail_pose_head_bwd")
         return dh, acc[:3 * C].view(3, C), acc[3 * C:3 * C + 3], None, None, None, None, None
 
@@ -171,8 +173,6 @@ def pose_head(h, w, bias, xyz1, R, t, scale, grads):
     """(kp_hand (B,3,J), kp_cam (B,J,3)) = (h w^T + bias + xyz1, scale R kp_hand + t): h (B*J, C) rows, w (3, C), bias (3,), xyz1
     (B,3,J), R (B,3,3), t (B,3[,1]), scale (B,).  Gradients to h, w, bias."""
     B = xyz1.shape[0]
-    scale = scale.reshape(-1)
-    if scale.numel() == 1:
-        scale = scale.expand(B)
+    scale = scale.reshape(-1)  # (B,) or (1,): one value for every cloud
     args = [a.contiguous().float() for a in (h, w, bias, xyz1, R.reshape(B, 3, 3), t.reshape(B, 3), scale)]
     return _PoseHead.apply(*args, grads.take(3 * w.shape[1] + 3))

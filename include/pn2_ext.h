@@ -454,13 +454,13 @@ int pn2x_tail_relu_drop_fwd(long rows, int c, const float *z, const float *bias,
 int pn2x_tail_relu_drop_bwd(long rows, int c, const float *z, const float *bias, float p, int site, const long long *seed_in,
                             const float *dh, float *dz, float *dbias, void *stream);
 /* The last layer of final_mlp + residual on the initial keypoints + de-canonicalisation, in training (hand_network.py:141-147):
- * h (b*j, c) rows, w (3, c), bias (3), xyz1 (b, 3, j), R (b, 3, 3), t (b, 3), scale (b) ->
+ * h (b*j, c) rows, w (3, c), bias (3), xyz1 (b, 3, j), R (b, 3, 3), t (b, 3), scale (b; scale_stride 0: one value for all) ->
  * kp_hand (b, 3, j) = h w^T + bias + xyz1, kp_cam (b, j, 3) = scale R kp_hand + t.  Backward: g_hand (b, 3, j) and / or g_cam (b, j, 3)
  * -> dh (b*j, c); dw (3, c) and dbias (3) are ADDED to (zero-filled accumulators). */
 int pn2x_tail_pose_head_fwd(int b, int j, int c, const float *h, const float *w, const float *bias, const float *xyz1, const float *R,
-                            const float *t, const float *scale, float *kp_hand, float *kp_cam, void *stream);
+                            const float *t, const float *scale, int scale_stride, float *kp_hand, float *kp_cam, void *stream);
 int pn2x_tail_pose_head_bwd(int b, int j, int c, const float *h, const float *w, const float *g_hand, const float *g_cam, const float *R,
-                            const float *scale, float *dh, float *dw, float *dbias, void *stream);
+                            const float *scale, int scale_stride, float *dh, float *dw, float *dbias, void *stream);
 
 /*
  * One Adam step over n fp32 tensors (csrc/adam.hip): torch.optim.Adam semantics (L2 weight decay added to the gradient, bias

@@ -209,6 +209,7 @@ class HandTrackNet(nn.Module):
                 self._ftail = FastTail(self) if FastTail.supported(self) else False
             ftail = self._ftail or None
         if ftail is not None:  # the 21-token tail, token-major, fused element-wise runs (fast_train.FastTail)
+            xyz1 = xyz1.contiguous()  # (B,3,kp) once: the pose head and the loss kernel both read it channel-major
             ret["pred_kp_handframe"], ret["pred_kp"] = ftail.forward(ftrain.last_token_rows, xyz1, canon_pose)
         else:
             f15, f251 = self.transt(src1=f14, pos1=pos1, src2=src2, pos2=pos2, attn=False, elide_dead=elide,
