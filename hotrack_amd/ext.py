@@ -395,6 +395,35 @@ def pose_head(h: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xyz1: torch.
     return kp_hand, kp_cam
 
 
+_lib.pn2x_linear_small.argtypes = [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp]
+_lib.pn2x_linear_small.restype = _ci
+# where pn2x_linear_small beats the library's best recorded solution (scripts/probes/linear_small_bench.py, profiles/
+# r03_linear_small.json): 2 ... 512 rows, reductions up to 384 deep, up to 512 outputs -- e.g. 128 x 128 -> 256: 4.7 vs 20 us,
+# 128 x 131 -> 128: 7.0 vs 12.8; it loses on one row, on deep reductions (21 x 1024 -> 384: 17 vs 5.9) and from ~1000 rows
+LINEAR_SMALL_MAX_ROWS = int(__import__("os").environ.get("HOTRACK_LINEAR_SMALL_MAX_ROWS", "512"))
+LINEAR_SMALL_MAX_K, LINEAR_SMALL_MAX_N = 384, 512
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, relu: bool = False) -> torch.Tensor:
+    """act(x w^T + bias) for x (M, K) rows, w (N, K): small problems (the B = 1 / B = 8 tracking loop; bounds above) through
+    pn2x_linear_small (one workgroup per 32 x 32 output block), everything else through the BLAS library (torch, with its fused
+    bias + ReLU epilogue).  Inference only."""
+    M, K = x.shape
+    N = w.shape[0]
+    if (M > LINEAR_SMALL_MAX_ROWS or M < 2 or K > LINEAR_SMALL_MAX_K or N > LINEAR_SMALL_MAX_N or not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32 or x.stride(1) != 1
+            or w.stride(1) != 1 or (bias is not None and not bias.is_contiguous()) or torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
+        if relu and bias is not None:
+            return torch._addmm_activation(bias, x, w.t())
+        y = torch.nn.functional.linear(x, w, bias)
+        return torch.relu_(y) if relu else y
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _native._check(_lib.pn2x_linear_small(M, K, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+                                              None if bias is None else bias.data_ptr(), 1 if relu else 0, y.data_ptr(), N,
+                                              _native._stream(x)), "linear_small")
+    return y
+
+
 _lib.pn2x_knn_indices.argtypes = [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_knn_indices.restype = _ci
 

@@ -520,6 +520,12 @@ int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, int ldg, con
                 int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p, float *gp, int ldgp,
                 double *sums_bwd_p, float *partial, long partial_floats, float *dw, void *stream);
 
+/* y (m x n, row stride ldy) = act(x (m x k) . w^T (w: n x k) + bias (n | NULL)), relu != 0: ReLU -- a dense layer over FEW rows
+ * (the B = 1 tracking loop: 21 ... 1024 rows; csrc/linear_small.hip): one workgroup per 32 x 32 output block, its four waves
+ * splitting the reduction.  Same result as the BLAS library up to summation order. */
+int pn2x_linear_small(int m, int k, int n, const float *x, int ldx, const float *w, int ldw, const float *bias, int relu, float *y,
+                      int ldy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,8 +27,16 @@ import torch.nn.functional as F
 
 
 def _lin_relu(x2d: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """relu(x W^T + b) as one GEMM with a bias+ReLU epilogue (hipBLASLt)."""
-    return torch._addmm_activation(b, x2d, W.t())
+    """relu(x W^T + b): small problems (the B = 1 / B = 8 tracking loop) through pn2x_linear_small, one workgroup per 32 x 32
+    output block; otherwise one library GEMM with a bias+ReLU epilogue (hipBLASLt).  hotrack_amd.ext.linear decides."""
+    from hotrack_amd import ext
+    return ext.linear(x2d, W, b, relu=True)
+
+
+def _lin(x2d: torch.Tensor, W: torch.Tensor, b: torch.Tensor = None) -> torch.Tensor:
+    """x W^T (+ b), same dispatch."""
+    from hotrack_amd import ext
+    return ext.linear(x2d, W, b)
 
 
 class FastEval:
@@ -271,7 +279,7 @@ class FastEval:
         c_l2 = p["l3"][0].shape[0]
         sa3_in = torch.empty((B, S2, c_l2 + 4), **f32)  # [l2_feat | l2_xyz | pad]: sa3's group-all input, no torch.cat
         idx2, l2_xyz = ext.ball_query_picks(bh.sa2.radius_list[0], K2, l1_xyz, i_l2, xyz_copy=sa3_in[:, :, c_l2:c_l2 + 3])
-        a1f = F.linear(l1_feat.reshape(B * S1, c_l1), p["w1f"]).view(B, S1, -1)
+        a1f = _lin(l1_feat.reshape(B * S1, c_l1), p["w1f"]).view(B, S1, -1)
         l2_feat = sa3_in[:, :, :c_l2]
         ext.sa_mlp_max(idx2, *p["l2"], *p["l3"], a1f=a1f, xyz=l1_xyz, cxyz=l2_xyz, wx=p["wx"], b1=p["b1"], out=l2_feat)
 
@@ -283,8 +291,8 @@ class FastEval:
 
         # ---- fp3: S == 1 -> the global feature is broadcast; first layer split so it is applied once per cloud
         p = P["fp3"]
-        g = F.linear(l3, p["wb"], p["b"])  # (B,256) per-cloud half, bias included
-        h = F.linear(sa3_in.view(B * S2, c_l2 + 4)[:, :c_l2], p["wa"]).view(B, S2, -1)
+        g = _lin(l3, p["wb"], p["b"])  # (B,256) per-cloud half, bias included
+        h = _lin(sa3_in.view(B * S2, c_l2 + 4)[:, :c_l2], p["wa"]).view(B, S2, -1)
         ext.bias_act_pm_(h, g, rows_per_bias=S2, relu=True)
         x = h.view(B * S2, -1)
         for W, b in p["rest"]:
@@ -329,20 +337,20 @@ class FastEval:
             # few slots and a batch large enough that the GEMM, not the launch count, is what costs (measured: pays from B ~ 32)
             if J * K * 2 <= N and B * N >= 32768:  # gather the J*K feature rows, then the GEMM (slot-major rows, identity index)
                 flat = (gi_small if K == kmin and gi_small is not None else gi[:, :, :K].contiguous()).view(B, J * K)
-                a = F.linear(ext.gather_rows(src3, flat).view(B * J * K, C), W).view(B, J * K, -1)
+                a = _lin(ext.gather_rows(src3, flat).view(B * J * K, C), W).view(B, J * K, -1)
                 plan.append((self._ident(B, J, K, dev), a, ext.gather_rows(xyz2, flat)))
             else:
                 idx = gi if K == kmax else (gi_small if K == kmin and gi_small is not None else gi[:, :, :K].contiguous())
-                plan.append((idx, F.linear(src2, W).view(B, N, -1), xyz2))
+                plan.append((idx, _lin(src2, W).view(B, N, -1), xyz2))
         f11 = torch.empty((B, J, 2 * c_q), **f32)
         self._q_scales(ext, "q1", plan, q, xyz1, c1q, 0, None, f11, c_q)
         Wr, br, perm = P["r1"]
-        f12 = F.linear(ext.gather_rows(f11, self._perm_idx(perm, B)).view(B * J, -1), Wr, br)  # (B*J, C)
-        cadd = F.linear(f12, P["wc2"]).view(B, J, -1)
+        f12 = _lin(ext.gather_rows(f11, self._perm_idx(perm, B)).view(B * J, -1), Wr, br)  # (B*J, C)
+        cadd = _lin(f12, P["wc2"]).view(B, J, -1)
         f13 = torch.empty((B, J, 2 * c_q), **f32)
         self._q_scales(ext, "q2", plan, q, xyz1, c1q, c1q, cadd, f13, c_q)
         Wr, br, perm = P["r2"]
-        f14 = F.linear(ext.gather_rows(f13, self._perm_idx(perm, B)).view(B * J, -1), Wr, br)
+        f14 = _lin(ext.gather_rows(f13, self._perm_idx(perm, B)).view(B * J, -1), Wr, br)
 
         # ---- "TransT" with attn=False: only LayerNorms and FFNs are live; the element-wise runs between the GEMMs
         # (residual add, bias, one or two LayerNorms) are one launch each --------------------------------------
@@ -350,7 +358,7 @@ class FastEval:
         x = ext.add_layernorm(f14, s11.norm1, ln2=c11.norm1)
         for blk, nxt in ((c11, c3.norm1), (c3, None)):
             hdn = _lin_relu(x, blk.linear1.weight, blk.linear1.bias)
-            x = ext.add_layernorm(x, blk.norm2, y=F.linear(hdn, blk.linear2.weight), bias=blk.linear2.bias, ln2=nxt)
+            x = ext.add_layernorm(x, blk.norm2, y=_lin(hdn, blk.linear2.weight), bias=blk.linear2.bias, ln2=nxt)
         hdn = _lin_relu(x, net.final_mlp[0].weight.squeeze(-1), net.final_mlp[0].bias)
         # head: last 1x1 conv + residual on the initial keypoints + back to the camera frame, one launch
         pred_hf, pred_kp = ext.pose_head(hdn, P["head_w"], net.final_mlp[2].bias, xyz1, R, t, 0.2, nonfinite=nonfinite)
