@@ -89,7 +89,8 @@ ROUTE_DENSE = _os.environ.get("HOTRACK_STACK_ROUTE_DENSE", "1") != "0"  # max-ro
 # The weight gradients are not read before the optimiser: the backward writes only partial tiles and ONE launch at the end of
 # the pass (autograd's final callbacks) sums the tiles of every layer of every stack.  Off (HOTRACK_STACK_DEFER_REDUCE=0, or
 # `DEFER_REDUCE = False`) where something reads .grad from inside the pass -- DistributedDataParallel's bucket hooks do.
-DEFER_REDUCE = _os.environ.get("HOTRACK_STACK_DEFER_REDUCE", "1") != "0"
+DEFER_REDUCE = (_os.environ.get("HOTRACK_STACK_DEFER_REDUCE", "1") != "0" and hasattr(torch._C, "_current_graph_task_id")
+                and hasattr(torch.autograd.Variable._execution_engine, "queue_callback"))  # (engine hooks of this torch build)
 _pending = []
 _pending_task = [None]  # the autograd pass the pending items belong to (a pass that raised leaves stale ones behind)
 
