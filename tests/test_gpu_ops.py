@@ -43,6 +43,35 @@ def test_fps_index_exact(ops, oracle, B, N, M, kind):
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
 
 
+# large clouds (16 points per lane), degenerate extents, all-equal points
+FPS_LARGE_CASES = [
+    (2, 8192, 2048, "uniform"), (2, 8192, 700, "lattice"), (2, 4097, 300, "uniform"), (3, 5000, 1500, "hand"), (2, 6000, 600, "dup"),
+    (1, 8192, 8192, "uniform"), (2, 5832, 900, "lattice"), (2, 7000, 256, "plane"), (2, 4500, 128, "line"), (1, 5000, 80, "same"),
+]
+
+
+def _large_cloud(seed, B, N, kind):
+    if kind in ("uniform", "lattice", "dup", "hand"):
+        return cloud(seed, B, N, kind)
+    rng = np.random.default_rng(seed)
+    x = rng.random((B, N, 3), dtype=np.float32)
+    if kind == "plane":       # zero extent along one axis
+        x[:, :, 2] = 0.25
+    elif kind == "line":
+        x[:, :, 1:] = -1.5
+    elif kind == "same":      # every point identical: all distances 0, every arg-max a tie over all points
+        x[:] = 0.5
+    return x
+
+
+@pytest.mark.parametrize("B,N,M,kind", FPS_LARGE_CASES)
+def test_fps_large_clouds_index_exact(ops, oracle, B, N, M, kind):
+    xyz = _large_cloud(B * 77 + N, B, N, kind)
+    ref = oracle.furthest_point_sample(xyz, M)
+    got = ops.furthest_point_sample(dev(xyz), M)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("threads", ["64", "256", "1024"])
 def test_fps_thread_configs_agree(ops, oracle, threads, monkeypatch):
     """Every (threads, points-per-lane) layout must give the reference's tie order."""
