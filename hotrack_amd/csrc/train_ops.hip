@@ -409,6 +409,77 @@ bn_relu_bwd_apply_kernel(long rows, int C, const float *__restrict__ dH, int ldd
     }
 }
 
+// The same pass for the first layer of a set-abstraction scale, which ALSO forms the partial sums of d(W_xyz) = dY^T rel (rel
+// (rows x 3): the relative coordinates sa_layer1 saved): dY is in registers here anyway, and the separate pass over it
+// (rows_outer3_kernel) re-read 33 MB per scale.  partial: [gridDim.x][C][3], summed by rows_outer3_sum_kernel.
+__global__ void __launch_bounds__(kTT)
+bn_relu_bwd_apply_rel_kernel(long rows, int C, const float *__restrict__ dH, int ldd, const float *__restrict__ Y, int ldy,
+                             const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
+                             const float *__restrict__ beta, const double *__restrict__ sums, int rows_per_block, int relu,
+                             float *__restrict__ dY, int ldo, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                             float *__restrict__ dbias, const float *__restrict__ rel, float *__restrict__ partial) {
+    __shared__ float red[12][kTT];
+    const int Q = C >> 2, rpp = kTT / Q;
+    const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
+    float a[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (rr < rpp) {
+        BnCh k;
+        load_saved(k, 4 * q, mean, invstd, gamma, beta);
+        float sg[4], sgx[4], scale[4];
+        const float inv_r = (float)(1.0 / (double)rows);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double sa = 0.0, sb = 0.0;
+            for (int r = 0; r < kRep; ++r) {
+                sa += sums[(size_t)r * 2 * C + 4 * q + i];
+                sb += sums[(size_t)r * 2 * C + C + 4 * q + i];
+            }
+            sg[i] = (float)sa;
+            sgx[i] = (float)sb;
+            scale[i] = k.g[i] * k.invstd[i];
+        }
+        if (blockIdx.x == 0 && rr == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dgamma[4 * q + i] = sgx[i];
+                dbeta[4 * q + i] = sg[i];
+                if (dbias) dbias[4 * q + i] = 0.f;
+            }
+        }
+        const long r0 = (long)blockIdx.x * rows_per_block;
+        const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+        for (long r = r0 + rr; r < r1; r += rpp) {
+            const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
+            const float4 g = *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q);
+            const float e0 = rel[r * 3 + 0], e1 = rel[r * 3 + 1], e2 = rel[r * 3 + 2];
+            const float yy[4] = {y.x, y.y, y.z, y.w};
+            float gg[4] = {g.x, g.y, g.z, g.w}, o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (relu && !(bn_act(yy[i], k, i) > 0.f)) gg[i] = 0.f;
+                const float xhat = (yy[i] - k.mean[i]) * k.invstd[i];
+                o[i] = scale[i] * (gg[i] - sg[i] * inv_r - xhat * (sgx[i] * inv_r));  // same expression as bn_relu_bwd_apply_kernel
+                a[i][0] += o[i] * e0; a[i][1] += o[i] * e1; a[i][2] += o[i] * e2;
+            }
+            *reinterpret_cast<float4 *>(dY + r * ldo + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) red[i * 3 + t][threadIdx.x] = a[i][t];
+    __syncthreads();
+    if (rr == 0) {
+        float *o = partial + (size_t)blockIdx.x * 3 * C + 12 * q;  // out[c][t], c = 4 q + i
+#pragma unroll
+        for (int kk = 0; kk < 12; ++kk) {
+            float s = red[kk][q];
+            for (int l = 1; l < rpp; ++l) s += red[kk][l * Q + q];
+            o[kk] = s;
+        }
+    }
+}
+
 // ---- transposes of the row gathers ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kTT)
 scatter_add_rows_kernel(int n, int m, int Q, const float *__restrict__ dOut, int ldo, const int *__restrict__ idx,
@@ -891,6 +962,32 @@ extern "C" int pn2x_bn_bwd_apply(long rows, int c, const float *g, int ldg, cons
     const int rpb = rows_per_block_for(rows, c);
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kTT), 0, (hipStream_t)stream, rows, c, g, ldg,
                        y, ldy, mean, invstd, gamma, beta, sums, rpb, relu, dy, ldo, dgamma, dbeta, dbias, (const int *)nullptr, 1);
+    return check_launch();
+}
+
+// pn2x_bn_bwd_apply that also returns dwx (c x 3) = dy^T rel (rel (rows x 3)); scratch: pn2x_bn_bwd_apply_rel_scratch_floats(rows, c)
+extern "C" long pn2x_bn_bwd_apply_rel_scratch_floats(long rows, int c) {
+    using namespace pn2;
+    if (rows < 1 || bad_c(c)) return -1;
+    const int rpb = rows_per_block_for(rows, c);
+    return ((rows + rpb - 1) / rpb) * 3L * c;
+}
+
+extern "C" int pn2x_bn_bwd_apply_rel(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean,
+                                     const float *invstd, const float *gamma, const float *beta, int relu, const double *sums, float *dy,
+                                     int ldo, float *dgamma, float *dbeta, float *dbias, const float *rel, float *scratch,
+                                     long scratch_floats, float *dwx, void *stream) {
+    using namespace pn2;
+    if (rows < 1 || bad_c(c) || c > 256 || ldy < c || ldy % 4 || ldg < c || ldg % 4 || ldo < c || ldo % 4) return PN2_EINVAL;
+    if (!g || !y || !mean || !invstd || !gamma || !beta || !sums || !dy || !dgamma || !dbeta || !rel || !scratch || !dwx) return PN2_ENULL;
+    if (((uintptr_t)y | (uintptr_t)g | (uintptr_t)dy) % 16) return PN2_EINVAL;
+    const int rpb = rows_per_block_for(rows, c);
+    const long blocks = (rows + rpb - 1) / rpb;
+    if (scratch_floats < blocks * 3L * c) return PN2_ESCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_rel_kernel, dim3((unsigned)blocks), dim3(kTT), 0, st, rows, c, g, ldg, y, ldy, mean, invstd, gamma,
+                       beta, sums, rpb, relu, dy, ldo, dgamma, dbeta, dbias, rel, scratch);
+    hipLaunchKernelGGL(rows_outer3_sum_kernel, dim3((3 * c + 15) / 16), dim3(kTT), 0, st, (int)blocks, 3 * c, scratch, dwx);
     return check_launch();
 }
 

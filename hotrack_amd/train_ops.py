@@ -230,7 +230,10 @@ class _SaLayer1(torch.autograd.Function):
     """One module call = all its scales: a1f (B,N,sum C1) | None, cadd (B,S,sum C1) | None, then per scale (idx_i, wx_i)."""
 
     @staticmethod
-    def forward(ctx, a1f, cadd, xyz, cxyz, n_scales, *rest):
+    def forward(ctx, a1f, cadd, xyz, cxyz, n_scales, aux, *rest):
+        # aux: dict | None -- a side channel to the stacks that consume the y1s (train_stack.mlp_stack(aux=(aux, i))): this forward
+        # leaves the relative coordinates there (aux["rel"][i]); a stack whose first-layer backward has dY_1 in registers anyway
+        # leaves d(wx_i) there (aux["dwx"][i]), which this backward then takes instead of a pass of its own over dY_1.
         # rest: idx_i (n_scales), wx_i (n_scales), then optionally the inverted neighbour lists (offsets_i, order_i) per scale
         idxs, wxs, invs = rest[:n_scales], rest[n_scales:2 * n_scales], rest[2 * n_scales:]
         B, N, _ = xyz.shape
@@ -254,6 +257,9 @@ class _SaLayer1(torch.autograd.Function):
             outs.append(out)
             rels.append(rel)
             col += C1
+        ctx.aux = aux
+        if aux is not None:
+            aux["rel"], aux["dwx"] = list(rels), {}
         ctx.save_for_backward(*idxs, *rels, *invs)
         ctx.meta = (n_scales, None if a1f is None else tuple(a1f.shape), None if cadd is None else tuple(cadd.shape), S)
         return tuple(outs)
@@ -278,7 +284,10 @@ class _SaLayer1(torch.autograd.Function):
                 scatter_add_rows(dy, idx.view(B, SK), d_a1f[:, :, col:col + C1])
             if d_cadd is not None:
                 torch.sum(dy.view(B, S, SK // S, C1), dim=2, out=d_cadd[:, :, col:col + C1])
-            if C1 % 4 == 0 and 256 % (C1 // 4) == 0 and rel.is_contiguous():  # one pass over dy (csrc/train_ops.hip: rows_outer3)
+            ready = ctx.aux["dwx"].pop(i, None) if ctx.aux is not None else None
+            if ready is not None:  # formed by the consumer's first-layer backward (pn2x_bn_bwd_apply_rel)
+                d_wx.append(ready)
+            elif C1 % 4 == 0 and 256 % (C1 // 4) == 0 and rel.is_contiguous():  # one pass over dy (csrc/train_ops.hip: rows_outer3)
                 dwx = torch.empty((C1, 3), dtype=_f32, device=dev)
                 scratch = torch.empty(int(_lib.pn2x_rows_outer3_scratch_floats(B * SK, C1)), dtype=_f32, device=dev)
                 with torch.cuda.device(dev):
@@ -288,17 +297,18 @@ class _SaLayer1(torch.autograd.Function):
             else:
                 d_wx.append(torch.mm(dy.view(B * SK, C1).t(), rel.view(B * SK, 3)))
             col += C1
-        return (d_a1f, d_cadd, None, None, None, *([None] * n), *d_wx, *([None] * len(invs)))
+        return (d_a1f, d_cadd, None, None, None, None, *([None] * n), *d_wx, *([None] * len(invs)))
 
 
-def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs, invs=None):
+def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs, invs=None, aux=None):
     """Layer-1 pre-activations of every scale of one SA module: list of (B, S*K_i, C1_i).
     a1f (B,N,sum C1) per-point feature terms [scale 0 | scale 1 ...] or None; cadd (B,S,sum C1) per-centroid terms or None;
     xyz (B,N,3), cxyz (B,S,3) (no gradient); idxs[i] (B,S,K_i) int32; wxs[i] (C1_i, 3).
     invs[i] = inverse_index(idxs[i].view(B, -1), N), computed by a caller that feeds the same neighbour lists to several modules
-    (the backward inverts them itself otherwise)."""
+    (the backward inverts them itself otherwise).  aux: an empty dict shared with train_stack.mlp_stack(aux=(aux, i)) -- see
+    _SaLayer1.forward."""
     extra = [t for inv in invs for t in inv] if invs else []
-    return list(_SaLayer1.apply(a1f, cadd, xyz, cxyz, len(idxs), *idxs, *wxs, *extra))
+    return list(_SaLayer1.apply(a1f, cadd, xyz, cxyz, len(idxs), aux, *idxs, *wxs, *extra))
 
 
 class _InterpRows(torch.autograd.Function):

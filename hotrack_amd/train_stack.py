@@ -134,6 +134,10 @@ def _reduce_items(items):
         _native._check(_lib.pn2x_tg_reduce_multi2(n, part, P, numel, dw, sm, ch, sld, dg, db, dbi, st), "tg_reduce_multi")
 
 
+_lib.pn2x_bn_bwd_apply_rel.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _cl, _vp, _vp]
+_lib.pn2x_bn_bwd_apply_rel.restype = _ci
+_lib.pn2x_bn_bwd_apply_rel_scratch_floats.argtypes = [_cl, _ci]
+_lib.pn2x_bn_bwd_apply_rel_scratch_floats.restype = _cl
 _lib.pn2x_bn_bwd_apply.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_bn_bwd_apply.restype = _ci
 _f32 = torch.float32
@@ -155,7 +159,7 @@ class Layer:
 
 class _Stack(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y1, K, ws, metas, *tensors):
+    def forward(ctx, y1, K, ws, metas, aux, *tensors):
         # tensors: per layer (weight | placeholder, gamma, beta, conv bias | placeholder); metas: per layer (running_mean, running_var, nbt, eps, momentum)
         L = len(metas)
         R, C1 = y1.shape
@@ -207,7 +211,7 @@ class _Stack(torch.autograd.Function):
                                                        sv[0].data_ptr(), sv[1].data_ptr(), out.data_ptr(), C, 1, st), "bn_relu_apply")
             saved.append(sv)
         ctx.save_for_backward(*ys, *saved, *([arg] if arg is not None else []), *tensors)
-        ctx.L, ctx.K = L, K
+        ctx.L, ctx.K, ctx.aux = L, K, aux
         ctx.has_bias = [tensors[4 * i + 3].numel() > 0 for i in range(L)]
         ctx.ws, ctx.ws_gen, ctx.ws_b_all = ws, ws.generation, ws_b
         return out
@@ -330,21 +334,39 @@ class _Stack(torch.autograd.Function):
             C1 = y1.shape[1]
             dy1 = torch.empty((R, C1), dtype=_f32, device=dev)
             dpar = torch.empty((3, C1), dtype=_f32, device=dev)
-            _native._check(_lib.pn2x_bn_bwd_apply(R, C1, g.data_ptr(), g.stride(0), y1.data_ptr(), y1.stride(0), sv1[0].data_ptr(),
-                                                  sv1[1].data_ptr(), gam(0).data_ptr(), bet(0).data_ptr(), 0, sums[0].data_ptr(),
-                                                  dy1.data_ptr(), C1, dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(), st),
-                           "bn_bwd_apply")
+            rel = None
+            if ctx.aux is not None:  # (aux dict of train_ops.sa_layer1, scale index): also d(W_xyz) = dY_1^T rel from this pass
+                adict, ai = ctx.aux
+                rel = adict.get("rel", [None] * (ai + 1))[ai]
+                if rel is None or not rel.is_contiguous() or rel.numel() != 3 * R or C1 > 256 or gmode != 0:
+                    rel = None
+            if rel is not None:
+                nf = int(_lib.pn2x_bn_bwd_apply_rel_scratch_floats(R, C1))
+                scratch = torch.empty(nf, dtype=_f32, device=dev)
+                dwx = torch.empty((C1, 3), dtype=_f32, device=dev)
+                _native._check(_lib.pn2x_bn_bwd_apply_rel(R, C1, g.data_ptr(), g.stride(0), y1.data_ptr(), y1.stride(0), sv1[0].data_ptr(),
+                                                          sv1[1].data_ptr(), gam(0).data_ptr(), bet(0).data_ptr(), 0, sums[0].data_ptr(),
+                                                          dy1.data_ptr(), C1, dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(),
+                                                          rel.data_ptr(), scratch.data_ptr(), nf, dwx.data_ptr(), st), "bn_bwd_apply_rel")
+                adict["dwx"][ai] = dwx
+            else:
+                _native._check(_lib.pn2x_bn_bwd_apply(R, C1, g.data_ptr(), g.stride(0), y1.data_ptr(), y1.stride(0), sv1[0].data_ptr(),
+                                                      sv1[1].data_ptr(), gam(0).data_ptr(), bet(0).data_ptr(), 0, sums[0].data_ptr(),
+                                                      dy1.data_ptr(), C1, dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(), st),
+                               "bn_bwd_apply")
             grads[1], grads[2] = dpar[0], dpar[1]
             if ctx.has_bias[0]:
                 grads[3] = dpar[2]
-        return (dy1, None, None, None, *grads)
+        return (dy1, None, None, None, None, *grads)
 
 
-def mlp_stack(y1: torch.Tensor, layers, ws, max_over: int = 0) -> torch.Tensor:
+def mlp_stack(y1: torch.Tensor, layers, ws, max_over: int = 0, aux=None) -> torch.Tensor:
     """relu(BN_L(... relu(BN_1(y1)) W_2^T ...)), optionally followed by the max over every `max_over` consecutive rows.
     y1 (R, C_1) pre-activations of layer 1 (without the conv bias: it cancels in the normalisation); layers: list of Layer;
     ws: train_ops.Workspace.  Conv biases get no gradient here (identically zero in front of a BatchNorm): the caller returns
-    zeros for them where the reference's `grad is None` mask needs a tensor."""
+    zeros for them where the reference's `grad is None` mask needs a tensor.
+    aux = (dict, i): the side channel of train_ops.sa_layer1 whose i-th output y1 is (its relative coordinates are read from
+    dict["rel"][i]; the first-layer backward then also leaves d(W_xyz) in dict["dwx"][i])."""
     R = y1.shape[0]
     if max_over and R % max_over:
         raise ValueError("mlp_stack: rows must be a multiple of max_over")
@@ -359,7 +381,7 @@ def mlp_stack(y1: torch.Tensor, layers, ws, max_over: int = 0) -> torch.Tensor:
                       bn.num_batches_tracked if track else None, bn.eps, bn.momentum if bn.momentum is not None else 0.1))
         none = y1.new_empty(0)
         tensors += [l.weight if i else none, bn.weight, bn.bias, l.conv_bias if l.conv_bias is not None else none]
-    return _Stack.apply(y1, int(max_over), ws, metas, *tensors)
+    return _Stack.apply(y1, int(max_over), ws, metas, aux, *tensors)
 
 
 def stack_supported(c1: int, widths) -> bool:

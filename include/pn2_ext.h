@@ -375,6 +375,14 @@ int pn2x_bn_bwd_apply(long rows, int c, const float *g, int ldg, const float *y,
                       const float *gamma, const float *beta, int relu, const double *sums, float *dy, int ldo, float *dgamma,
                       float *dbeta, float *dbias, void *stream);
 
+/* pn2x_bn_bwd_apply for the first layer of a set-abstraction scale, also forming dwx (c x 3) = dy^T rel from the dy it has in
+ * registers (rel (rows x 3): the relative coordinates pn2x_sa_layer1 wrote) -- the separate pn2x_rows_outer3 pass disappears.
+ * c <= 256; scratch: pn2x_bn_bwd_apply_rel_scratch_floats(rows, c) floats. */
+long pn2x_bn_bwd_apply_rel_scratch_floats(long rows, int c);
+int pn2x_bn_bwd_apply_rel(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean, const float *invstd,
+                          const float *gamma, const float *beta, int relu, const double *sums, float *dy, int ldo, float *dgamma,
+                          float *dbeta, float *dbias, const float *rel, float *scratch, long scratch_floats, float *dwx, void *stream);
+
 /*
  * Train-mode [Conv 1x1 + BatchNorm + ReLU] layers with the BatchNorm folded into fp32-MFMA GEMMs (csrc/train_gemm.hip;
  * reference composition: pointnet_utils.py:399-403, :460-462, :504-506, :577-581 as Conv2d/Conv1d + BatchNorm + ReLU modules).

@@ -95,7 +95,7 @@ class FastTrain:
         return all(w % 4 == 0 and w <= 1024 for w in widths)
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _stack(self, x2d, convs, bns, first_done=False, max_over=0):
+    def _stack(self, x2d, convs, bns, first_done=False, max_over=0, aux=None):
         """[1x1 conv + train-mode BatchNorm + ReLU]*; max_over = K > 0: the last layer also takes the max over every K
         consecutive rows (its full-size activations are then never written).  Layers 2.. run as fused BatchNorm GEMMs
         (hotrack_amd.train_stack: normalise + ReLU on load, statistics in the epilogue, dY on load in the backward) when
@@ -108,7 +108,7 @@ class FastTrain:
                 y1 = x2d if first_done else F.linear(x2d, _w2d(convs[0]))
                 layers = [train_stack.Layer(None, bns[0], convs[0].bias)]
                 layers += [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(convs[1:], bns[1:])]
-                return train_stack.mlp_stack(y1, layers, self.ws, max_over)
+                return train_stack.mlp_stack(y1, layers, self.ws, max_over, aux=aux if first_done else None)
         last = len(convs) - 1
         for i, (conv, bn) in enumerate(zip(convs, bns)):
             y = x2d if (first_done and i == 0) else F.linear(x2d, _w2d(conv))
@@ -144,11 +144,13 @@ class FastTrain:
         if center2d is not None:
             wc = w1[0][2] if len(w1) == 1 else torch.cat([w[2] for w in w1], dim=0)
             cadd = F.linear(center2d, wc).view(B, S, -1)
-        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1], invs=invs)
+        aux = {} if self.use_fused_stacks else None  # relative coordinates -> the stacks, d(W_xyz) <- the stacks (train_ops.sa_layer1)
+        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1], invs=invs, aux=aux)
         outs = []
         for i, y1 in enumerate(y1s):
             K = idxs[i].shape[2]
-            h = self._stack(y1.view(B * S * K, -1), mod.conv_blocks[i], mod.bn_blocks[i], first_done=True, max_over=K)
+            h = self._stack(y1.view(B * S * K, -1), mod.conv_blocks[i], mod.bn_blocks[i], first_done=True, max_over=K,
+                            aux=None if aux is None else (aux, i))
             outs.append(h.view(B, S, -1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
 
