@@ -42,13 +42,16 @@ def _time_linear(x, w, scoped: bool) -> float:
     try:
         for _ in range(3):
             F.linear(x, w)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            F.linear(x, w)
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / 10.0
+        best = float("inf")
+        for _ in range(5):  # the minimum of five short runs: other work on the GPU (a test suite, another stream) only ever adds time
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                F.linear(x, w)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 10.0)
+        return best
     finally:
         tunable.enable(was)
 
@@ -71,7 +74,7 @@ def _self_test(loaded: bool):
             w = torch.randn(cout, cin, device="cuda")
             t_tab, t_def = _time_linear(x, w, True), _time_linear(x, w, False)
             detail["%dx%d->%d" % (rows, cin, cout)] = {"table_ms": round(t_tab, 4), "default_ms": round(t_def, 4)}
-            lost |= t_tab > 1.25 * t_def
+            lost |= t_tab > 1.5 * t_def  # (a stale table is 3-10x off on these shapes; timing noise is not)
         _state["detail"] = detail
         _state["status"] = "stale" if lost else "applied"
         if lost:
