@@ -145,6 +145,16 @@ tg_bwd_kernel(BwdArgs a) {
     long tile = blockIdx.x;
     if (tile < T) prefetch(tile);  // the first tile's operands travel while the constants (and W_i) are set up
 
+    // W_i (where it is LDS-resident) is requested before the constants are derived and stored after them: one memory round trip
+    constexpr int WQ = Kd * N / 4, WCNT = P::WLDS ? (WQ + kT - 1) / kT : 1;
+    float4 wreg[WCNT];
+    if constexpr (P::WLDS) {
+#pragma unroll
+        for (int i = 0; i < WCNT; ++i) {
+            const int e = tid + i * kT, kd = e / (N / 4), q = e % (N / 4);
+            if (e < WQ) wreg[i] = *reinterpret_cast<const float4 *>(a.W + (size_t)kd * a.ldw + 4 * q);
+        }
+    }
     {
         const float inv_r = (float)(1.0 / (double)a.R);
         for (int c = tid; c < Kd; c += kT) {
@@ -163,11 +173,13 @@ tg_bwd_kernel(BwdArgs a) {
         }
         if (blockIdx.x == 0)
             for (int e = tid; e < Kd * N; e += kT) a.dW[e] = 0.f;
-        if constexpr (P::WLDS)
-            for (int e = tid; e < Kd * N / 4; e += kT) {
-                const int kd = e / (N / 4), q = e % (N / 4);
-                *reinterpret_cast<float4 *>(Ws + kd * N + 4 * q) = *reinterpret_cast<const float4 *>(a.W + (size_t)kd * a.ldw + 4 * q);
+        if constexpr (P::WLDS) {
+#pragma unroll
+            for (int i = 0; i < WCNT; ++i) {
+                const int e = tid + i * kT, kd = e / (N / 4), q = e % (N / 4);
+                if (e < WQ) *reinterpret_cast<float4 *>(Ws + kd * N + 4 * q) = wreg[i];
             }
+        }
     }
     __syncthreads();
 

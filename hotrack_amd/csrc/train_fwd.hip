@@ -78,6 +78,15 @@ tgf_kernel(FwdArgs a) {
     };
     long tile = blockIdx.x;
     if (tile < tiles) prefetch(tile);  // the first tile's operands travel while the constants and W_i are set up
+    // W_i's slice: requested now, stored to LDS after the constants (one memory round trip for both instead of two in a row)
+    constexpr int WCNT = NW * (K / 4) / T;
+    static_assert(NW * (K / 4) % T == 0, "W_i slice splits evenly over the workgroup");
+    float4 wreg[WCNT];
+#pragma unroll
+    for (int i = 0; i < WCNT; ++i) {
+        const int e = tid + i * T, n = e / (K / 4), q = e % (K / 4);
+        wreg[i] = *reinterpret_cast<const float4 *>(a.W + (size_t)(n0 + n) * a.ldw + 4 * q);
+    }
     for (int k = tid; k < K; k += T) {
         double s1 = 0.0, s2 = 0.0;
         for (int r = 0; r < kBnRep; ++r) {
@@ -101,11 +110,11 @@ tgf_kernel(FwdArgs a) {
         }
     }
     if (first && tid == 0 && a.nbt) *a.nbt += 1;
-    for (int e = tid; e < NW * (K / 4); e += T) {
-        const int n = e / (K / 4), q = e % (K / 4);
-        const float4 w = *reinterpret_cast<const float4 *>(a.W + (size_t)(n0 + n) * a.ldw + 4 * q);
+#pragma unroll
+    for (int i = 0; i < WCNT; ++i) {
+        const int e = tid + i * T, n = e / (K / 4), q = e % (K / 4);
         float *dst = Ws + n * LDK + 4 * q;
-        dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+        dst[0] = wreg[i].x; dst[1] = wreg[i].y; dst[2] = wreg[i].z; dst[3] = wreg[i].w;
     }
     __syncthreads();
 
