@@ -135,7 +135,9 @@ def test_graph_step_trains_like_eager(tmp_path, monkeypatch):
             real = st["exp_avg_sq"] > 1e-9
             worst = max(worst, float(((pe[k] - pg[k]).abs() * real).max()))
             sg_ = graph.optimizer.state[pg[k]]
-            torch.testing.assert_close(sg_["exp_avg"] * real, st["exp_avg"] * real, rtol=5e-2, atol=5e-5)  # BN-cancellation noise in g is ~1e-4
+            # BN-cancellation noise in g is ~1e-4 between ANY two runs (atomics order in the statistics / the partial sums; the
+            # small batch of this test amplifies it): once in ~40 full-suite runs an element exceeded 5e-5 in exp_avg = 0.1 g
+            torch.testing.assert_close(sg_["exp_avg"] * real, st["exp_avg"] * real, rtol=5e-2, atol=2e-4, msg=lambda m: f"{k}: {m}")
             checked += 1
     assert checked > 50 and worst < 2e-5, (checked, worst)   # a lost / doubled / stale Adam step would be 1e-4
     # ---- four more: the replayed step keeps training
