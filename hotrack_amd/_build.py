@@ -2,8 +2,10 @@
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
+import sys
 from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +28,24 @@ HIPCC_FLAGS = [
 # canonicalises every v_max operand first (v_max x, x, x): ~130 extra VALU instructions per tile in a kernel whose every
 # non-MFMA instruction costs an issue slot of the matrix pipe's bubbles.  Arithmetic results are unchanged for non-NaN inputs.
 PER_FILE_FLAGS = {"sa_fused.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
+
+
+_REMARK_CONTEXT = re.compile(r"^\s*(\d+ \||\|)")   # the source-line echo under a remark
+
+
+def scratch_kernels(remarks: str) -> dict:
+    """{mangled kernel name: scratch bytes per lane} for the kernels of a -Rpass-analysis=kernel-resource-usage compile
+    whose ScratchSize is not zero."""
+    bad, name = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r"remark:\s+ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name is not None and int(m.group(1)) != 0:
+            bad[name] = int(m.group(1))
+    return bad
 
 
 def _hipcc() -> str:
@@ -62,10 +82,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr)):
             return obj
         cmd = [hipcc, *HIPCC_FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []),
-               *os.environ.get("PN2_EXTRA_HIPCC_FLAGS", "").split(), "-c", src, "-o", obj]  # env: tuning sweeps
+               *os.environ.get("PN2_EXTRA_HIPCC_FLAGS", "").split(), "-Rpass-analysis=kernel-resource-usage",
+               "-c", src, "-o", obj]  # env: tuning sweeps
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        diag = "\n".join(ln for ln in p.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln
+                         and not _REMARK_CONTEXT.match(ln))
+        if diag.strip():
+            print(diag, file=sys.stderr)
+        if p.returncode:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        # No kernel may use scratch (private) memory: a register array that hipcc leaves there costs 5-10x on a hot loop
+        #  and is invisible in the source.  PN2_ALLOW_SCRATCH=1 lets a tuning build through.
+        bad = scratch_kernels(p.stderr)
+        if bad and os.environ.get("PN2_ALLOW_SCRATCH", "0") != "1":
+            if os.path.exists(obj):
+                os.remove(obj)
+            raise RuntimeError("%s: kernels with scratch memory (bytes/lane): %s" % (os.path.basename(src), bad))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

@@ -241,37 +241,73 @@ knn_wave_kernel(int n, int m, int k, const float *__restrict__ unknown_all, cons
     }
 }
 
-// Fallback for m > 64*32 candidates: thread per query, reference-style insertion list in
-// private memory (k <= 200).  Correct for any m; not tuned.
-__global__ void __launch_bounds__(64)
-knn_thread_kernel(int n, int m, int k, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
+// m > 64*32 candidates (any m): still one WAVE per query, but the candidates stream past in steps of 64 and the k best keys
+// live as a sorted list in LDS.  A step computes 64 keys, ballots those below the current k-th key (wave-uniform, in SGPRs)
+// and inserts the few that pass one by one in lane (= index) order: every lane owns the list entries e = lane + 64 s, reads
+// entry e and e-1, and the new entry e is old[e] (below the new key), the new key (old[e-1] below it, old[e] not) or
+// old[e-1] -- a shift by one done with two LDS reads and one write per entry, no private-memory arrays (the reference keeps
+// double[200] + int[200] per thread in local memory; so did this fallback until round 4: 1616 bytes of scratch per lane).
+// After the first few steps almost nothing passes the ballot (expected k (1 + ln(m / k)) insertions per query in total), so the
+// scan runs at the rate of its distance evaluations.  The result is the k smallest (distance, index) keys in order, i.e. the
+// reference's insertion list (strict `<`: an equal distance at a higher index never displaces a lower one).
+template <int NS>  // list slots per lane: k <= 64 NS
+__global__ void __launch_bounds__(256)
+knn_stream_kernel(int n, int m, int k, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
                   float *__restrict__ dist2_all, int *__restrict__ idx_all, int k2, int *__restrict__ idx2_all) {
+    __shared__ unsigned long long lists[4][64 * NS];
     const int b = blockIdx.y;
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= n) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= n) return;  // wave-uniform; the kernel has no workgroup barrier
+    // volatile: the accesses below stay in program order (a wave executes its LDS instructions in order, so "all reads of an
+    // insertion before its writes" in the program is what the other lanes of the wave observe)
+    volatile unsigned long long *L = lists[wv];
     const float *__restrict__ known = known_all + (size_t)b * m * 3;
     const float *__restrict__ u = unknown_all + ((size_t)b * n + q) * 3;
     const float ux = u[0], uy = u[1], uz = u[2];
-    float best[PN2_KNN_MAX_K];
-    int besti[PN2_KNN_MAX_K];
-    for (int i = 0; i < k; ++i) { best[i] = __builtin_inff(); besti[i] = 0; }
-    for (int i = 0; i < m; ++i) {
-        const float d = sqdist(ux, uy, uz, known[3 * i], known[3 * i + 1], known[3 * i + 2]);
-        if (!(d < best[k - 1])) continue;
-        int j = k - 1;
-        while (j > 0 && d < best[j - 1]) { best[j] = best[j - 1]; besti[j] = besti[j - 1]; --j; }
-        best[j] = d;
-        besti[j] = i;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) L[lane + 64 * s] = kInfKey;
+    unsigned long long kth = kInfKey;  // wave-uniform: the current k-th best key
+    for (int base = 0; base < m; base += 64) {
+        const int c = base + lane;
+        const bool in = c < m;
+        const float *src = known + (size_t)3 * (in ? c : 0);
+        const float d = sqdist(ux, uy, uz, src[0], src[1], src[2]);
+        // `d < best[k-1]` against the 1e40 sentinel never admits inf / NaN (interpolate_gpu.cu:33,41)
+        const unsigned long long key = (in && d < __builtin_inff()) ? (((unsigned long long)(unsigned)f2i(d) << 32) | (unsigned)c) : kInfKey;
+        uint64_t pass = __ballot(key < kth);
+        while (pass) {
+            const int l = __builtin_ctzll(pass);
+            pass &= pass - 1;
+            const unsigned long long kb = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), l) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, l);
+            if (!(kb < kth)) continue;  // (wave-uniform) the k-th key has dropped since the ballot
+            unsigned long long cur[NS], prev[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int e = lane + 64 * s;
+                cur[s] = L[e];
+                prev[s] = e > 0 ? L[e - 1] : 0ull;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) L[lane + 64 * s] = cur[s] < kb ? cur[s] : (prev[s] < kb ? kb : prev[s]);
+            kth = L[k - 1];  // broadcast read of the entry just written
+            kth = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kth >> 32)) << 32) |
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kth);
+        }
     }
-    int *oi = idx_all + ((size_t)b * n + q) * k;
-    for (int i = 0; i < k; ++i) oi[i] = besti[i];
-    if (dist2_all) {  // index-only callers (pn2x_knn_indices) pass no distance buffer
-        float *od = dist2_all + ((size_t)b * n + q) * k;
-        for (int i = 0; i < k; ++i) od[i] = best[i];
-    }
-    if (idx2_all) {   // the first k2 entries again, contiguous (the smaller neighbourhood of a multi-scale module)
-        int *o2 = idx2_all + ((size_t)b * n + q) * k2;
-        for (int i = 0; i < k2; ++i) o2[i] = besti[i];
+    float *__restrict__ od = dist2_all ? dist2_all + ((size_t)b * n + q) * k : nullptr;
+    int *__restrict__ oi = idx_all + ((size_t)b * n + q) * k;
+    int *__restrict__ oi2 = idx2_all ? idx2_all + ((size_t)b * n + q) * k2 : nullptr;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = lane + 64 * s;
+        if (e < k) {
+            const unsigned long long v = L[e];
+            if (od) od[e] = i2f((int)(unsigned)(v >> 32));
+            oi[e] = (int)(unsigned)v;
+            if (oi2 && e < k2) oi2[e] = (int)(unsigned)v;
+        }
     }
 }
 
@@ -286,8 +322,10 @@ int knn_dispatch(int b, int n, int m, int k, const float *unknown, const float *
     }
     PN2_KNN_CASE(1) PN2_KNN_CASE(2) PN2_KNN_CASE(4) PN2_KNN_CASE(8) PN2_KNN_CASE(16) PN2_KNN_CASE(32)
 #undef PN2_KNN_CASE
-    dim3 grid2((n + 63) / 64, b);
-    hipLaunchKernelGGL(knn_thread_kernel, grid2, dim3(64), 0, st, n, m, k, unknown, known, dist2, idx, k2, idx2);
+    if (k <= 64) hipLaunchKernelGGL(knn_stream_kernel<1>, grid, dim3(256), 0, st, n, m, k, unknown, known, dist2, idx, k2, idx2);
+    else if (k <= 128) hipLaunchKernelGGL(knn_stream_kernel<2>, grid, dim3(256), 0, st, n, m, k, unknown, known, dist2, idx, k2, idx2);
+    else hipLaunchKernelGGL(knn_stream_kernel<4>, grid, dim3(256), 0, st, n, m, k, unknown, known, dist2, idx, k2, idx2);
+    static_assert(PN2_KNN_MAX_K <= 256, "knn_stream_kernel<4> holds 256 list entries");
     return check_launch();
 }
 

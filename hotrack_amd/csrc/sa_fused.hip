@@ -159,9 +159,12 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     // term W2e x_e is added on the VALU when the layer-2 accumulators are written out.
     constexpr bool ROWS = MODE == 4 || MODE == 5, ROWS_EXTRA = MODE == 5;
     static_assert(!ROWS_EXTRA || SA_PAD >= 4, "the extra input columns live in the LDS row padding");
-    const bool has_a1f = MODE == 3 ? A.a1f != nullptr : MODE >= 1;
-    const bool has_xyz = MODE == 3 ? A.xyz != nullptr : !ROWS;
-    const bool has_cadd = MODE == 3 ? A.cadd != nullptr : MODE == 2;
+    // MODE 3 runs the code of MODE 2 (all three operands); an absent operand gets a zero-length buffer descriptor, whose loads
+    // return 0 through the hardware bounds check (and Wx = 0 without coordinates): no run-time branches in the LOAD role, and the
+    // register budget of MODE 2 (tested at run time, the 128-128-192 instance spilled 12-24 registers to scratch memory).
+    constexpr bool has_a1f = MODE >= 1, has_xyz = !ROWS, has_cadd = MODE == 2 || MODE == 3;
+    const bool p_a1f = MODE == 3 ? A.a1f != nullptr : has_a1f, p_xyz = MODE == 3 ? A.xyz != nullptr : has_xyz;
+    const bool p_cadd = MODE == 3 ? A.cadd != nullptr : has_cadd;
     constexpr int lgK = K == 16 ? 4 : K == 32 ? 5 : 6;
     const int N = A.N, S = A.S;
     const float *__restrict__ W2 = A.w2, *__restrict__ b2 = A.b2, *__restrict__ W3 = A.w3, *__restrict__ b3 = A.b3;
@@ -196,7 +199,7 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     float wxr[4][3] = {{0.f}};
     float4 b1r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!compute) {
-        if (has_xyz) {
+        if (p_xyz) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -241,8 +244,8 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     const unsigned a1f_ldb = 4u * (unsigned)A.a1f_ld, cadd_ldb = 4u * (unsigned)A.cadd_ld;
     const unsigned idx_cloud = 4u * (unsigned)SK, a1f_cloud = (unsigned)N * a1f_ldb, xyz_cloud = 12u * (unsigned)N;
     const unsigned cxyz_cloud = 12u * (unsigned)S, cadd_cloud = (unsigned)S * cadd_ldb;
-    const rsrc_t ra_all = make_rsrc(A.a1f, has_a1f ? (unsigned)A.B * a1f_cloud : 0u);
-    const rsrc_t rx_all = make_rsrc(A.xyz, has_xyz ? (unsigned)A.B * xyz_cloud : 0u);
+    const rsrc_t ra_all = make_rsrc(A.a1f, p_a1f ? (unsigned)A.B * a1f_cloud : 0u);
+    const rsrc_t rx_all = make_rsrc(A.xyz, p_xyz ? (unsigned)A.B * xyz_cloud : 0u);
     struct HalfIdx { int jj[RPT], ss; };
     struct HalfRows { float4 a[RPT], pj[RPT], c, cs, e; };  // pj / cs: (x, y, z, the following record's x -- unused); e: MODE 5
     auto load_idx = [&](const Cursor &cu, int h, HalfIdx &I) {
@@ -276,12 +279,12 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
             if (ROWS_EXTRA && lt < TM / 2) D.e = ld_b128(ra_all, mad24(I.jj[0] - row0 + lt, a1f_ldb, 4u * C1), so);
         }
         if (has_cadd) {
-            const rsrc_t rd = make_rsrc(reinterpret_cast<const char *>(A.cadd) + (size_t)b * cadd_cloud, cadd_cloud);
+            const rsrc_t rd = make_rsrc(reinterpret_cast<const char *>(A.cadd) + (size_t)b * cadd_cloud, p_cadd ? cadd_cloud : 0u);
             D.c = ld_b128(rd, mad24(I.ss, cadd_ldb, c4x16), 0);
         }
         if (has_xyz) {
             const int so = (int)((unsigned)b * xyz_cloud);
-            const rsrc_t rc = make_rsrc(reinterpret_cast<const char *>(A.cxyz) + (size_t)b * cxyz_cloud, cxyz_cloud);
+            const rsrc_t rc = make_rsrc(reinterpret_cast<const char *>(A.cxyz) + (size_t)b * cxyz_cloud, p_xyz ? cxyz_cloud : 0u);
 #pragma unroll
             for (int r = 0; r < RPT; ++r) D.pj[r] = ld_b128(rx_all, mul24(I.jj[r], 12u), so);
             D.cs = ld_b128(rc, mul24(I.ss, 12u), 0);

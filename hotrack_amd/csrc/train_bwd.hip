@@ -35,6 +35,7 @@ namespace tgb {
 constexpr int kT = 512;
 constexpr int BM = 64;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float relu_nan(float h) { return !(h <= 0.f) ? h : 0.f; }  // propagates NaN like torch
 
@@ -147,12 +148,12 @@ tg_bwd_kernel(BwdArgs a) {
 
     // W_i (where it is LDS-resident) is requested before the constants are derived and stored after them: one memory round trip
     constexpr int WQ = Kd * N / 4, WCNT = P::WLDS ? (WQ + kT - 1) / kT : 1;
-    float4 wreg[WCNT];
+    f32x4 wreg[WCNT];  // a native vector type: an array of float4 structs is copied with memcpy and stays in scratch memory
     if constexpr (P::WLDS) {
 #pragma unroll
         for (int i = 0; i < WCNT; ++i) {
-            const int e = tid + i * kT, kd = e / (N / 4), q = e % (N / 4);
-            if (e < WQ) wreg[i] = *reinterpret_cast<const float4 *>(a.W + (size_t)kd * a.ldw + 4 * q);
+            const int e0 = tid + i * kT, e = e0 < WQ ? e0 : WQ - 1, kd = e / (N / 4), q = e % (N / 4);  // unconditional clamped loads
+            wreg[i] = *reinterpret_cast<const f32x4 *>(a.W + (size_t)kd * a.ldw + 4 * q);
         }
     }
     {
@@ -177,7 +178,7 @@ tg_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int i = 0; i < WCNT; ++i) {
                 const int e = tid + i * kT, kd = e / (N / 4), q = e % (N / 4);
-                if (e < WQ) *reinterpret_cast<float4 *>(Ws + kd * N + 4 * q) = wreg[i];
+                if (e < WQ) *reinterpret_cast<f32x4 *>(Ws + kd * N + 4 * q) = wreg[i];
             }
         }
     }

@@ -39,6 +39,7 @@ constexpr int LDK = KC + 1;  // k-minor LDS tiles: odd stride
 constexpr int RC = 32;       // rows per chunk (wgrad: the reduction runs over rows)
 constexpr int kMaxC = 512;   // channels of a fused layer (LDS constant tables)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float relu_nan(float h) { return !(h <= 0.f) ? h : 0.f; }  // propagates NaN like torch
 
@@ -334,7 +335,8 @@ tg_dgrad_kernel(DgradArgs a) {
     constexpr int BQ = NT / 4;        // float4 per weight row
     constexpr int BI = NT / 32;       // weight float4 per thread and chunk
     const int jq = tid % BQ, kr0 = tid / BQ;
-    float4 pg[4], py[4], pb[BI];
+    float4 pg[4], py[4];
+    f32x4 pb[BI];  // native vector type: a conditionally written array of float4 structs stays in scratch memory (memcpy copies)
     int4 par[4];
     const DySrc &d = a.dy;
     auto prefetch = [&](long tile, int chunk, bool with_b) {
@@ -355,7 +357,7 @@ tg_dgrad_kernel(DgradArgs a) {
         if (with_b) {
 #pragma unroll
             for (int i = 0; i < BI; ++i)
-                pb[i] = *reinterpret_cast<const float4 *>(a.W + (size_t)(chunk * KC + kr0 + (kT / BQ) * i) * a.ldw + n0 + 4 * jq);
+                pb[i] = *reinterpret_cast<const f32x4 *>(a.W + (size_t)(chunk * KC + kr0 + (kT / BQ) * i) * a.ldw + n0 + 4 * jq);
         }
     };
     auto commit = [&](long tile, int chunk, bool with_b) {
@@ -378,7 +380,7 @@ tg_dgrad_kernel(DgradArgs a) {
         }
         if (with_b) {
 #pragma unroll
-            for (int i = 0; i < BI; ++i) *reinterpret_cast<float4 *>(Bs + (kr0 + (kT / BQ) * i) * NT + 4 * jq) = pb[i];
+            for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4 *>(Bs + (kr0 + (kT / BQ) * i) * NT + 4 * jq) = pb[i];
         }
     };
 

@@ -120,3 +120,24 @@ def test_tuned_gemm_table_is_well_formed():
     if not torch.cuda.is_available():
         assert gemm_tuning.enable() is False  # no GPU: nothing is touched
         assert gemm_tuning.status()["gemm_table"] == "off"
+
+
+def test_build_refuses_kernels_with_scratch_memory(tmp_path):
+    """The build parses hipcc's kernel-resource-usage remarks and fails on any kernel that uses scratch (private) memory
+    (hot tg_bwd / tg_dgrad instantiations kept a register array there unnoticed)."""
+    import subprocess
+    from hotrack_amd import _build
+    sample = ("a.hip:1:1: remark: Function Name: _Z3foov [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:9:1: remark: Function Name: _Z3barv [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:9:1: remark:     ScratchSize [bytes/lane]: 48 [-Rpass-analysis=kernel-resource-usage]\n")
+    assert _build.scratch_kernels(sample) == {"_Z3barv": 48}
+    # a real compile: a dynamically indexed private array must live in scratch memory
+    src = tmp_path / "scr.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n__global__ void k(float *o, const int *i, int n) {\n  float a[64];\n'
+                   '  for (int j = 0; j < 64; ++j) a[j] = o[j];\n  for (int j = 0; j < n; ++j) a[i[j] & 63] += 1.f;\n'
+                   '  o[threadIdx.x] = a[i[threadIdx.x] & 63];\n}\n')
+    p = subprocess.run([_build._hipcc(), *_build.HIPCC_FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o",
+                        str(tmp_path / "scr.o")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert list(_build.scratch_kernels(p.stderr).values())[0] >= 256

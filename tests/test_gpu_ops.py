@@ -141,7 +141,9 @@ def test_three_nn(ops, oracle, B, n, m, kind):
 
 KNN_CASES = [(4, 21, 1024, 16), (4, 21, 1024, 64), (2, 21, 1024, 4), (2, 21, 1024, 200), (2, 30, 1000, 50),
              (2, 17, 100, 7), (2, 5, 64, 64), (2, 9, 2048, 33), (1, 40, 3000, 20), (2, 8, 10, 16), (2, 4, 1, 1),
-             (2, 128, 512, 32)]
+             (2, 128, 512, 32),
+             # m > 2048: the streaming kernel (sorted LDS list), one case per list-slot instantiation + ragged last step
+             (2, 21, 8192, 64), (2, 33, 4097, 16), (1, 10, 5000, 100), (1, 7, 20000, 200), (2, 9, 2049, 129)]
 
 
 @pytest.mark.parametrize("B,n,m,k", KNN_CASES)
