@@ -69,9 +69,11 @@ def _self_test(loaded: bool):
         return
     else:
         detail, lost = {}, False
+        gen = torch.Generator(device="cuda")  # a private generator: the self-test must not advance the default CUDA RNG stream
+        gen.manual_seed(0)                    # (whether / when the first enable() fires would change every later torch dropout mask)
         for rows, cin, cout in SENTINELS:
-            x = torch.randn(rows, cin, device="cuda")
-            w = torch.randn(cout, cin, device="cuda")
+            x = torch.randn(rows, cin, device="cuda", generator=gen)
+            w = torch.randn(cout, cin, device="cuda", generator=gen)
             # interleaved, minimum of three rounds each (and each round the minimum of five runs): the first measurement of a
             # process runs on clocks that are still ramping -- a 20 us GEMM once read 33 us that way and the table was declared stale
             t_tab = t_def = float("inf")
@@ -80,6 +82,7 @@ def _self_test(loaded: bool):
                 t_tab = min(t_tab, _time_linear(x, w, True))
             detail["%dx%d->%d" % (rows, cin, cout)] = {"table_ms": round(t_tab, 4), "default_ms": round(t_def, 4)}
             lost |= t_tab > 1.5 * t_def  # (a stale table is 3-10x off on these shapes; timing noise is not)
+            del x, w  # ~100 MB for the large sentinel: returned to the allocator before the next one is drawn
         _state["detail"] = detail
         _state["status"] = "stale" if lost else "applied"
         if lost:

@@ -55,9 +55,25 @@ class FusedAdam(torch.optim.Optimizer):
                     or stp.untyped_storage().data_ptr() != buf.untyped_storage().data_ptr()):
                 # a loaded state dict (torch.optim.Adam's or ours; host counters if it was not capturable): re-home the counter
                 new = self._new_step(p.device)
-                new.fill_(float(stp))
+                new.copy_(stp if torch.is_tensor(stp) else torch.tensor(float(stp)))  # (no host read of a device counter)
                 st["step"] = new
         return st
+
+    def load_state_dict(self, state_dict):
+        """torch's loader, then every step counter is re-homed ONCE, eagerly, into a fresh shared buffer (counters of a loaded
+        state -- torch.optim.Adam's or ours -- are separate tensors; re-homing them lazily inside step() could overflow the
+        buffer of an optimiser that had already stepped and would then re-home, with a host sync, inside a later step or a
+        graph capture)."""
+        super().load_state_dict(state_dict)
+        self._step_bufs = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "step" in st:
+                    stp = st["step"]
+                    new = self._new_step(p.device)
+                    new.copy_(stp if torch.is_tensor(stp) else torch.tensor(float(stp)))
+                    st["step"] = new
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -71,6 +87,8 @@ class FusedAdam(torch.optim.Optimizer):
             if not ps:
                 continue
             n = len(ps)
+            if any(p.device != ps[0].device for p in ps):
+                raise RuntimeError("FusedAdam: the parameters of a group must live on one device (one launch, one stream)")
             arr = lambda: (_vp * n)()
             P, G, M, V, S = arr(), arr(), arr(), arr(), arr()
             N = (ctypes.c_long * n)()

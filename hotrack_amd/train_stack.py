@@ -93,21 +93,64 @@ DEFER_REDUCE = (_os.environ.get("HOTRACK_STACK_DEFER_REDUCE", "1") != "0" and ha
                 and hasattr(torch.autograd.Variable._execution_engine, "queue_callback"))  # (engine hooks of this torch build)
 _pending = []
 _pending_task = [None]  # the autograd pass the pending items belong to (a pass that raised leaves stale ones behind)
+_pending_params = set()  # data pointers of the parameters whose gradients of this pass are still unreduced
+
+
+def _enter_task():
+    """Pending state belongs to ONE autograd pass: entering another one drops what a pass that raised left behind.
+    Returns True when this call opened the pass (the end-of-pass callback must then be queued)."""
+    task = torch._C._current_graph_task_id()
+    if _pending_task[0] == task:
+        return False
+    _pending.clear()
+    _pending_params.clear()
+    _pending_task[0] = task
+    return True
 
 
 def _defer(item):
-    task = torch._C._current_graph_task_id()
-    if _pending_task[0] != task:
-        _pending.clear()
-        _pending_task[0] = task
+    if _enter_task():
         torch.autograd.Variable._execution_engine.queue_callback(_flush_reductions)
     _pending.append(item)
 
 
 def _flush_reductions():
     items, _pending[:] = list(_pending), []
+    _pending_params.clear()
     _pending_task[0] = None
     _reduce_items(items)
+
+
+def _flush_now():
+    """Reduce what is pending without ending the pass (the queued end-of-pass callback then finds nothing)."""
+    items, _pending[:] = list(_pending), []
+    _pending_params.clear()
+    _reduce_items(items)
+
+
+def _has_hooks(t) -> bool:
+    return bool(getattr(t, "_backward_hooks", None)) or bool(getattr(t, "_post_accumulate_grad_hooks", None))
+
+
+def _may_defer(params) -> bool:
+    """Deferring is sound only where autograd ADOPTS the returned tensor as .grad and nothing reads it inside the pass: every
+    parameter a leaf without gradient and without hooks (tensor hooks / post-accumulate hooks run inside the pass), and used
+    by ONE stack node of this pass.  A parameter met a second time in a pass (weight tying, a module called twice before one
+    backward()) would have its two gradients summed by autograd right when this node returns: the pending reductions --
+    the first use's among them -- run now, and this node reduces immediately."""
+    if not DEFER_REDUCE:
+        return False
+    if torch._C._current_graph_task_id() != _pending_task[0]:
+        _pending.clear()          # (a pass that raised left these behind)
+        _pending_params.clear()
+        _pending_task[0] = None
+    ptrs = [t.data_ptr() for t in params]
+    if any(p in _pending_params for p in ptrs) or len(set(ptrs)) != len(ptrs):
+        _flush_now()
+        return False
+    if not all(t.is_leaf and t.grad is None and not _has_hooks(t) for t in params):
+        return False
+    return True
 
 
 def _pending_now(item):
@@ -244,8 +287,13 @@ class _Stack(torch.autograd.Function):
         # deferring is only sound when autograd ADOPTS the returned tensors (grad is None); an in-place accumulation into an
         # existing .grad would read them before the reduction ran
         # (nor may anything downstream consume them inside the pass: leaves only)
-        defer = DEFER_REDUCE and all(tensors[j].is_leaf and tensors[j].grad is None
-                                     for i in range(1, L) for j in (4 * i, 4 * i + 1, 4 * i + 2))
+        # (the conv bias shares dpar with gamma / beta: dpar[2] is written by the same deferred launch)
+        dparams = [tensors[j] for i in range(1, L) for j in (4 * i, 4 * i + 1, 4 * i + 2)]
+        dparams += [tensors[4 * i + 3] for i in range(1, L) if ctx.has_bias[i]]
+        defer = _may_defer(dparams)
+        if defer:
+            _enter_task() and torch.autograd.Variable._execution_engine.queue_callback(_flush_reductions)
+            _pending_params.update(t.data_ptr() for t in dparams)
         gam = lambda i: tensors[4 * i + 1]
         bet = lambda i: tensors[4 * i + 2]
         with torch.cuda.device(dev):

@@ -248,7 +248,37 @@ class FastTail:
 
     def __init__(self, net):
         self.net = net
-        self.seed = None
+        self.seed = None   # device counter, created at the first forward (see _seed_tensor)
+        self._restore = None
+
+    # The dropout masks are a hash of (counter, site, element); the counter lives on the device (capture-safe) and advances by
+    # one per forward.  It STARTS from torch's seed mixed with the data-parallel rank -- torch.manual_seed() selects the stream,
+    # ranks draw different masks (like the CUDA generator the reference's torch dropout uses) -- and is part of a checkpoint
+    # (Trainer.save / resume via dropout_state()), so a resumed run continues the stream instead of replaying it.
+    def _seed_tensor(self, dev):
+        if self.seed is None or self.seed.device != dev:
+            if self._restore is not None:
+                start, self._restore = int(self._restore), None
+            else:
+                import torch.distributed as dist
+                rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+                start = ((int(torch.initial_seed()) * 0x9E3779B97F4A7C15) ^ ((rank + 1) * 0xD1B54A32D192ED03)) & ((1 << 62) - 1)
+            self.seed = torch.full((1,), start, dtype=torch.int64, device=dev)
+        return self.seed
+
+    def dropout_state(self) -> int:
+        """The counter's current value (a host read: checkpoint time only); None before the first forward."""
+        if self.seed is None:
+            return self._restore
+        return int(self.seed.item())
+
+    def set_dropout_state(self, value):
+        if value is None:
+            return
+        if self.seed is None:
+            self._restore = int(value)
+        else:
+            self.seed.fill_(int(value))
 
     @staticmethod
     def supported(net) -> bool:
@@ -270,8 +300,7 @@ class FastTail:
         dev = rows.device
         B, _, J = xyz1.shape
         C, H, Hf = rows.shape[1], c11.linear1.out_features, net.final_mlp[0].weight.shape[0]
-        if self.seed is None or self.seed.device != dev:
-            self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._seed_tensor(dev)
         seed_used = torch.empty(1, dtype=torch.int64, device=dev)
         grads = T.TailGrads(dev, 14 * C + 2 * H + Hf + 3 * Hf + 3)
         pd = lambda m: float(m.p) if m.training else 0.0

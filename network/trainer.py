@@ -220,18 +220,35 @@ class Trainer(nn.Module):
                     self.optimizer.load_state_dict(state["optimizer"])
                 except (ValueError, KeyError):
                     pass
+                tail = getattr(self._bare_model(), "_ftail", None)
+                if "tail_dropout_state" in state:  # the fused tail's dropout counter continues where it stopped
+                    if not tail:
+                        from models.fast_train import FastTail
+                        net = self._bare_model()
+                        if hasattr(net, "_ftail") and FastTail.supported(net):
+                            tail = net._ftail = FastTail(net)
+                    if tail:
+                        tail.set_dropout_state(state["tail_dropout_state"])
                 self.scheduler = self._make_scheduler(last_epoch=self.epoch)
             self.log_string("Resume from epoch %d" % self.epoch)
         self.model.load_state_dict(ckpt, strict=False)
         return self.epoch
+
+    def _bare_model(self):
+        """The HandTrackNet inside whatever self.model is (the tracking models wrap it as .handnet)."""
+        return getattr(self.model, "handnet", self.model)
 
     def save(self, name=None):
         if int(os.environ.get("RANK", "0")) != 0:
             return
         name = name or f"model_{self.epoch:04d}"
         path = pjoin(self.ckpt_dir, name + ".pt")
-        torch.save({"epoch": self.epoch, "iteration": self.iteration, "model": self.model.state_dict(),
-                    "optimizer": self.optimizer.state_dict()}, path)
+        state = {"epoch": self.epoch, "iteration": self.iteration, "model": self.model.state_dict(),
+                 "optimizer": self.optimizer.state_dict()}  # the reference's four keys (trainer.py:253-268)
+        tail = getattr(self._bare_model(), "_ftail", None)
+        if tail and tail.dropout_state() is not None:
+            state["tail_dropout_state"] = tail.dropout_state()
+        torch.save(state, path)
         self.log_string(f"Saving model at epoch {self.epoch}, path {path}")
 
     @staticmethod
@@ -374,36 +391,51 @@ class Trainer(nn.Module):
         # would replay their zero-fill every step).
         model_snap = {k: v.clone() for k, v in self.model.state_dict().items()}
         opt_snap = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.optimizer.state.items()}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self._step(self._static)
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            for k, v in self.model.state_dict().items():
-                v.copy_(model_snap[k])
-            for p, st in self.optimizer.state.items():
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        v.copy_(opt_snap[p][k]) if p in opt_snap else v.zero_()
-        self.optimizer.zero_grad(set_to_none=True)
+        flat = self.dp_mode == "flat"
+        err = None
         graph = torch.cuda.CUDAGraph()
         self._opt_graph = None
-        if self.dp_mode == "flat":
-            from hotrack_amd import gemm_tuning
+        from hotrack_amd import gemm_tuning
+        try:
+            # The warm-up steps are LOCAL (no gradient exchange: their effect is undone below anyway).  A rank that raises here
+            # has therefore issued exactly as many collectives as its peers -- none -- when the ranks agree below (ADVICE r3:
+            # with the all-reduce inside the warm-up a failing rank met its peers' all-reduce with the agreement's).
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            try:
+                with torch.cuda.stream(side), gemm_tuning.scope():
+                    for _ in range(2):
+                        self._forward_backward(self._static)
+                        self.optimizer.step()
+            finally:  # whatever happened, the step update() was called for starts from the state it was called with
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.no_grad():
+                    for k, v in self.model.state_dict().items():
+                        v.copy_(model_snap[k])
+                    for p, st in self.optimizer.state.items():
+                        for k, v in st.items():
+                            if torch.is_tensor(v):
+                                v.copy_(opt_snap[p][k]) if p in opt_snap else v.zero_()
+                self.optimizer.zero_grad(set_to_none=True)
             with gemm_tuning.scope():
                 with torch.cuda.graph(graph):
-                    self._static_loss = self._forward_backward(self._static, zero=False)
+                    self._static_loss = self._forward_backward(self._static, zero=False) if flat else self._step(self._static, zero=False)
+        except RuntimeError as exc:
+            err = exc
+            torch.cuda.synchronize()
+        if flat:
+            # first collective of the capture: every rank arrives here, having exchanged nothing so far
+            if not self._agree(err is None):
+                raise RuntimeError(f"graph capture failed ({err or 'on another rank'})")
+            with gemm_tuning.scope():
                 self._allreduce_flat()  # eager (collectives stay outside the graphs); also fixes the flat buffer / gradient list
                 opt_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(opt_graph, pool=graph.pool()):
                     self._scatter_flat()
                     self.optimizer.step()
             self._opt_graph = opt_graph
-        else:
-            with torch.cuda.graph(graph):
-                self._static_loss = self._step(self._static, zero=False)
+        elif err is not None:
+            raise err
         self._graph, self._graph_sig = graph, sig
 
     def test(self, data, save_flag=False):

@@ -513,6 +513,40 @@ def test_mlp_stack_deferred_weight_gradient_sums():
                     torch.testing.assert_close(p.grad, 2 * b, rtol=1e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
         finally:
             train_stack._flush_reductions = flush
+        # ---- a parameter that feeds TWO stack nodes of one pass (weight tying / a module called twice before one
+        # backward()): autograd sums the two gradients when the second node returns, so the first node's pending reduction must
+        # have run by then; and parameters with tensor hooks are never deferred (the hook would see an unreduced tensor)
+        convs, bns = stacks[0]
+        shared = [train_stack.Layer(None, bns[0])] + [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(convs, bns[1:])]
+        tied = [p_ for m in convs + bns for p_ in m.parameters()]
+
+        def run_tied():
+            ws.reset()
+            for p_ in tied:
+                p_.grad = None
+            a = train_stack.mlp_stack(ys[0], shared, ws, max_over=16)
+            b = train_stack.mlp_stack(ys[1], shared, ws, max_over=16)
+            ((a * gos[0]).sum() + (b * gos[1]).sum()).backward()
+            return [None if p_.grad is None else p_.grad.clone() for p_ in tied]
+
+        train_stack.DEFER_REDUCE = False
+        ref_tied = run_tied()
+        train_stack.DEFER_REDUCE = True
+        for _ in range(3):  # unreduced tiles are uninitialised memory: repeat so that a stale-but-equal buffer cannot pass
+            got_tied = run_tied()
+            assert not train_stack._pending and not train_stack._pending_params
+            for a, b in zip(got_tied, ref_tied):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
+        seen_in_hook = []
+        h = convs[0].weight.register_hook(lambda gr: seen_in_hook.append(gr.clone()))
+        try:
+            zero(); run_pass()
+        finally:
+            h.remove()
+        torch.testing.assert_close(seen_in_hook[0], ref[params.index(convs[0].weight)], rtol=1e-4,
+                                   atol=1e-5 * max(1.0, float(seen_in_hook[0].abs().max())))
     finally:
         train_stack.DEFER_REDUCE = old
 
@@ -559,6 +593,22 @@ def test_fused_adam_matches_torch_adam(wd):
     od.step()
     for c, d in zip(pc, pd):
         torch.testing.assert_close(c, d, rtol=2e-6, atol=2e-7)
+    # load_state_dict on an optimiser that HAS stepped re-homes every counter once, eagerly, into a fresh shared
+    # buffer (no overflow, no host sync left for a later step): the next step is one advance launch and can be captured
+    od.load_state_dict(ob.state_dict())
+    live = [d for i, d in enumerate(pd) if i % 10 != 9]
+    buf, used = od._step_bufs[live[0].device]
+    assert used == len(live) <= buf.numel()
+    assert sorted(od.state[d]["step"].data_ptr() for d in live) == [buf.data_ptr() + 4 * i for i in range(used)]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        od.step()   # warm-up on the side stream, then the same step under capture (a host read of a counter would raise)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            od.step()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert all(float(od.state[d]["step"]) == 9.0 for d in live)   # 7 loaded + the warm-up step + one replay (capture does not run)
 
 
 def test_fused_hand_losses_match_the_torch_composition():
