@@ -103,12 +103,13 @@ int pn2_ball_query(int b, int n, int m, float radius, int nsample, const float *
     PN2_REQ(new_xyz && xyz && idx, PN2_ENULL);
     PN2_REQ(b <= 65535, PN2_ERANGE);
     PN2_REQ(fits_int((long)n * 3) && fits_int((long)m * nsample), PN2_ERANGE);
-    // large clouds with many centroids: the cell-grid search (identical output, ball_query_grid.hip) when library-owned scratch is
+    // large clouds with many centroids: the cell-grid search (identical output, ball_query_grid.hip) when a stream-ordered temporary is
     // available (not while the stream is being captured: callers that capture use pn2x_ball_query_grid with their own scratch)
     if (n >= 4096 && (long)m * n >= (1L << 22) && radius > 0.f) {
         const long words = pn2x_ball_query_grid_scratch_words(b, n);
         if (words > 0 && words < (1L << 30)) {
-            int *scratch = stream_scratch_ints((size_t)words + 4, (hipStream_t)stream);
+            StreamScratch own;  // stream-ordered temporary: released when this call returns, after the launches
+            int *scratch = own.acquire((size_t)words + 4, (hipStream_t)stream);
             if (scratch) {
                 unsigned *aligned = reinterpret_cast<unsigned *>(((uintptr_t)scratch + 15) & ~(uintptr_t)15);
                 const int rc = ball_query_grid_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, aligned, (size_t)words, (hipStream_t)stream);

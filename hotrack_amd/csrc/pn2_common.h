@@ -156,14 +156,24 @@ struct PerDeviceOnce {
 
 // train_ops.hip: counting-sort inversion of an index list (offsets (b, n_dst+1), order (b, l)); PN2_ERANGE if n_dst does not fit LDS
 int inverse_index_launch(int b, int n_dst, int l, const int *idx, int *offsets, int *order, hipStream_t st);
-// Library-owned device scratch for kernels whose C ABI (the reference's signatures) has no scratch argument: one buffer per
-// (device, stream), grown on demand.  Returns nullptr whenever the stream is being captured into a graph (the pointer would be
-// baked into the graph and a later growth would free it): callers then take their scratch-free path.
-int *stream_scratch_ints(size_t count, hipStream_t st);
+// Device scratch for kernels whose C ABI (the reference's signatures) has no scratch argument: a STREAM-ORDERED temporary,
+// allocated (hipMallocAsync) before the enqueue and released (hipFreeAsync) right after it, in stream order -- the library keeps
+// nothing between calls (pn2_hip.h: "keeps no state"); the memory comes from and returns to the HIP runtime's own pool.
+// p == nullptr whenever the stream is being captured into a graph (an allocation node would tie the graph to this call) or the
+// allocation fails: callers then take their scratch-free path.
+struct StreamScratch {
+    int *p = nullptr;
+    hipStream_t st = nullptr;
+    StreamScratch() = default;
+    int *acquire(size_t count, hipStream_t stream);  // at most once per object; returns p
+    ~StreamScratch();
+    StreamScratch(const StreamScratch &) = delete;
+    StreamScratch &operator=(const StreamScratch &) = delete;
+};
 // Atomics-free backward of group / gather / three_interpolate on the channel-major operator layout (scatter_cm.hip):
 // t = 1: grad_points[b,c,idx[b,e]] += grad_out[b,c,e];  t = 3: grad_points[b,c,idx[b,j,k]] += w[b,j,k] * grad_out[b,c,j].
 // Returns PN2_ERANGE when the shape does not fit (caller falls back to its LDS-atomic kernel).
-// scratch == nullptr: library-owned per-stream scratch (PN2_ERANGE if it cannot be provided, e.g. during graph capture).
+// scratch == nullptr: a stream-ordered temporary (PN2_ERANGE if it cannot be provided, e.g. during graph capture).
 int scatter_cm_dispatch(int t, int b, int c, int n_dst, int m_src, const float *grad_out, const int *idx, const float *weight,
                         float *grad_points, hipStream_t st, int *scratch = nullptr, size_t scratch_ints = 0);
 

@@ -8,41 +8,27 @@
 // offsets + order, train_ops.hip) and a workgroup that owns (cloud, cc channels) stages its [cc][M] slice of grad_out in LDS
 // with coalesced loads; every (target i, channel) then SUMS its contributions with plain LDS reads and adds the result to
 // grad_points with one coalesced read-modify-write (the reference's accumulate-into-the-caller's-buffer semantics).
-#include <mutex>
-#include <unordered_map>
-
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
 namespace pn2 {
 
-int *stream_scratch_ints(size_t count, hipStream_t st) {
-    struct Buf { int *p = nullptr; size_t n = 0; };
-    static std::mutex mu;
-    static std::unordered_map<unsigned long long, Buf> bufs;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(mu);
-    // Never hand out library-owned scratch to a capturing stream, even when the cached buffer is large enough: its pointer
-    // would be baked into the graph, and a later, larger eager call on this stream frees it (replays would then run on freed
-    // memory).  Captured callers take the scratch-free kernels (or pass their own scratch: pn2x_scatter_cm).
+int *StreamScratch::acquire(size_t count, hipStream_t stream) {
+    st = stream;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
         return nullptr;
     }
-    Buf &b = bufs[((unsigned long long)dev << 48) ^ (unsigned long long)(uintptr_t)st];
-    if (b.n >= count) return b.p;
-    // the old buffer may still be in use by work already enqueued on this stream: free it in stream order
-    if (b.p) (void)hipFreeAsync(b.p, st);
-    const size_t want = count + count / 2;
-    if (hipMallocAsync((void **)&b.p, want * sizeof(int), st) != hipSuccess) {
+    if (hipMallocAsync((void **)&p, (count ? count : 1) * sizeof(int), st) != hipSuccess) {
         (void)hipGetLastError();
-        b.p = nullptr; b.n = 0;
-        return nullptr;
+        p = nullptr;
     }
-    b.n = want;
-    return b.p;
+    return p;
+}
+
+StreamScratch::~StreamScratch() {
+    if (p && hipFreeAsync(p, st) != hipSuccess) (void)hipGetLastError();  // after the kernels enqueued in between, in stream order
 }
 
 constexpr int kScT = 1024;  // 16 waves per workgroup: the LDS slab allows only ~2 workgroups per CU, the waves hide the update latency
@@ -125,8 +111,9 @@ int scatter_cm_dispatch(int t, int b, int c, int n_dst, int m_src, const float *
     if (cc > c) cc = c;
     while (cc > 1 && (long)b * ((c + cc - 1) / cc) < 512) cc = (cc + 1) / 2;  // >= 2 workgroups of 16 waves per CU
     const size_t need = scatter_cm_scratch_ints(t, b, n_dst, m_src);
+    StreamScratch own;  // released in stream order when this call returns (after the launches below)
     if (!scratch) {
-        scratch = stream_scratch_ints(need, st);
+        scratch = own.acquire(need, st);
         if (!scratch) return PN2_ERANGE;
     } else if (scratch_ints < need) {
         return PN2_ESCRATCH;

@@ -12,7 +12,12 @@
  * Common contract (same as the reference unless noted):
  *   - all float tensors are fp32, all index tensors int32, contiguous, batch-major;
  *   - the caller allocates every output; the library only borrows pointers for the duration
- *     of the enqueue and keeps no state (re-entrant, fork/spawn safe, nothing at load time);
+ *     of the enqueue and keeps no state (re-entrant, fork/spawn safe, nothing at load time).
+ *     The entries whose reference signature has no scratch argument but whose kernels want one
+ *     (the three *_grad entries, ball_query on large clouds) take a stream-ordered temporary from
+ *     the HIP runtime (hipMallocAsync before, hipFreeAsync after the enqueue, both on `stream`)
+ *     and fall back to scratch-free kernels while `stream` is being captured into a graph;
+ *     pn2_ext.h has the same operations with caller-provided scratch (capture-safe);
  *   - calls are asynchronous on `stream`; nothing synchronises;
  *   - return value: PN2_OK (0) or a negative PN2_E* code.  The reference's int wrappers always
  *     returned 1 and exit(-1)ed the process on a launch failure

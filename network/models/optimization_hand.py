@@ -88,6 +88,8 @@ class gf_optimize_hand_pose:
         self.obj_t = init_obj_pose["translation"].to(self.device).reshape(1, 1, 3).float()
 
     # ---- SDF part (one launch for lookup + penetration) --------------------------------------------------------------------
+    sdf_lookup = None  # test hook: callable(optimiser, hand) -> (queried_sdf, penetration); None = hotrack_amd.sdf (GPU only)
+
     def query_sdf(self, hand):
         from hotrack_amd import sdf as _sdf
         return _sdf.query_sdf(hand.float(), self.obj_r, self.obj_t, self.sdf_volume, self.voxel_scale)
@@ -144,11 +146,9 @@ class gf_optimize_hand_pose:
         """Energy of every candidate (B,), :277-293."""
         # queried_sdf / pen stay in the volume's dtype (fp16 in the reference): the penetration and attraction terms are formed
         # in that precision there, and the energies are compared with the reference's to 1e-5
-        if hand.is_cuda:
-            queried_sdf, pen = self.query_sdf_and_penetration(hand)
-        else:  # (CPU tensors: the torch composition -- used by the oracle-side tests only)
-            queried_sdf = self._query_sdf_torch(hand)
-            pen = self.get_penetration_loss(queried_sdf)
+        # (sdf_lookup: None in the product -- the fused HIP lookup, which raises for CPU tensors; CPU-side tests inject the
+        # reference's torch composition, oracle/sdf_torch.py, the way they inject the operator backend)
+        queried_sdf, pen = self.sdf_lookup(self, hand) if self.sdf_lookup is not None else self.query_sdf_and_penetration(hand)
         loss = {"sil_loss": self.get_silhouette_loss(hand), "penetrate_sum_loss": pen}
         loss["vis_regu_loss"], loss["invis_regu_loss"] = self.get_regularization_loss(kp)
         loss["temporal_smooth"] = self.get_temporal_smooth_loss(kp)
@@ -158,15 +158,6 @@ class gf_optimize_hand_pose:
         for key in ("sil_loss", "penetrate_sum_loss", "vis_regu_loss", "invis_regu_loss", "temporal_smooth", "attraction_loss"):
             energy = energy + loss[key] * self.energy_weight[key]
         return energy
-
-    def _query_sdf_torch(self, hand):  # optimization_hand.py:248-261 as written (CPU path of the tests)
-        B, N, _ = hand.shape
-        p = torch.matmul(hand - self.obj_t, self.obj_r).reshape(-1, 3)
-        half = self.volume_size // 2
-        ix = torch.clamp(p[:, 0] // self.voxel_scale, -half, half).long() + half
-        iy = torch.clamp(p[:, 1] // self.voxel_scale, -half, half).long() + half
-        iz = torch.clamp(p[:, 2] // self.voxel_scale, -half, half).long() + half
-        return self.sdf_volume[ix, iy, iz].reshape(B, N)
 
     def update_seach_size(self, energy, mean_transform):
         s = mean_transform.abs() + 1e-3

@@ -24,6 +24,10 @@ def _setup(device):
     cfg = {"device": device, "opt": {"energy_weight": {"penetrate_sum_loss": 1, "sil_loss": 0.1, "attraction_loss": 0.05,
                                                         "vis_regu_loss": 10, "invis_regu_loss": 0, "temporal_smooth": 1}}}
     opt = gf_optimize_hand_pose(cfg, hand_model=SyntheticLBSHand(), particle_size=g["pre_sampled_particle"].shape[0])
+    if device == "cpu":  # the product has no CPU lookup: the reference's torch composition is injected (test infrastructure)
+        sys.path.insert(0, ROOT)
+        from oracle import sdf_torch
+        opt.sdf_lookup = sdf_torch.lookup
     opt.pre_sampled_particle = torch.from_numpy(g["pre_sampled_particle"]).to(device)
     opt.load_volume(torch.from_numpy(g["volume"]).reshape(res, res, res), stride)
     proj = dict(zip(("fx", "fy", "cx", "cy", "w", "h"), g["proj"].tolist()))
@@ -68,6 +72,17 @@ def test_golden_report_hand():
     rep = json.load(open(os.path.join(G, "GOLDEN_REPORT_HAND.json")))
     assert rep["frames"] == 4 and rep["penetrating_candidates_frame0"] > 0
     assert all(a < b for a, b in zip(rep["mean_kp_error_optimised_m"], rep["mean_kp_error_init_m"]))
+
+
+def test_product_lookup_has_no_cpu_path():
+    """Without the injected test lookup the optimiser's SDF query is the HIP kernel and refuses CPU tensors loudly."""
+    g, opt, proj, obj_pose, mask = _setup("cpu")
+    opt.sdf_lookup = None
+    with torch.no_grad():
+        mano, pose, kp0, last, vis = _frame_inputs(g, 0, "cpu")
+        opt.set_init_para(mano, pose, kp0, last, vis, obj_pose, None, proj, mask)
+        with pytest.raises(RuntimeError, match="CPU|cuda|GPU|device"):
+            opt.query_sdf_and_penetration(torch.zeros(2, 778, 3))
 
 
 def test_hand_optimiser_matches_reference_cpu():
