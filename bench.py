@@ -137,61 +137,39 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(npoints, budget_s=24.0, max_frames=200):
+def cpu_baseline(npoints, budget_s=24.0):
     """Reference CPU path (port) on the host, SURVEY.md 8(d) protocol: B=1 frames through the same network with NO dead-work
-    elision, warm-up then up to 200 timed frames per setting, per-frame median / p10 / p90, at 1 thread (what the
-    reference's test.py:26 sets) and at all cores (torch.set_num_threads(nproc)); 16 threads is timed too because torch's
-    intra-op pool stops scaling far below this host's core count on per-frame tensors.  Bounded to ~budget_s of CPU work:
-    the frames actually timed are stated in `sample`."""
-    from netinit import synthetic_frames
-    from models import pointnet_utils
-    from oracle import cpu_reference
-    saved = pointnet_utils._OPS
-    pointnet_utils.set_operator_backend(cpu_reference)
-    try:
-        model = build_model("cpu", elide=False)
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        frames = [synthetic_frames(1000 + i, 1, npoints) for i in range(4)]
-        out = {}
-        cands = sorted({1, min(16, avail), avail})
-        per = budget_s / len(cands)
-        for threads in cands:
-            torch.set_num_threads(threads)
-            with torch.no_grad():
-                t0 = time.perf_counter()
-                model(frames[0], dict(FLAGS))  # first warm-up frame, also a guard against a collapsing thread pool
-                first = time.perf_counter() - t0
-                if first > per / 2:
-                    out[threads] = {"frames": 1, "median_ms": round(first * 1e3, 2), "p10_ms": None, "p90_ms": None,
-                                    "frames_per_s": round(1.0 / first, 3), "note": "thread pool collapses at this size: one frame only"}
-                    continue
-                t_w = time.perf_counter()
-                nw = 1
-                while nw < 20 and time.perf_counter() - t_w < per * 0.15:  # up to 20 warm-up frames
-                    model(frames[nw % 4], dict(FLAGS))
-                    nw += 1
-                ts = []
-                t_all = time.perf_counter()
-                while len(ts) < max_frames and time.perf_counter() - t_all < per * 0.8:
-                    t0 = time.perf_counter()
-                    model(frames[len(ts) % 4], dict(FLAGS))
-                    ts.append(time.perf_counter() - t0)
-            ts.sort()
-            q = lambda f: ts[min(len(ts) - 1, int(f * len(ts)))]
-            out[threads] = {"frames": len(ts), "warmup_frames": nw, "median_ms": round(q(0.5) * 1e3, 2), "p10_ms": round(q(0.1) * 1e3, 2),
-                            "p90_ms": round(q(0.9) * 1e3, 2), "frames_per_s": round(1.0 / q(0.5), 3)}
-        torch.set_num_threads(min(avail, 32))
-    finally:
-        pointnet_utils.set_operator_backend(saved)
-    best = max(out, key=lambda t: out[t]["frames_per_s"])
+    elision, warm-up then up to 200 timed frames per point, per-frame median / p10 / p90 (scripts/cpu_point.py).  Points:
+    1 thread (what the reference's test.py:26 sets) and 16 threads in this process; 64 and 128 threads as child processes
+    PINNED to that many physical cores (one hardware thread per core, OMP_PROC_BIND=close) -- "all physical cores" of 8(d),
+    capped by what the host has.  Bounded to ~budget_s of CPU work; the frames actually timed are stated in `sample`."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import cpu_point
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    phys = len(cpu_point.physical_cores())
+    inproc = sorted({1, min(16, avail)})
+    pinned = sorted({min(64, phys), min(128, phys)} - set(inproc))
+    per = budget_s / (len(inproc) + len(pinned))
+    out = {}
+    model = build_model("cpu", elide=False)
+    for threads in inproc:
+        out[threads] = cpu_point.measure(threads, per, npoints, model=model)
+    torch.set_num_threads(min(avail, 32))
+    for threads in pinned:
+        out[threads] = cpu_point.pinned_point(threads, per, npoints)
+    ok = {t: v for t, v in out.items() if "frames_per_s" in v}
+    best = max(ok, key=lambda t: ok[t]["frames_per_s"])
     return {
-        "value": out[best]["frames_per_s"], "unit": "frames/s", "cores": best, "kind": "port",
-        "sample": f"{out[best]['frames']} frames (median of per-frame times), B=1, N={npoints}, eval forward, reference fallback "
+        "value": ok[best]["frames_per_s"], "unit": "frames/s", "cores": best, "kind": "port",
+        "sample": f"{ok[best]['frames']} frames (median of per-frame times), B=1, N={npoints}, eval forward, reference fallback "
                   f"algorithms (oracle/cpu_reference.py), attention not elided, torch CPU intra-op threads={best} "
-                  f"(best of {sorted(out)}; host exposes {avail} cores)",
-        "cpu_model": _cpu_model(), "host_cores": avail,
-        "one_thread": out.get(1), "all_cores": out.get(avail),
+                  f"(best of {sorted(out)}; host: {phys} physical cores / {avail} hardware threads)",
+        "cpu_model": _cpu_model(), "host_cores": avail, "host_physical_cores": phys,
+        "one_thread": out.get(1), "physical_cores": {str(t): out[t] for t in pinned},
         "by_threads": {str(t): v for t, v in sorted(out.items())},
+        "note": "torch.set_num_threads(all %d hardware threads) is not a point of this table: at B=1 the intra-op pool collapses "
+                "there (one frame took 37.5 s on the 256-thread driver box, BENCH_r03.json); the pinned physical-core points "
+                "are the 'all physical cores' setting of SURVEY.md 8(d)" % avail,
     }
 
 
@@ -247,9 +225,12 @@ def main():
     ap.add_argument("--npoints", type=int, default=1024)
     ap.add_argument("--min-time", type=float, default=6.0, help="repeat the K-step timed region until this many seconds are timed "
                     "(default 6 s: longer than the 5-s tick of an external GPU-busy sampler)")
-    ap.add_argument("--train-steps", type=int, default=20, help="WORLD_SIZE > 1 only: steps of the data-parallel training leg "
-                    "(configs[2] per GPU, flat-gradient RCCL all-reduce) appended after the headline regions; 0 = skip")
+    ap.add_argument("--train-steps", type=int, default=20, help="steps of the training leg (configs[2] per GPU, 32 x 1024, whole step "
+                    "as HIP graphs; WORLD_SIZE > 1: data parallel with a flat-gradient RCCL all-reduce) appended after the headline "
+                    "regions; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (child processes after the headline regions: "
+                    "`train` = configs[2] per GPU, and at N = 1 `stress` = configs[4] per GPU and `latency_b1`)")
     ap.add_argument("--no-elide", action="store_true", help="also compute the attention the reference discards")
     ap.add_argument("--no-fused", action="store_true", help="disable the fused SA kernels (unfused torch MLPs)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -423,22 +404,56 @@ def main():
             replay_check = {"max_abs_diff_pred_kp": worst, "batches": POOL, "streams": ninf, "tolerance": 1e-5}
     assert all(torch.isfinite(o["pred_kp"]).all() for o in outs if o is not None)
 
-    # ---- WORLD_SIZE > 1: per-rank spread of the headline, and a data-parallel TRAINING leg (outside the headline) so that a
-    # multi-GPU record shows RCCL carrying the gradient all-reduce: configs[2] per GPU (32 x 1024), whole step in HIP graphs,
-    # one flat all-reduce per step (network/trainer.py dp=flat)
-    per_rank = train_leg = None
+    # ---- secondary legs, all OUTSIDE the headline regions and each in a CHILD process (scripts/bench_legs.py): an exception, a
+    # hang (bounded by a timeout, the child is killed by pid) or a crash in a leg costs that leg's entry ({"error": ...}), never
+    # the headline.  N = 1: train (configs[2] per GPU), stress (configs[4] per GPU), latency_b1.  N > 1: per-rank spread of the
+    # headline and the data-parallel training leg -- the children of all ranks form their OWN process group on a fresh port, so
+    # a multi-GPU record shows RCCL carrying the gradient all-reduce (network/trainer.py dp=flat) while the parents' group
+    # stays untouched; the parents meet again at the barrier below whatever happened to the children.
+    per_rank = None
+    legs = {}
+    torch.cuda.synchronize()
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench_legs
+    backend_world = dist.get_world_size() if world > 1 else 1
+    assert backend_world == args.gpus, f"backend sees {backend_world} ranks, --gpus {args.gpus}"
     if world > 1:
         t = torch.tensor([args.batch * args.steps / headline_local], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         per_rank = [round(float(g), 1) for g in gathered]
-        if args.train_steps > 0:
-            if use_graph:
-                del graphs, slots, g_single
-            torch.cuda.empty_cache()
-            sys.path.insert(0, os.path.join(ROOT, "scripts"))
-            from bench_train import run_training_leg
-            train_leg = run_training_leg(args.train_steps, 5, 32, True, rank, world)
+    if use_graph and not args.no_legs:
+        del graphs, slots, g_single
+        torch.cuda.empty_cache()
+    if not args.no_legs and args.train_steps > 0:
+        if world > 1:
+            import socket
+            port = torch.zeros(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            if rank == 0:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port[0] = sk.getsockname()[1]
+            dist.broadcast(port, src=0)
+            env = dict(os.environ, MASTER_PORT=str(int(port[0])), MASTER_ADDR="127.0.0.1", PN2_DIST_BACKEND=backend, HOTRACK_KEEP_GRAPH="1")
+            cmd = [sys.executable, os.path.join(ROOT, "scripts", "bench_train.py"), "--steps", str(args.train_steps), "--warmup", "5",
+                   "--batch", "32", "--graph"]
+            got = bench_legs.run_child(cmd, float(os.environ.get("PN2_BENCH_LEG_TIMEOUT", "600")), env=env, expect_json=(rank == 0))
+            # every parent is alive here whatever its child did; one small collective tells rank 0 whether any child failed
+            bad = torch.tensor([1 if "error" in got else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+            if int(bad[0]) and "error" not in got:
+                got = {"error": "%d of %d rank children failed" % (int(bad[0]), world)}
+            elif int(bad[0]):
+                got["failed_ranks"] = int(bad[0])
+            legs["train"] = got
+        else:
+            legs["train"] = bench_legs.run_child(bench_legs.leg_cmd("train", args.train_steps, 5, 32), 420)
+    if not args.no_legs and world == 1:
+        legs["stress"] = bench_legs.run_child(bench_legs.leg_cmd("stress"), 300)
+        legs["latency_b1"] = bench_legs.run_child(bench_legs.leg_cmd("latency"), 300)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()  # before the CPU leg: the other ranks are done (rank 0 alone times the host)
 
     if rank == 0:
         med = sorted(regions)[len(regions) // 2]
@@ -509,16 +524,17 @@ def main():
         from hotrack_amd import gemm_tuning
         res["gemm_table"] = gemm_tuning.status()["gemm_table"]
         res["config"]["gemm_table_detail"] = gemm_tuning.status()["detail"]
+        res["world_size_seen_by_backend"] = backend_world
         if per_rank is not None:
             res["per_rank_frames_per_s"] = {"min": min(per_rank), "max": max(per_rank), "ranks": per_rank}
-        if train_leg is not None:
-            res["train"] = train_leg
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(args.npoints)
-            res["speedup_vs_cpu_baseline"] = round(fps / res["cpu_baseline"]["value"], 1)
+        res.update(legs)  # train / stress / latency_b1: results of the child legs, or {"error": ...}
+        if not args.no_cpu_baseline:
+            try:  # (N > 1: rank 0 alone, after the process group is gone; per-GPU comparison = value / n_gpus)
+                res["cpu_baseline"] = cpu_baseline(args.npoints)
+                res["speedup_vs_cpu_baseline"] = round(fps / world / res["cpu_baseline"]["value"], 1)
+            except Exception as exc:  # noqa: BLE001  (a reported baseline must never cost the line)
+                res["cpu_baseline"] = {"error": repr(exc)[:300]}
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -393,7 +393,9 @@ class Trainer(nn.Module):
         opt_snap = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.optimizer.state.items()}
         flat = self.dp_mode == "flat"
         err = None
-        graph = torch.cuda.CUDAGraph()
+        # HOTRACK_KEEP_GRAPH=1: keep the hipGraph_t next to its executable (bench legs count its kernel nodes)
+        keep = {"keep_graph": True} if os.environ.get("HOTRACK_KEEP_GRAPH", "0") == "1" else {}
+        graph = torch.cuda.CUDAGraph(**keep)
         self._opt_graph = None
         from hotrack_amd import gemm_tuning
         try:
@@ -429,7 +431,7 @@ class Trainer(nn.Module):
                 raise RuntimeError(f"graph capture failed ({err or 'on another rank'})")
             with gemm_tuning.scope():
                 self._allreduce_flat()  # eager (collectives stay outside the graphs); also fixes the flat buffer / gradient list
-                opt_graph = torch.cuda.CUDAGraph()
+                opt_graph = torch.cuda.CUDAGraph(**keep)
                 with torch.cuda.graph(opt_graph, pool=graph.pool()):
                     self._scatter_flat()
                     self.optimizer.step()

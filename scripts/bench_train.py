@@ -54,7 +54,17 @@ def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce
     sync()
     local = time.perf_counter() - t0
     dt = reduce_max(local)
+    # live dense work of a step: forward 1.344 GFLOP per frame (0.67 GMAC of grouped MLPs + heads, the discarded
+    # attention excluded) x 3 (forward, data gradient, weight gradient) -- the figure DESIGN.md 5b prices the step with
+    flops = 3 * 1.344e9 * batch
+    launches = None
+    if getattr(tr, "_graph", None) is not None:
+        from hotrack_amd.graph_utils import kernel_nodes
+        parts = [kernel_nodes(g) for g in (tr._graph, tr._opt_graph) if g is not None]
+        launches = sum(parts) if parts and all(p is not None for p in parts) else None
     res = {"metric": "HandTrackNet training frames/sec (N=1024)", "value": round(batch * world * steps / dt, 1),
+           "launches": launches, "tflops": round(flops / (dt / steps) / 1e12, 2),
+           "mfma_frac": round(flops / (dt / steps) / 1e12 / 157.3, 4),
            "unit": "frames/s", "n_gpus": world, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "per_gpu_batch": batch,
            "scaling": "weak", "graph_step": bool(getattr(tr, "graph_step", False)), "dp_mode": tr.dp_mode,
            "loss": float(loss["total_loss"]), "dtype": "f32", "data": "synthetic"}
@@ -84,6 +94,8 @@ def main():
     a = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local % torch.cuda.device_count())
+    if os.environ.get("PN2_BENCH_FAIL_TRAIN_LEG", "") == str(rank):  # harness self-test: this rank's training leg dies
+        raise RuntimeError("injected failure of the training leg on rank %d (PN2_BENCH_FAIL_TRAIN_LEG)" % rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("PN2_DIST_BACKEND", "nccl"))  # gloo: several ranks on one GPU (self-test)

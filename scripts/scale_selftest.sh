@@ -23,6 +23,7 @@ assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) < 
 # the multi-GPU extras: per-rank spread of the headline and the data-parallel training leg that shows the gradient all-reduce
 pr, tr = d["per_rank_frames_per_s"], d["train"]
 assert len(pr["ranks"]) == n and pr["min"] <= pr["max"]
+assert d["world_size_seen_by_backend"] == n, d
 assert tr["n_gpus"] == n and tr["world_size_seen_by_backend"] == n and tr["dp_mode"] == "flat" and tr["graph_step"] is True, tr
 assert tr["backend"] == "gloo" and tr["bytes"] > 16e6 and tr["allreduce_us"] > 0 and tr["ms_per_step"] > 0, tr
 assert d["replay_check"]["max_abs_diff_pred_kp"] <= 1e-5 and d["gemm_table"] in ("applied", "stale", "off")
@@ -31,6 +32,18 @@ print(f"bench --gpus {n}: ok  n_gpus={d['n_gpus']} world_size={d['config']['worl
       f"(1 rank on the same GPU: {one['value']:.0f})")
 PY
 done
+# a training leg that dies on ONE rank (its peers then wait for it until the leg's timeout): the headline must survive, the
+# line must carry train.error, and the process group of the parents must still shut down cleanly (exit code 0)
+line=$(PN2_BENCH_BACKEND=gloo PN2_BENCH_FAIL_TRAIN_LEG=1 PN2_BENCH_LEG_TIMEOUT=90 python -m torch.distributed.run --nnodes=1 \
+       --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29650 bench.py --gpus 2 --steps 5 --warmup 2 --min-time 0.2 \
+       --train-steps 5 --no-cpu-baseline | grep '^{')
+python - "$line" <<'PY'
+import json, sys
+d = json.loads(sys.argv[1])
+assert d["n_gpus"] == 2 and d["value"] > 0 and d["replay_check"]["max_abs_diff_pred_kp"] <= 1e-5, d
+assert "error" in d["train"], d["train"]
+print("bench --gpus 2 with a failing training leg: headline survives (%.0f frames/s), train = %s" % (d["value"], d["train"]))
+PY
 for N in 2; do
   PN2_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
       --master-port $((29700 + N)) network/train.py --config handtracknet_train_SimGrasp.yml --num_points 512 --batch_size 4 \

@@ -164,8 +164,8 @@ def test_bench_line_contract():
     """bench.py prints ONE JSON line with the fields the driver and the judge read (short run, no CPU leg)."""
     import json
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--min-time", "0.5", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--min-time", "0.5", "--no-cpu-baseline",
+                          "--train-steps", "6"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -184,3 +184,12 @@ def test_bench_line_contract():
     rc = d["replay_check"]
     assert rc["batches"] == 5 and rc["streams"] == d["config"]["batches_in_flight"] and rc["max_abs_diff_pred_kp"] <= 1e-5
     assert d["gemm_table"] == "applied", d["config"].get("gemm_table_detail")
+    # the secondary legs (child processes after the headline): configs[2] per GPU, configs[4] per GPU, B = 1 latency
+    tr, st_, lat = d["train"], d["stress"], d["latency_b1"]
+    assert "error" not in tr and tr["graph_step"] is True and tr["per_gpu_batch"] == 32 and 0 < tr["ms_per_step"] < 20, tr
+    assert tr["launches"] is None or 50 < tr["launches"] < 600, tr
+    assert abs(tr["mfma_frac"] - tr["tflops"] / 157.3) < 1e-3 and 0 < tr["mfma_frac"] < 1, tr
+    for k in ("fps_ms", "ball_ms_r01", "ball_ms_r02", "sa_ms", "level_ms", "level_ms_pipelined"):
+        assert "error" not in st_ and 0 < st_[k] < 100, (k, st_)
+    assert st_["pipelined_equals_serial"] is True and 0 < st_["sa_mfma_frac"] < 1
+    assert "error" not in lat and 0 < lat["graph_ms"] < 5 and lat["max_abs_diff_vs_eager"] <= 1e-5, lat
