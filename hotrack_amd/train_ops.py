@@ -313,32 +313,35 @@ def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs, invs=None, aux=None):
 
 class _InterpRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, points, idx, weight):
+    def forward(ctx, points, idx, weight, *inv):
         from . import ext
         B, M, C = points.shape
         n = idx.shape[1]
         out = torch.empty((B, n, C), dtype=_f32, device=points.device)
         ext.three_interpolate_pm(points, idx, weight, out)
-        ctx.save_for_backward(idx, weight)
+        ctx.save_for_backward(idx, weight, *inv)
         ctx.m = M
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        idx, weight = ctx.saved_tensors
+        idx, weight, *inv = ctx.saved_tensors
         dout = dout.contiguous()
         B, n, C = dout.shape
+        none = (None,) * len(inv)
         if ctx.m <= INVERSE_MAX_ROWS:
             dp = torch.empty((B, ctx.m, C), dtype=_f32, device=dout.device)
-            rows_segment_sum(dout, inverse_index(idx.view(B, n * 3), ctx.m), ctx.m, dp, weight=weight)
-            return dp, None, None
+            rows_segment_sum(dout, tuple(inv) if inv else inverse_index(idx.view(B, n * 3), ctx.m), ctx.m, dp, weight=weight)
+            return (dp, None, None, *none)
         dp = torch.zeros((B, ctx.m, C), dtype=_f32, device=dout.device)
         with torch.cuda.device(dout.device):
             _native._check(_lib.pn2x_three_interpolate_pm_grad(B, C, ctx.m, n, dout.data_ptr(), C, idx.data_ptr(), weight.data_ptr(),
                                                                dp.data_ptr(), C, _native._stream(dout)), "three_interpolate_pm_grad")
-        return dp, None, None
+        return (dp, None, None, *none)
 
 
-def interpolate_rows(points: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    """points (B,M,C) contiguous, idx / weight (B,n,3) -> (B,n,C); gradient to points only (reference pointnet2_utils.py:190)."""
-    return _InterpRows.apply(points.contiguous(), idx, weight)
+def interpolate_rows(points: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor, inv=None) -> torch.Tensor:
+    """points (B,M,C) contiguous, idx / weight (B,n,3) -> (B,n,C); gradient to points only (reference pointnet2_utils.py:190).
+    inv = inverse_index(idx.view(B, 3 n), M) when the caller has it already (it depends on the geometry only: a training loop
+    computes it for the NEXT batch beside this batch's dense work); the backward inverts the lists itself otherwise."""
+    return _InterpRows.apply(points.contiguous(), idx, weight, *(inv if inv is not None else ()))

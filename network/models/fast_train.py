@@ -154,17 +154,18 @@ class FastTrain:
             outs.append(h.view(B, S, -1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
 
-    def _fp(self, mod, xyz1, xyz2, points1, points2, extra=None):
+    def _fp(self, mod, xyz1, xyz2, points1, points2, extra=None, nn3=None):
         """xyz1 (B,N,3), xyz2 (B,S,3), points1 (B,N,D1)|None, points2 (B,S,D2) -> (B*N, D') rows.
-        extra = (conv, bn): a further Conv1d + BatchNorm + ReLU appended to the module's stack (backbone conv1 / bn1)."""
+        extra = (conv, bn): a further Conv1d + BatchNorm + ReLU appended to the module's stack (backbone conv1 / bn1).
+        nn3 = (weights, indices, inverted lists | None) of the three-NN search when the geometry stage has run it."""
         from hotrack_amd import ext
         from hotrack_amd.train_ops import interpolate_rows
         B, N, _ = xyz1.shape
         if xyz2.shape[1] == 1:
             interp = points2.expand(B, N, points2.shape[2])
         else:
-            w, i3 = ext.three_nn_weights(xyz1, xyz2)
-            interp = interpolate_rows(points2, i3, w)
+            w, i3, inv = nn3 if nn3 is not None else (*ext.three_nn_weights(xyz1, xyz2), None)
+            interp = interpolate_rows(points2, i3, w, inv=inv)
         x = interp if points1 is None else torch.cat([points1, interp], dim=2)
         convs, bns = list(mod.mlp_convs), list(mod.mlp_bns)
         if extra is not None:
@@ -173,11 +174,46 @@ class FastTrain:
         return self._stack(x.reshape(B * N, -1), convs, bns)
 
     # ------------------------------------------------------------------------------------------------------------------
-    def forward(self, xyz2_cm: torch.Tensor, xyz1_cm: torch.Tensor):
-        """xyz2_cm (B,3,N) hand-frame cloud, xyz1_cm (B,3,J) hand-frame keypoints (no gradient flows into coordinates:
-        they derive from the inputs only) -> f14 (B,C,J) channel-major as `r2` returns it, src2 (B,N,C) point-major."""
+    def geometry(self, xyz: torch.Tensor, kp: torch.Tensor, with_inverse: bool = True) -> dict:
+        """Everything of a training step that depends on the COORDINATES only (no parameter, no gradient): the two sampling levels
+        (furthest point sampling + ball query: reference pointnet_utils.py:368-388), the three-NN searches and weights of the
+        feature propagation (:440-449), the keypoints' kNN lists (:551-556) and, for the backward row scatters, the inverted
+        neighbour lists.  xyz (B,N,3) hand-frame cloud, kp (B,J,3) hand-frame keypoints, point-major.  A training loop runs this
+        stage for batch t+1 on its own stream while batch t's dense work runs (network/trainer.py: update(next_data=...))."""
         from hotrack_amd import ext
         from hotrack_amd import pointnet2_utils as ops
+        from hotrack_amd.train_ops import INVERSE_MAX_ROWS, inverse_index
+        net, bh = self.net, self.net.bhand
+        B, N, _ = xyz.shape
+        S1, S2 = bh.sa1.npoint, bh.sa2.npoint
+        inv = (lambda i, n: inverse_index(i.view(B, -1), n)) if (with_inverse and N <= INVERSE_MAX_ROWS) else (lambda i, n: None)
+        g = {}
+        g["l1_xyz"] = ext.gather_rows(xyz, ops.furthest_point_sample(xyz, S1))
+        g["idx1"] = ops.ball_query(bh.sa1.radius_list[0], bh.sa1.nsample_list[0], xyz, g["l1_xyz"])
+        g["l2_xyz"] = ext.gather_rows(g["l1_xyz"], ops.furthest_point_sample(g["l1_xyz"], S2))
+        g["idx2"] = ops.ball_query(bh.sa2.radius_list[0], bh.sa2.nsample_list[0], g["l1_xyz"], g["l2_xyz"])
+        g["inv2"] = inv(g["idx2"], S1)
+        w, i3 = ext.three_nn_weights(g["l1_xyz"], g["l2_xyz"])      # fp2: level-1 points from level 2
+        g["fp2"] = (w, i3, inv(i3, S2))
+        w, i3 = ext.three_nn_weights(xyz, g["l1_xyz"])              # fp1: all points from level 1
+        g["fp1"] = (w, i3, inv(i3, S1))
+        Ks = list(net.q1.nsample_list)
+        kmax = max(Ks)
+        if len(set(Ks)) == 2 and len(Ks) == 2:  # one search: the smaller list is the prefix of the larger
+            gi, gi_small = ext.knn_indices(kmax, kp, xyz, k2=min(Ks))
+            idxs = [gi if K == kmax else gi_small for K in Ks]
+        else:
+            idxs = [ops.knn(K, kp, xyz)[1] for K in Ks]
+        g["knn"] = idxs
+        g["knn_inv"] = [inv(i, N) for i in idxs]
+        if g["knn_inv"][0] is None:
+            g["knn_inv"] = None
+        return g
+
+    def forward(self, xyz2_cm: torch.Tensor, xyz1_cm: torch.Tensor, geo: dict = None):
+        """xyz2_cm (B,3,N) hand-frame cloud, xyz1_cm (B,3,J) hand-frame keypoints (no gradient flows into coordinates:
+        they derive from the inputs only) -> f14 (B,C,J) channel-major as `r2` returns it, src2 (B,N,C) point-major.
+        geo: the result of geometry() for these coordinates when the caller has it already (computed here otherwise)."""
         from hotrack_amd.train_ops import Workspace
         net, bh = self.net, self.net.bhand
         dev = xyz2_cm.device
@@ -188,38 +224,30 @@ class FastTrain:
         kp = xyz1_cm.detach().transpose(1, 2).contiguous()    # (B,J,3)
         B, N, _ = xyz.shape
         J = kp.shape[1]
+        if geo is None:
+            geo = self.geometry(xyz, kp, with_inverse=torch.is_grad_enabled())
 
         # ---- backbone: sa1, sa2, sa3 (group-all), fp3, fp2, fp1, conv1 -------------------------------------------------
         S1, S2 = bh.sa1.npoint, bh.sa2.npoint
-        l1_xyz = ext.gather_rows(xyz, ops.furthest_point_sample(xyz, S1))
-        idx1 = ops.ball_query(bh.sa1.radius_list[0], bh.sa1.nsample_list[0], xyz, l1_xyz)
-        l1_feat = self._sa_scales(bh.sa1, xyz, l1_xyz, None, [idx1])                                   # (B,S1,64)
-        l2_xyz = ext.gather_rows(l1_xyz, ops.furthest_point_sample(l1_xyz, S2))
-        idx2 = ops.ball_query(bh.sa2.radius_list[0], bh.sa2.nsample_list[0], l1_xyz, l2_xyz)
-        l2_feat = self._sa_scales(bh.sa2, l1_xyz, l2_xyz, l1_feat.reshape(B * S1, -1), [idx2])        # (B,S2,128)
+        l1_xyz, l2_xyz = geo["l1_xyz"], geo["l2_xyz"]
+        l1_feat = self._sa_scales(bh.sa1, xyz, l1_xyz, None, [geo["idx1"]])                            # (B,S1,64)
+        l2_feat = self._sa_scales(bh.sa2, l1_xyz, l2_xyz, l1_feat.reshape(B * S1, -1), [geo["idx2"]],
+                                  invs=None if geo["inv2"] is None else [geo["inv2"]])                  # (B,S2,128)
         x = torch.cat([l2_xyz, l2_feat], dim=2).view(B * S2, -1)   # group-all: [xyz | feat], centre = origin (not subtracted)
         l3 = self._stack(x, bh.sa3.mlp_convs, bh.sa3.mlp_bns, max_over=S2).view(B, 1, -1)                    # (B,1,512)
         l2_out = self._fp(bh.fp3, l2_xyz, l2_xyz[:, :1], l2_feat, l3).view(B, S2, -1)
-        l1_out = self._fp(bh.fp2, l1_xyz, l2_xyz, l1_feat, l2_out).view(B, S1, -1)
+        l1_out = self._fp(bh.fp2, l1_xyz, l2_xyz, l1_feat, l2_out, nn3=geo["fp2"]).view(B, S1, -1)
         # fp1 (skip = xyz) and the backbone's conv1 / bn1 as one stack [131 -> 128 -> 128 -> C]
-        src2 = self._fp(bh.fp1, xyz, l1_xyz, xyz, l1_out, extra=(bh.conv1, bh.bn1))                    # (B*N, C)
+        src2 = self._fp(bh.fp1, xyz, l1_xyz, xyz, l1_out, extra=(bh.conv1, bh.bn1), nn3=geo["fp1"])    # (B*N, C)
         C = src2.shape[1]
 
         # ---- q1 -> r1 -> q2 -> r2 around the J keypoints; one kNN search for both neighbourhood sizes ------------------
-        Ks = list(net.q1.nsample_list)
-        kmax = max(Ks)
-        if len(set(Ks)) == 2 and len(Ks) == 2:
-            gi, gi_small = ext.knn_indices(kmax, kp, xyz, k2=min(Ks))
-            idxs = [gi if K == kmax else gi_small for K in Ks]
-        else:
-            idxs = [ops.knn(K, kp, xyz)[1] for K in Ks]
+        idxs, invs = geo["knn"], geo["knn_inv"]
         # the per-point halves of both modules' first layers read src2: one Function, one input gradient (_Linear2Shared)
         w1_q1, wf_q1 = self._first_layer_blocks(net.q1, C, False)
         w1_q2, wf_q2 = self._first_layer_blocks(net.q2, C, True)
         a1f_q1, a1f_q2 = _Linear2Shared.apply(src2, wf_q1, wf_q2)
-        # both modules gather through the same neighbour lists: inverted once here for the two backward scatters
-        from hotrack_amd.train_ops import INVERSE_MAX_ROWS, inverse_index
-        invs = [inverse_index(i.view(B, -1), N) for i in idxs] if (torch.is_grad_enabled() and N <= INVERSE_MAX_ROWS) else None
+        # both modules gather through the same neighbour lists: inverted once (geometry) for the two backward scatters
         f11 = self._sa_scales(net.q1, xyz, kp, src2, idxs, pre=(w1_q1, a1f_q1), invs=invs)             # (B,J,C)
         f12 = self._rearrange(net.r1, f11)                                                                 # (B*J, C)
         f13 = self._sa_scales(net.q2, xyz, kp, src2, idxs, center2d=f12, pre=(w1_q2, a1f_q2), invs=invs)

@@ -122,6 +122,37 @@ class HandTrackNet(nn.Module):
             raise NotImplementedError(self.handframe)
         return {"scale": scale, "rotation": R, "translation": t}
 
+    def _fast_train_frame_ok(self, hand_points, palm_template, kp_num, use_ft) -> bool:
+        return bool(self.training and use_ft and self.handframe == "kp" and self.elide_dead_attention and hand_points.is_cuda
+                    and kp_num == 21 and palm_template.shape[-2] == 6 and pointnet_utils.hip_backend_active())
+
+    def precompute_geometry(self, input, flag_dict):
+        """The part of a TRAINING step on the GPU that depends on the batch only, not on the parameters: the hand frame (Kabsch of
+        the palm template, canonicalised cloud and keypoints: hand_utils.py:30-66) and FastTrain.geometry (sampling, ball query,
+        three-NN, kNN, inverted neighbour lists).  Returns a dict to hand back as input["_geometry"] with the same batch, or None
+        when this configuration does not run the point-major training path.  No gradient, no parameter, no state: a training
+        loop runs it for batch t+1 on a second stream while batch t's dense work occupies the matrix cores
+        (network/trainer.py)."""
+        use_ft = getattr(self, "_force_fast_train", self.use_fast_train)
+        dev = self.device
+        palm_template = (input["pred_palm_template"] if flag_dict["track_flag"] else input["gt_hand_pose"]["palm_template"]).to(dev).float()
+        jittered_kp = input["jittered_hand_kp"].to(dev).float()
+        hand_points = input["hand_points"].to(dev).float()
+        if not self._fast_train_frame_ok(hand_points, palm_template, jittered_kp.shape[1], use_ft):
+            return None
+        if self._ftrain is None:
+            from .fast_train import FastTrain
+            self._ftrain = FastTrain(self) if FastTrain.supported(self) else False
+        if not self._ftrain:
+            return None
+        from hotrack_amd import ext
+        with torch.no_grad():
+            frame = ext.hand_frame(palm_template.contiguous(), jittered_kp.contiguous(), _palm_idx(hand_points.device),
+                                   hand_points.contiguous(), 0.2)
+            geo = self._ftrain.geometry(frame[2], frame[3], with_inverse=True)
+        geo["frame"] = tuple(frame)
+        return geo
+
     def forward(self, input, flag_dict):
         """input: hand_points (B,N,3), jittered_hand_kp (B,21,3), palm template (gt_hand_pose.palm_template
         or pred_palm_template when tracking).  Returns the reference's ret_dict (pred_kp (B,21,3), ...)."""
@@ -159,8 +190,12 @@ class HandTrackNet(nn.Module):
         elide = self.elide_dead_attention
         cam = None
         use_ft = getattr(self, "_force_fast_train", self.use_fast_train)  # class-level override: tests compare the two paths
-        if (self.training and use_ft and self.handframe == "kp" and elide and hand_points.is_cuda and kp_num == 21
-                and palm_template.shape[-2] == 6 and pointnet_utils.hip_backend_active()):
+        geo = input.get("_geometry") if self.training and use_ft else None  # precompute_geometry() of THIS batch (trainer prefetch)
+        if geo is not None:
+            R, t, xyz2_pm, xyz1_pm = geo["frame"]
+            canon_pose = {"scale": _scale_const(hand_points.device), "rotation": R, "translation": t}
+            xyz2, xyz1 = xyz2_pm.transpose(1, 2), xyz1_pm.transpose(1, 2)
+        elif self._fast_train_frame_ok(hand_points, palm_template, kp_num, use_ft):
             # training on the GPU: the hand frame (Kabsch of the palm template + canonicalisation of cloud and keypoints) as ONE
             # launch, as in the inference path -- no gradient flows through it (inputs only); the torch composition below is
             # ~12 launches (gather, device Kabsch, cat, transposes, subtract, matmul, divide, two copies)
@@ -193,7 +228,7 @@ class HandTrackNet(nn.Module):
                 self._ftrain = FastTrain(self) if FastTrain.supported(self) else False
             ftrain = self._ftrain or None
         if ftrain is not None:  # point-major training path, same mathematics (tests/test_gpu_train.py)
-            f14, src2_pm = ftrain.forward(xyz2, xyz1)
+            f14, src2_pm = ftrain.forward(xyz2, xyz1, geo=geo)
             src2 = None if elide else src2_pm.transpose(1, 2)
         else:
             xyz2, xyz1 = xyz2.contiguous(), xyz1.contiguous()

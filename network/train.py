@@ -50,13 +50,17 @@ def main(args):
         if world > 1:
             train_loader.sampler.set_epoch(epoch)
         acc, n = {}, 0
-        for i, data in enumerate(train_loader):
-            loss = trainer.update(data)
+        it = iter(train_loader)
+        data = next(it, None)
+        while data is not None:
+            # one batch of lookahead: with graph_step the trainer runs the NEXT batch's geometry stage (sampling, neighbour
+            # searches) on a second stream beside this batch's dense step
+            nxt = None if (args.max_iters and n + 1 >= args.max_iters) else next(it, None)
+            loss = trainer.update(data, next_data=nxt)
             for k, v in loss.items():
                 acc[k] = acc.get(k, 0.0) + float(v)
             n += 1
-            if args.max_iters and n >= args.max_iters:
-                break
+            data = nxt
         for k, v in acc.items():
             trainer.log_string("Train {} is {}".format(k, v / max(n, 1)))
         trainer.log_string("world_size %d, %d iterations" % (world, n))

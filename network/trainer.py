@@ -95,6 +95,12 @@ class Trainer(nn.Module):
             # replaying it removes the host from the loop.  Single process only (DDP's bucketed all-reduce stays eager).
             self.graph_step = bool(cfg.get("graph_step", os.environ.get("HOTRACK_GRAPH_STEP", "0") == "1"))
             self._graph = self._graph_sig = self._static = self._static_loss = None
+            # geometry prefetch (graph_step only): the batch-only part of a step (hand frame, sampling, neighbour searches,
+            # inverted lists: HandTrackNet.precompute_geometry) as its own HIP graph on its own stream, replayed for batch t+1
+            # while batch t's dense step runs -- update(data, next_data=...)
+            self.prefetch_geometry = bool(cfg.get("prefetch_geometry", os.environ.get("HOTRACK_PREFETCH_GEOMETRY", "1") == "1"))
+            self._geo_graph = self._geo_in = self._geo_pack_g = self._geo_pack_d = self._static_geo = None
+            self._geo_stream = self._geo_done = self._geo_ready_for = None
             if cfg["optimizer"] == "Adam":
                 # GPU: the fused multi-tensor Adam (one or two launches over all parameters instead of ~15 foreach kernels;
                 # device-side step counters, so it is graph-capturable as is).  Same update rule: L2 weight decay, no amsgrad.
@@ -270,10 +276,12 @@ class Trainer(nn.Module):
         self.optimizer.step()
         return loss_dict
 
-    def _forward_backward(self, data, zero=True):
+    def _forward_backward(self, data, zero=True, geo=None):
         if zero:
             self.optimizer.zero_grad()
         flags = self.init_flag_dict()
+        if geo is not None:  # this batch's precomputed geometry (static buffers of the captured step)
+            data = dict(data, _geometry=geo)
         if self.ddp is not None:
             loss_dict = self.ddp(data, flags)  # forward + compute_loss inside the DDP-wrapped module
         else:
@@ -330,7 +338,9 @@ class Trainer(nn.Module):
             off += g.numel()
         torch._foreach_copy_(self._flat_grads, views)
 
-    def update(self, data):
+    def update(self, data, next_data=None):
+        """One training step on `data`.  next_data: the batch the NEXT call will be given (the same object), if the loop knows
+        it -- with graph_step its geometry stage is then replayed on a second stream beside this step's dense work."""
         self.model.train()
         loss_dict = None
         if getattr(self, "graph_step", False) and self.ddp is None and torch.cuda.is_available():  # ("ddp" mode stays eager)
@@ -348,7 +358,7 @@ class Trainer(nn.Module):
                     self.log_string(f"graph_step disabled ({err or 'capture failed on another rank'})")
                     self.graph_step, self._graph, self._opt_graph = False, None, None
             if self.graph_step:
-                loss_dict = dict(self._graphed_step(data, sig))
+                loss_dict = dict(self._graphed_step(data, sig, next_data))
         if loss_dict is None:
             loss_dict = self._step(data)
         self.iteration += 1
@@ -365,13 +375,42 @@ class Trainer(nn.Module):
             elif torch.is_tensor(v):
                 yield prefix + (k,), v
 
-    def _graphed_step(self, data, sig=None):
+    def _copy_leaves(self, dst_tree, src_tree):
+        for (_, dst), (_, src) in zip(self._leaves(dst_tree), self._leaves(src_tree)):
+            dst.copy_(src, non_blocking=True)
+
+    def _geometry_for(self, data, next_data):
+        """Geometry of `data` into the dense step's static buffers; then, if the loop named its next batch, that batch's
+        geometry graph on the side stream.  One graph executable, so its replays are strictly ordered: a prefetch still in
+        flight is always waited for before anything else touches the graph or its buffers."""
+        cur = torch.cuda.current_stream()
+        if self._geo_ready_for is not None:
+            cur.wait_event(self._geo_done)
+        if self._geo_ready_for is None or self._geo_ready_for is not data:  # not prefetched: here and now, on this stream
+            self._copy_leaves(self._geo_in, data)
+            self._geo_graph.replay()
+        self._geo_pack_d.copy_(self._geo_pack_g, non_blocking=True)
+        self._geo_ready_for = None
+        if next_data is not None:
+            consumed = torch.cuda.Event()
+            consumed.record(cur)
+            with torch.cuda.stream(self._geo_stream):
+                self._geo_stream.wait_event(consumed)  # the pack above has been handed over; the dense step reads its copy
+                self._copy_leaves(self._geo_in, next_data)
+                self._geo_graph.replay()
+                self._geo_done.record(self._geo_stream)
+            self._geo_ready_for = next_data
+
+    def _graphed_step(self, data, sig=None, next_data=None):
         if sig is None:
             sig = tuple((path, tuple(t.shape), t.dtype) for path, t in self._leaves(data))
         if self._graph is None or sig != self._graph_sig:
             self._capture(data, sig)
-        for (_, dst), (_, src) in zip(self._leaves(self._static), self._leaves(data)):
-            dst.copy_(src, non_blocking=True)
+        if self._geo_graph is not None:
+            if next_data is not None and tuple((p_, tuple(t.shape), t.dtype) for p_, t in self._leaves(next_data)) != sig:
+                next_data = None  # (a differently shaped batch re-captures everything at its own step)
+            self._geometry_for(data, next_data)
+        self._copy_leaves(self._static, data)
         self._graph.replay()
         if self._opt_graph is not None:  # data parallel: forward+backward graph | eager all-reduce | optimiser graph
             self._allreduce_flat()
@@ -385,6 +424,9 @@ class Trainer(nn.Module):
                     for k, v in d.items()}
 
         self._graph, self._static = None, clone(data)
+        if self._geo_ready_for is not None:  # a prefetch of the previous capture's graph may still be running
+            torch.cuda.current_stream().wait_event(self._geo_done)
+        self._geo_graph = self._static_geo = self._geo_ready_for = None
         # Warm-up on a side stream (MIOpen / BLAS pick their algorithms, autograd builds its buffers, Adam creates its
         # state) -- then put every value back, IN PLACE, so the captured step starts from the state update() was called
         # with and the optimizer state tensors the graph will update already exist (creating them inside the capture
@@ -402,12 +444,14 @@ class Trainer(nn.Module):
             # The warm-up steps are LOCAL (no gradient exchange: their effect is undone below anyway).  A rank that raises here
             # has therefore issued exactly as many collectives as its peers -- none -- when the ranks agree below (ADVICE r3:
             # with the all-reduce inside the warm-up a failing rank met its peers' all-reduce with the agreement's).
+            if self.prefetch_geometry and hasattr(self._bare_model(), "precompute_geometry"):
+                self._capture_geometry(clone(data))  # (inside the try: under dp=flat every failure is agreed on below)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             try:
                 with torch.cuda.stream(side), gemm_tuning.scope():
                     for _ in range(2):
-                        self._forward_backward(self._static)
+                        self._forward_backward(self._static, geo=self._static_geo)
                         self.optimizer.step()
             finally:  # whatever happened, the step update() was called for starts from the state it was called with
                 torch.cuda.current_stream().wait_stream(side)
@@ -421,7 +465,9 @@ class Trainer(nn.Module):
                 self.optimizer.zero_grad(set_to_none=True)
             with gemm_tuning.scope():
                 with torch.cuda.graph(graph):
-                    self._static_loss = self._forward_backward(self._static, zero=False) if flat else self._step(self._static, zero=False)
+                    self._static_loss = self._forward_backward(self._static, zero=False, geo=self._static_geo)
+                    if not flat:
+                        self.optimizer.step()
         except RuntimeError as exc:
             err = exc
             torch.cuda.synchronize()
@@ -440,6 +486,44 @@ class Trainer(nn.Module):
             raise err
         self._graph, self._graph_sig = graph, sig
 
+    def _capture_geometry(self, geo_in):
+        """The geometry stage of `geo_in`-shaped batches as its own HIP graph: inputs geo_in (static), outputs packed into ONE flat
+        buffer (pack_g) so that handing a batch's geometry to the dense step is a single device-to-device copy into pack_d, of
+        which self._static_geo holds typed views.  Leaves self._geo_graph None when the model has no such stage here."""
+        net, flags = self._bare_model(), self.init_flag_dict()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            geo = None
+            for _ in range(2):  # warm-up (allocations, kernel selection) outside the capture
+                geo = net.precompute_geometry(geo_in, flags)
+        cur.wait_stream(side)
+        if geo is None:
+            return
+        leaves, spec = _tree_flatten(geo)
+        assert all(t.dtype in (torch.float32, torch.int32) for t in leaves), "geometry leaves are 4-byte tensors"
+        offs, total = [], 0
+        for t in leaves:
+            offs.append(total)
+            total += (t.numel() + 3) // 4 * 4  # every leaf starts 16-byte aligned
+        dev = leaves[0].device
+        pack_g = torch.zeros(total, dtype=torch.int32, device=dev)
+        pack_d = torch.zeros(total, dtype=torch.int32, device=dev)
+        views = lambda pack: [pack[o:o + t.numel()] for o, t in zip(offs, leaves)]
+        graph = torch.cuda.CUDAGraph(**({"keep_graph": True} if os.environ.get("HOTRACK_KEEP_GRAPH", "0") == "1" else {}))
+        with torch.cuda.graph(graph, stream=side):
+            geo = net.precompute_geometry(geo_in, flags)
+            src = [t.contiguous().view(-1).view(torch.int32) for t in _tree_flatten(geo)[0]]
+            torch._foreach_copy_(views(pack_g), src)
+        self._static_geo = _tree_unflatten(spec, [v.view(t.dtype).view(t.shape) for v, t in zip(views(pack_d), leaves)])
+        self._geo_graph, self._geo_in, self._geo_pack_g, self._geo_pack_d = graph, geo_in, pack_g, pack_d
+        self._geo_stream, self._geo_done = side, torch.cuda.Event()
+        # the static batch's own geometry, for the warm-up steps and the capture of the dense step
+        cur.wait_stream(side)
+        graph.replay()
+        pack_d.copy_(pack_g)
+
     def test(self, data, save_flag=False):
         flags = self.init_flag_dict()
         flags["test_flag"], flags["save_flag"] = True, save_flag
@@ -448,6 +532,39 @@ class Trainer(nn.Module):
             ret = self.model(data, flags)
             loss_dict, ret = self.model.compute_loss(data, ret, flags)
         return loss_dict, ret
+
+
+def _tree_flatten(obj):
+    """(tensor leaves, structure) of nested dicts / lists / tuples / None (dict keys in sorted order)."""
+    leaves = []
+
+    def walk(o):
+        if torch.is_tensor(o):
+            leaves.append(o)
+            return ("t",)
+        if o is None:
+            return ("n",)
+        if isinstance(o, dict):
+            return ("d", [(k, walk(o[k])) for k in sorted(o)])
+        if isinstance(o, (list, tuple)):
+            return ("l" if isinstance(o, list) else "u", [walk(v) for v in o])
+        raise TypeError(f"unsupported node {type(o)}")
+    return leaves, walk(obj)
+
+
+def _tree_unflatten(spec, leaves):
+    it = iter(leaves)
+
+    def build(sp):
+        if sp[0] == "t":
+            return next(it)
+        if sp[0] == "n":
+            return None
+        if sp[0] == "d":
+            return {k: build(v) for k, v in sp[1]}
+        seq = [build(v) for v in sp[1]]
+        return seq if sp[0] == "l" else tuple(seq)
+    return build(spec)
 
 
 class _StepModule(nn.Module):

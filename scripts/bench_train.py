@@ -45,12 +45,14 @@ def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t)
 
+    # the loop names its next batch (what network/train.py does with one batch of DataLoader lookahead): the trainer then runs
+    # that batch's geometry stage on a second stream beside this batch's dense step
     for i in range(warmup):
-        loss = tr.update(batches[i % 4])
+        loss = tr.update(batches[i % 4], next_data=batches[(i + 1) % 4])
     sync()
     t0 = time.perf_counter()
     for i in range(steps):
-        loss = tr.update(batches[i % 4])
+        loss = tr.update(batches[(warmup + i) % 4], next_data=batches[(warmup + i + 1) % 4])
     sync()
     local = time.perf_counter() - t0
     dt = reduce_max(local)
@@ -60,13 +62,14 @@ def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce
     launches = None
     if getattr(tr, "_graph", None) is not None:
         from hotrack_amd.graph_utils import kernel_nodes
-        parts = [kernel_nodes(g) for g in (tr._graph, tr._opt_graph) if g is not None]
+        parts = [kernel_nodes(g) for g in (tr._graph, tr._opt_graph, getattr(tr, "_geo_graph", None)) if g is not None]
         launches = sum(parts) if parts and all(p is not None for p in parts) else None
     res = {"metric": "HandTrackNet training frames/sec (N=1024)", "value": round(batch * world * steps / dt, 1),
            "launches": launches, "tflops": round(flops / (dt / steps) / 1e12, 2),
            "mfma_frac": round(flops / (dt / steps) / 1e12 / 157.3, 4),
            "unit": "frames/s", "n_gpus": world, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "per_gpu_batch": batch,
            "scaling": "weak", "graph_step": bool(getattr(tr, "graph_step", False)), "dp_mode": tr.dp_mode,
+           "geometry_prefetch": getattr(tr, "_geo_graph", None) is not None,
            "loss": float(loss["total_loss"]), "dtype": "f32", "data": "synthetic"}
     if world > 1:
         res["backend"] = dist.get_backend()  # "nccl" = RCCL on ROCm
