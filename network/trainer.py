@@ -100,7 +100,8 @@ class Trainer(nn.Module):
             # while batch t's dense step runs -- update(data, next_data=...)
             self.prefetch_geometry = bool(cfg.get("prefetch_geometry", os.environ.get("HOTRACK_PREFETCH_GEOMETRY", "1") == "1"))
             self._geo_graph = self._geo_in = self._geo_pack_g = self._geo_pack_d = self._static_geo = None
-            self._geo_stream = self._geo_done = self._geo_ready_for = None
+            self._geo_stream = self._geo_done = self._geo_ready_for = self._geo_srcs = self._geo_copied = None
+            self._geo_slot = 0
             if cfg["optimizer"] == "Adam":
                 # GPU: the fused multi-tensor Adam (one or two launches over all parameters instead of ~15 foreach kernels;
                 # device-side step counters, so it is graph-capturable as is).  Same update rule: L2 weight decay, no amsgrad.
@@ -381,25 +382,39 @@ class Trainer(nn.Module):
 
     def _geometry_for(self, data, next_data):
         """Geometry of `data` into the dense step's static buffers; then, if the loop named its next batch, that batch's
-        geometry graph on the side stream.  One graph executable, so its replays are strictly ordered: a prefetch still in
-        flight is always waited for before anything else touches the graph or its buffers."""
+        geometry graph on the side stream.
+
+        Synchronisation (measured on this runtime, scripts/probes/two_graph_overlap.py): a wait of the BUSY stream on an event
+        of the side stream is free, but an event recorded on the busy stream that another stream waits for stalls the busy
+        stream by 50 - 200 us -- whether or not the event completed long ago.  So the dense stream never records an event for the
+        side stream: the geometry graph's results are packed (one eager concatenation on the side stream) into one of TWO
+        buffers, alternately, and before the side stream is given the buffer of two steps ago the HOST waits for the dense
+        stream's copy out of it (an event nobody waits for on the device).  That bounds the host's run-ahead to about two
+        steps; it needs 0.3 ms per step against 3.3 ms on the device.  One graph executable, so its replays are strictly
+        ordered: a prefetch still in flight is always waited for before the graph or its buffers are touched."""
         cur = torch.cuda.current_stream()
         if self._geo_ready_for is not None:
             cur.wait_event(self._geo_done)
         if self._geo_ready_for is None or self._geo_ready_for is not data:  # not prefetched: here and now, on this stream
             self._copy_leaves(self._geo_in, data)
             self._geo_graph.replay()
-        self._geo_pack_d.copy_(self._geo_pack_g, non_blocking=True)
-        self._geo_ready_for = None
+            self._pack_geometry(self._geo_slot)
+        slot = self._geo_slot
+        self._geo_pack_d.copy_(self._geo_pack_g[slot], non_blocking=True)
+        self._geo_copied[slot].record(cur)  # (no stream waits for it: the host does, two steps from now)
+        self._geo_slot, self._geo_ready_for = 1 - slot, None
         if next_data is not None:
-            consumed = torch.cuda.Event()
-            consumed.record(cur)
+            self._geo_copied[1 - slot].synchronize()  # the copy that last read the other pack (previous step) has finished
             with torch.cuda.stream(self._geo_stream):
-                self._geo_stream.wait_event(consumed)  # the pack above has been handed over; the dense step reads its copy
                 self._copy_leaves(self._geo_in, next_data)
                 self._geo_graph.replay()
+                self._pack_geometry(1 - slot)
                 self._geo_done.record(self._geo_stream)
             self._geo_ready_for = next_data
+
+    def _pack_geometry(self, slot):
+        """The geometry graph's outputs (static buffers of its private pool) -> pack_g[slot], one concatenation on the current stream."""
+        torch.cat(self._geo_srcs, out=self._geo_pack_g[slot])
 
     def _graphed_step(self, data, sig=None, next_data=None):
         if sig is None:
@@ -503,26 +518,35 @@ class Trainer(nn.Module):
             return
         leaves, spec = _tree_flatten(geo)
         assert all(t.dtype in (torch.float32, torch.int32) for t in leaves), "geometry leaves are 4-byte tensors"
-        offs, total = [], 0
-        for t in leaves:
-            offs.append(total)
-            total += (t.numel() + 3) // 4 * 4  # every leaf starts 16-byte aligned
         dev = leaves[0].device
-        pack_g = torch.zeros(total, dtype=torch.int32, device=dev)
-        pack_d = torch.zeros(total, dtype=torch.int32, device=dev)
-        views = lambda pack: [pack[o:o + t.numel()] for o, t in zip(offs, leaves)]
         graph = torch.cuda.CUDAGraph(**({"keep_graph": True} if os.environ.get("HOTRACK_KEEP_GRAPH", "0") == "1" else {}))
         with torch.cuda.graph(graph, stream=side):
             geo = net.precompute_geometry(geo_in, flags)
-            src = [t.contiguous().view(-1).view(torch.int32) for t in _tree_flatten(geo)[0]]
-            torch._foreach_copy_(views(pack_g), src)
-        self._static_geo = _tree_unflatten(spec, [v.view(t.dtype).view(t.shape) for v, t in zip(views(pack_d), leaves)])
-        self._geo_graph, self._geo_in, self._geo_pack_g, self._geo_pack_d = graph, geo_in, pack_g, pack_d
-        self._geo_stream, self._geo_done = side, torch.cuda.Event()
+        # the captured outputs live at fixed addresses of the graph's pool: flat int32 views of them, interleaved with zero pads
+        # so that every leaf starts 16-byte aligned in the pack (the kernels of the dense step load rows as float4 / int4)
+        outs = [t.contiguous().view(-1).view(torch.int32) for t in _tree_flatten(geo)[0]]
+        assert all(o.data_ptr() == t.data_ptr() for o, t in zip(outs, _tree_flatten(geo)[0])), "geometry outputs are contiguous"
+        srcs, offs, total = [], [], 0
+        for o in outs:
+            offs.append(total)
+            srcs.append(o)
+            total += o.numel()
+            if total % 4:
+                srcs.append(torch.zeros(4 - total % 4, dtype=torch.int32, device=dev))
+                total += srcs[-1].numel()
+        pack_g = [torch.zeros(total, dtype=torch.int32, device=dev) for _ in range(2)]
+        pack_d = torch.zeros(total, dtype=torch.int32, device=dev)
+        self._static_geo = _tree_unflatten(spec, [pack_d[o:o + t.numel()].view(t.dtype).view(t.shape) for o, t in zip(offs, leaves)])
+        self._geo_graph, self._geo_in, self._geo_pack_g, self._geo_pack_d, self._geo_srcs = graph, geo_in, pack_g, pack_d, srcs
+        self._geo_stream, self._geo_done, self._geo_slot = side, torch.cuda.Event(), 0
+        self._geo_copied = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in self._geo_copied:
+            e.record(cur)
         # the static batch's own geometry, for the warm-up steps and the capture of the dense step
         cur.wait_stream(side)
         graph.replay()
-        pack_d.copy_(pack_g)
+        self._pack_geometry(0)
+        pack_d.copy_(pack_g[0])
 
     def test(self, data, save_flag=False):
         flags = self.init_flag_dict()

