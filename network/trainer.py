@@ -395,7 +395,8 @@ class Trainer(nn.Module):
         cur = torch.cuda.current_stream()
         if self._geo_ready_for is not None:
             cur.wait_event(self._geo_done)
-        if self._geo_ready_for is None or self._geo_ready_for is not data:  # not prefetched: here and now, on this stream
+        inline = self._geo_ready_for is None or self._geo_ready_for is not data
+        if inline:  # not prefetched: here and now, on this stream
             self._copy_leaves(self._geo_in, data)
             self._geo_graph.replay()
             self._pack_geometry(self._geo_slot)
@@ -405,6 +406,8 @@ class Trainer(nn.Module):
         self._geo_slot, self._geo_ready_for = 1 - slot, None
         if next_data is not None:
             self._geo_copied[1 - slot].synchronize()  # the copy that last read the other pack (previous step) has finished
+            if inline:  # the graph has just been replayed on THIS stream: its next replay must not start beside that one
+                self._geo_copied[slot].synchronize()
             with torch.cuda.stream(self._geo_stream):
                 self._copy_leaves(self._geo_in, next_data)
                 self._geo_graph.replay()
