@@ -14,8 +14,6 @@
 //     iteration (double-buffered by iteration parity; the reference needs 11);
 //   * all waves redundantly combine the <=16 wave candidates with DPP inside one row and
 //     pull the winner's coordinates into SGPRs with v_readlane.
-#include <stdlib.h>
-
 #include "pn2_common.h"
 
 namespace pn2 {
@@ -345,14 +343,6 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
     // Measured per (slots) on MI355X, any batch <= 256 clouds (scripts/probes/fps_threads.py):
     //   512 slots: T=64 39.5 us (one wave, no barrier at all), T=128 45.9;   1024: T=256 90.7, T=128 107, T=512 ~90;
     //   8192: T=512 1353 us, T=1024 1413.
-    // large clouds: the culled kernel (fps_cull.hip: a pick updates only the register slots whose bounding box the new sample can
-    // reach; 1.36 ms -> see profiles for 8192 -> 2048).  force_threads selects the plain kernels (tests compare the two);
-    // PN2_FPS_CULL=0 switches it off for A/B timing.
-    static const bool cull_on = [] { const char *e = getenv("PN2_FPS_CULL"); return !(e && e[0] == '0'); }();
-    if (cull_on && !force_threads && !skip_flags && !radii && n > 2048 && n <= 8192 && bs == 1024) {
-        const int rc = fps_cull_launch(b, n, m, bs, lg, xyz, idx, st);
-        if (rc != PN2_ERANGE) return rc;
-    }
     int T = slots <= 512 ? 64 : (slots <= 1024 ? 256 : 512);
     if (slots > 512 * 16) T = 1024;
     if (force_threads == 64 || force_threads == 128 || force_threads == 256 || force_threads == 512 || force_threads == 1024) {

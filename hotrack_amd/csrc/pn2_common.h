@@ -177,10 +177,6 @@ struct StreamScratch {
 int scatter_cm_dispatch(int t, int b, int c, int n_dst, int m_src, const float *grad_out, const int *idx, const float *weight,
                         float *grad_points, hipStream_t st, int *scratch = nullptr, size_t scratch_ints = 0);
 
-// fps_cull.hip: furthest point sampling of 2048 < n <= 8192 points with exact spatial culling (same picks as fps.hip);
-// PN2_ERANGE when the shape is not covered
-int fps_cull_launch(int b, int n, int m, int bs, int lg, const float *xyz, int *idx, hipStream_t st);
-
 // ball_query_grid.hip: PN2_ERANGE when the shape is not covered (n < 2048, radius <= 0, no scratch): the caller scans
 int ball_query_grid_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
                              unsigned *scratch, size_t scratch_words, hipStream_t st);

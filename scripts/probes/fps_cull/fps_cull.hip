@@ -18,19 +18,18 @@
 //     the winner inside the slot that holds it is found by an equality ballot on that one slot.  The points are no longer in the
 //     reference's tie order (they are sorted by cell), so every point carries its tie rank and equal maxima are resolved by the
 //     smallest rank: within the slot (wave min), across slots, across waves (LDS exchange, one barrier per pick, as fps.hip).
-//   * a register slot needs a compile-time index: the touched slots are reached through a 4-level binary branch tree on the
-//     (wave-uniform) slot number, not through a 16-way chain.
+//   * a register slot selected at run time: the slot number is wave-uniform, so the register arrays are native 16-element
+//     vectors indexed through M0-relative register addressing -- no branch chain over code copies per slot.
 //
 // Index-exact with fps.hip / the oracle on every case of tests/test_gpu_ops.py (lattices, duplicates, planes, lines, all-equal
 // clouds: whole slots tie there and every rank comparison is exercised).
-#include <type_traits>
+#include <stdlib.h>
 
 #include "pn2_common.h"
 
 namespace pn2 {
 namespace fpc {
 
-constexpr int kT = 512, kP = 16, kW = kT / kWave;  // 8 waves x 16 slots x 64 lanes = 8192 points
 constexpr int kG = 16, kCells = kG * kG * kG;      // cell grid of the prologue sort
 
 // signed-int order == float order (any non-NaN floats, both signs)
@@ -40,23 +39,19 @@ __device__ __forceinline__ int ordered(float f) {
 }
 __device__ __forceinline__ float unordered(int i) { return i2f(i ^ ((i >> 31) & 0x7fffffff)); }
 
-// f(integral_constant<int, j>) for a wave-uniform run-time j in [LO, LO + N): binary branch tree, log2(N) scalar branches
-template <int LO, int N, class F>
-__device__ __forceinline__ void with_slot(int j, F &&f) {
-    if constexpr (N == 1) {
-        f(std::integral_constant<int, LO>{});
-    } else {
-        if (j < LO + N / 2) with_slot<LO, N / 2>(j, f);
-        else with_slot<LO + N / 2, N / 2>(j, f);
-    }
-}
 
 __device__ __forceinline__ unsigned spread4(unsigned v) {  // 4 bits -> every third bit
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
 
+// kT threads = kW waves, kP register slots of 64 points per wave: kW kP 64 = 8192 points
+template <int kT, int kP>
 __global__ void __launch_bounds__(kT)
 fps_cull_kernel(int n, int m, int bs, int lg, const float *__restrict__ xyz_all, int *__restrict__ idx_all) {
+    constexpr int kW = kT / kWave;
+    static_assert(kW * kP * 64 == 8192 && (kP == 16 || kP == 32), "register layout");
+    typedef float fvec __attribute__((ext_vector_type(kP)));
+    typedef int ivec __attribute__((ext_vector_type(kP)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *ent = reinterpret_cast<int *>(smem);          // [parity][field][wave]: field 0 = value bits, 1 = tie rank
     float *lxyz = smem + 2 * 2 * 16;                   // (n, 3): the sample's coordinates by point index (main loop)
@@ -139,12 +134,21 @@ fps_cull_kernel(int n, int m, int bs, int lg, const float *__restrict__ xyz_all,
     for (int k = tid; k < n; k += kT) perm[atomicAdd(&hist[cell_key(k)], 1)] = k;
     __syncthreads();
 
-    // ---- 3. this thread's points: slot j of wave w, lane l = sorted position (w kP + j) 64 + l ------------------------------
-    float px[kP], py[kP], pz[kP], pt[kP];
-    int pk[kP];  // tie rank (bitrev(k mod bs) << 4 | k div bs): smaller wins among equal distances
+    // ---- 3. this thread's points: slot j of wave w, lane l = sorted position (j kW + w) 64 + l.  Blocks of 64 consecutive
+    // sorted points are dealt to the waves round-robin: the slots one sample touches are neighbours in the sorted order, and
+    // the waves meet at a barrier every pick -- dealt wave-major, one wave updated 4 - 8 slots while seven waited (4.3 ms)
+    // Register arrays as native vectors: a slot is selected by a WAVE-UNIFORM run-time index, which the compiler turns into
+    // M0-relative register addressing (s_set_gpr_idx / v_movrel: two or three instructions), not into a branch tree over 16
+    // code copies (measured: 0.37 us per touched slot through a 4-level scalar branch tree -- instruction refetches -- and
+    // 0.41 us for the winner search; the builder's 16-way chain of round 3 was worse still).
+    // block of slot j of this wave: round-robin, skewed by the higher bits of j -- in Morton order a block's spatial neighbours
+    // sit 1, 2, 4, 8, ... blocks away, and a plain j kW + w puts the ones 8 and 16 away into the same wave again
+    auto blk = [&](int j) { return j * kW + ((w ^ j ^ (j >> 3)) & (kW - 1)); };
+    fvec px, py, pz, pt;
+    ivec pk;  // tie rank (bitrev(k mod bs) << 4 | k div bs): smaller wins among equal distances
 #pragma unroll
     for (int j = 0; j < kP; ++j) {
-        const int sp = (w * kP + j) * 64 + lane;
+        const int sp = blk(j) * 64 + lane;
         const bool valid = sp < n;
         const int k = valid ? perm[sp] : 0;
         px[j] = valid ? xyz[3 * k + 0] : 0.f;
@@ -159,13 +163,13 @@ fps_cull_kernel(int n, int m, int bs, int lg, const float *__restrict__ xyz_all,
     int slotbits = (int)0x80000000;
 #pragma unroll
     for (int j = 0; j < kP; ++j) {
-        const bool valid = (w * kP + j) * 64 + lane < n;
+        const bool valid = blk(j) * 64 + lane < n;
         const int none = (int)0x80000000;
         const int hx = wave_max_i32(valid ? ordered(px[j]) : none), lx = wave_max_i32(valid ? ordered(-px[j]) : none);
         const int hy = wave_max_i32(valid ? ordered(py[j]) : none), ly = wave_max_i32(valid ? ordered(-py[j]) : none);
         const int hz = wave_max_i32(valid ? ordered(pz[j]) : none), lz = wave_max_i32(valid ? ordered(-pz[j]) : none);
-        const bool any = (w * kP + j) * 64 < n;  // (wave-uniform) the slot holds at least one point
-        if ((lane & 15) == j) {
+        const bool any = blk(j) * 64 < n;  // (wave-uniform) the slot holds at least one point
+        if ((lane & (kP - 1)) == j) {
             bhx = unordered(hx); bhy = unordered(hy); bhz = unordered(hz);
             blx = -unordered(lx); bly = -unordered(ly); blz = -unordered(lz);
             slotbits = any ? f2i(1e10f) : f2i(-1.0f);
@@ -183,30 +187,27 @@ fps_cull_kernel(int n, int m, int bs, int lg, const float *__restrict__ xyz_all,
         const float ex = fmaxf(fmaxf(blx - cx, cx - bhx), 0.f), ey = fmaxf(fmaxf(bly - cy, cy - bhy), 0.f),
                     ez = fmaxf(fmaxf(blz - cz, cz - bhz), 0.f);
         const float bound = __builtin_fmaf(ez, ez, __builtin_fmaf(ex, ex, ey * ey));
-        unsigned touch = (unsigned)__ballot(!(bound >= i2f(slotbits))) & 0xffffu;
+        constexpr unsigned kSlots = kP == 32 ? 0xffffffffu : 0xffffu;
+        unsigned touch = (unsigned)__ballot(!(bound >= i2f(slotbits))) & kSlots;
         while (touch) {
-            const int j = __builtin_ctz(touch);
+            const int j = __builtin_ctz(touch);  // wave-uniform
             touch &= touch - 1;
-            with_slot<0, kP>(j, [&](auto J) {
-                constexpr int jj = decltype(J)::value;
-                const float tt = fmin_raw(sqdist(px[jj], py[jj], pz[jj], cx, cy, cz), pt[jj]);
-                pt[jj] = tt;
-                const int mx = wave_max_i32(f2i(tt));  // >= 0 floats (or -1.0f) order like their bit patterns
-                slotbits = (lane & 15) == jj ? mx : slotbits;
-            });
+            const float tt = fmin_raw(sqdist(px[j], py[j], pz[j], cx, cy, cz), pt[j]);
+            pt[j] = tt;
+            const int mx = wave_max_i32(f2i(tt));  // >= 0 floats (or -1.0f) order like their bit patterns
+            slotbits = (lane & (kP - 1)) == j ? mx : slotbits;
         }
         // the wave's maximum = the maximum of its slot values; its holder = the smallest tie rank among the points that reach it
-        const int wbest = __builtin_amdgcn_readlane(row_group_max_i32<16>(slotbits), 0);
-        unsigned cand = (unsigned)__ballot(slotbits == wbest) & 0xffffu;
+        int rmax = row_group_max_i32<16>(slotbits);
+        if constexpr (kP == 32) PN2_DPP_STEP("v_max_i32_dpp", rmax, "row_bcast:15 row_mask:0xa bank_mask:0xf");  // lane 31: rows 0 and 1
+        const int wbest = __builtin_amdgcn_readlane(rmax, kP - 1);
+        unsigned cand = (unsigned)__ballot(slotbits == wbest) & kSlots;
         unsigned ltk = 0x7fffffffu;
         while (cand) {
             const int j = __builtin_ctz(cand);
             cand &= cand - 1;
-            with_slot<0, kP>(j, [&](auto J) {
-                constexpr int jj = decltype(J)::value;
-                const unsigned r = wave_min_u32(f2i(pt[jj]) == wbest ? (unsigned)pk[jj] : 0x7fffffffu);
-                ltk = r < ltk ? r : ltk;
-            });
+            const unsigned r = wave_min_u32(f2i(pt[j]) == wbest ? (unsigned)pk[j] : 0x7fffffffu);
+            ltk = r < ltk ? r : ltk;
         }
         int *e = ent + (it & 1) * (2 * 16);
         if (lane == 0) {
@@ -228,20 +229,28 @@ fps_cull_kernel(int n, int m, int bs, int lg, const float *__restrict__ xyz_all,
     }
 }
 
-}  // namespace fpc
-
 // n in (2048, 8192], bs = 1024 (lg = 10): the register layout holds 8192 points, the tie rank packs k div bs into 4 bits.
-int fps_cull_launch(int b, int n, int m, int bs, int lg, const float *xyz, int *idx, hipStream_t st) {
-    using namespace fpc;
-    if (n > kT * kP || (n >> lg) > 15) return PN2_ERANGE;
+template <int kT, int kP>
+static int launch_cull(int b, int n, int m, int bs, int lg, const float *xyz, int *idx, hipStream_t st) {
+    constexpr int kW = kT / kWave;
     const size_t prologue = (size_t)(kCells + 2 * kT + 8192 + 6 * kW) * sizeof(int);
     const size_t loop = (size_t)3 * n * sizeof(float);
     const size_t lds = 2 * 2 * 16 * sizeof(int) + (prologue > loop ? prologue : loop);
+    auto kfn = fps_cull_kernel<kT, kP>;
     static PerDeviceOnce raised;
     if (raised.first_use())
-        (void)hipFuncSetAttribute((const void *)fps_cull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipLaunchKernelGGL(fps_cull_kernel, dim3(b), dim3(kT), lds, st, n, m, bs, lg, xyz, idx);
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipLaunchKernelGGL(kfn, dim3(b), dim3(kT), lds, st, n, m, bs, lg, xyz, idx);
     return check_launch();
+}
+
+}  // namespace fpc
+
+int fps_cull_launch(int b, int n, int m, int bs, int lg, const float *xyz, int *idx, hipStream_t st) {
+    if (n > 8192 || (n >> lg) > 15) return PN2_ERANGE;
+    static const int waves = [] { const char *e = getenv("PN2_FPC_WAVES"); return e ? atoi(e) : 8; }();  // A/B: 8 waves x 16 slots | 4 x 32
+    if (waves == 4) return fpc::launch_cull<256, 32>(b, n, m, bs, lg, xyz, idx, st);
+    return fpc::launch_cull<512, 16>(b, n, m, bs, lg, xyz, idx, st);
 }
 
 }  // namespace pn2

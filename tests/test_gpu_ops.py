@@ -47,7 +47,7 @@ def test_fps_index_exact(ops, oracle, B, N, M, kind):
 FPS_LARGE_CASES = [
     (2, 8192, 2048, "uniform"), (2, 8192, 700, "lattice"), (2, 4097, 300, "uniform"), (3, 5000, 1500, "hand"), (2, 6000, 600, "dup"),
     (1, 8192, 8192, "uniform"), (2, 5832, 900, "lattice"), (2, 7000, 256, "plane"), (2, 4500, 128, "line"), (1, 5000, 80, "same"),
-    # the culled kernel's range ends (2048 < n <= 8192: fps_cull.hip), a partly filled last register slot, few picks / many picks
+    # 16 points per lane: range ends, a partly filled last register slot, few picks / many picks
     (2, 2049, 300, "uniform"), (1, 8191, 500, "lattice"), (2, 3000, 3000, "hand"), (3, 8192, 64, "dup"),
 ]
 
