@@ -178,15 +178,15 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane) {
 __global__ void __launch_bounds__(kQueryT)
 query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz_all, const unsigned *__restrict__ scratch_all,
              int *__restrict__ idx_all) {
-    extern __shared__ int tab[];  // [kMaxKeys + 4] cell starts | per wave: 256 bitmap words (a lane owns 4 consecutive words)
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // LDS: per wave 256 bitmap words (a lane owns 4 consecutive words).  The cell starts are read where they lie (global
+    // memory, wave-uniform addresses: scalar loads through the constant cache) -- a copy of the table in LDS (48 KiB reserved
+    // for the largest grid) held the kernel at 3 workgroups per compute unit, and its loads wait on L2 round trips.
+    __shared__ unsigned bitmaps[kQueryWaves * 256];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned *__restrict__ scratch = scratch_all + (size_t)b * cloud_words(n);
     const Header H = *reinterpret_cast<const Header *>(scratch);
-    const int nkeys = H.ncell * H.nblocks;
-    const int *__restrict__ gstart = reinterpret_cast<const int *>(scratch) + kHeader;
-    for (int i = tid; i <= nkeys; i += kQueryT) tab[i] = gstart[i];
-    unsigned *bm = reinterpret_cast<unsigned *>(tab + kMaxKeys + 4) + w * 256;
-    __syncthreads();
+    const int *__restrict__ tab = reinterpret_cast<const int *>(scratch) + kHeader;
+    unsigned *bm = bitmaps + w * 256;
     const float4 *__restrict__ rec = reinterpret_cast<const float4 *>(scratch + kHeader + kMaxKeys + 4);
     const int NB = 2048 * H.wpl;  // indices per block (<= 8192 = the bitmap)
     const int per_wg = kQueryWaves * 4;  // 4 centroids per wave
@@ -300,8 +300,7 @@ int ball_query_grid_dispatch(int b, int n, int m, float radius, int nsample, con
     hipLaunchKernelGGL(build_kernel, dim3(b), dim3(kBuildT), (size_t)(kMaxKeys + 1 + kBuildT) * sizeof(int), st, n, radius, nsample, xyz, scratch);
     if (int rc = check_launch()) return rc;
     const dim3 grid((m + kQueryWaves * 4 - 1) / (kQueryWaves * 4), b);
-    const size_t lds = (size_t)(kMaxKeys + 4 + kQueryWaves * 256) * sizeof(int);
-    hipLaunchKernelGGL(query_kernel, grid, dim3(kQueryT), lds, st, n, m, radius2, nsample, new_xyz, scratch, idx);
+    hipLaunchKernelGGL(query_kernel, grid, dim3(kQueryT), 0, st, n, m, radius2, nsample, new_xyz, scratch, idx);
     return check_launch();
 }
 
