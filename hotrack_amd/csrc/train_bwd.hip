@@ -92,9 +92,11 @@ struct Plan {
     static_assert(2 * RG * N <= KS_D * BM * LDX, "the final column-sum staging reuses the data-gradient staging");
 };
 
+// The tile loop of one problem, run by workgroup `wg` of the `nwg` workgroups assigned to it: a whole launch (tg_bwd_kernel) or
+// one share of a launch serving two problems of the same layer shape (tg_bwd_pair_kernel: the two neighbourhood sizes of a
+// keypoint-query module).
 template <int NB, int KB, int GMODE>
-__global__ void __launch_bounds__(kT, (NB == 1 && KB <= 2 ? 4 : 2))  // sa1's layers: two workgroups per CU (<= 128 registers)
-tg_bwd_kernel(BwdArgs a) {
+__device__ __forceinline__ void tg_bwd_body(const BwdArgs &a, const int wg, const int nwg) {
     using P = Plan<NB, KB, GMODE>;
     constexpr int N = P::N, Kd = P::Kd, LDY = P::LDY, LDX = P::LDX;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -143,7 +145,7 @@ tg_bwd_kernel(BwdArgs a) {
             ph[i] = *reinterpret_cast<const float4 *>(a.Yp + r * a.ldyp + 4 * cq);
         }
     };
-    long tile = blockIdx.x;
+    long tile = wg;
     if (tile < T) prefetch(tile);  // the first tile's operands travel while the constants (and W_i) are set up
 
     // W_i (where it is LDS-resident) is requested before the constants are derived and stored after them: one memory round trip
@@ -172,7 +174,7 @@ tg_bwd_kernel(BwdArgs a) {
         for (int c = tid; c < N; c += kT) {
             cP[c] = a.mean_p[c]; cP[N + c] = a.invstd_p[c]; cP[2 * N + c] = a.gamma_p[c]; cP[3 * N + c] = a.beta_p[c];
         }
-        if (blockIdx.x == 0)
+        if (wg == 0)
             for (int e = tid; e < Kd * N; e += kT) a.dW[e] = 0.f;
         if constexpr (P::WLDS) {
 #pragma unroll
@@ -276,7 +278,7 @@ tg_bwd_kernel(BwdArgs a) {
         TGB_T(t1);
         __syncthreads();
         TGB_T(t2);
-        const long ntile = tile + gridDim.x;
+        const long ntile = tile + nwg;
         if constexpr (P::WLDS) {  // nothing else of this tile touches global memory before the epilogue's stores
             if (ntile < T) prefetch(ntile);
         }
@@ -376,7 +378,7 @@ tg_bwd_kernel(BwdArgs a) {
 
     // weight-gradient partial tile of this workgroup (and row slice)
     {
-        float *out = a.partial + ((size_t)blockIdx.x * P::KS_W + ksw) * (size_t)(Kd * N);
+        float *out = a.partial + ((size_t)wg * P::KS_W + ksw) * (size_t)(Kd * N);
 #pragma unroll
         for (int j = 0; j < P::WB; ++j)
 #pragma unroll
@@ -401,16 +403,29 @@ tg_bwd_kernel(BwdArgs a) {
             s += (double)redS[r * N + tid];
             q += (double)redQ[r * N + tid];
         }
-        double *dst = a.sums_bwd_p + (size_t)(blockIdx.x % kBnRep) * 2 * N;
+        double *dst = a.sums_bwd_p + (size_t)(wg % kBnRep) * 2 * N;
         unsafeAtomicAdd(dst + tid, s);
         unsafeAtomicAdd(dst + N + tid, q);
     }
 #ifdef PN2_TGB_PROFILE
     if (tid == 0 && a.prof) {
         pacc[7] = clock64() - t_loop;
-        for (int k = 0; k < 8; ++k) a.prof[(size_t)blockIdx.x * 8 + k] = pacc[k];
+        for (int k = 0; k < 8; ++k) a.prof[(size_t)wg * 8 + k] = pacc[k];
     }
 #endif
+}
+
+template <int NB, int KB, int GMODE>
+__global__ void __launch_bounds__(kT, (NB == 1 && KB <= 2 ? 4 : 2))  // sa1's layers: two workgroups per CU (<= 128 registers)
+tg_bwd_kernel(BwdArgs a) {
+    tg_bwd_body<NB, KB, GMODE>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int NB, int KB, int GMODE>
+__global__ void __launch_bounds__(kT, (NB == 1 && KB <= 2 ? 4 : 2))
+tg_bwd_pair_kernel(BwdArgs a0, BwdArgs a1, int n0) {
+    if ((int)blockIdx.x < n0) tg_bwd_body<NB, KB, GMODE>(a0, (int)blockIdx.x, n0);
+    else tg_bwd_body<NB, KB, GMODE>(a1, (int)blockIdx.x - n0, (int)gridDim.x - n0);
 }
 
 struct Shape {
@@ -482,13 +497,20 @@ extern "C" int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, i
 // One column slice [c0, c0 + n) of a layer with sums_ld >= n channels: the caller passes g / yi / the per-channel vectors / sums_bwd_i /
 // w / dw already offset to the slice; arg (gmode 2) has its own row stride ldarg (g may be a column block of a wider tensor).  g_add (row stride ldga, may alias gp): the data-gradient partial of earlier slices; raw_out: leave
 // mask and sums to a later slice.
-extern "C" int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int ldarg, int kmax, const float *yi,
-                                 int ldyi, const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i,
-                                 const double *sums_bwd_i, int sums_ld, const float *w, int ldw, const float *yp, int ldyp,
-                                 const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p, float *gp,
-                                 int ldgp, double *sums_bwd_p, float *partial, long partial_floats, float *dw, const float *g_add,
-                                 int ldga, int raw_out, void *stream) {
-    Shape s;
+#define PN2_TGB_PARAMS(S)                                                                                                              \
+    long rows##S, int n##S, int k##S, int gmode##S, const float *g##S, int ldg##S, const int *arg##S, int ldarg##S, int kmax##S,         \
+        const float *yi##S, int ldyi##S, const float *mean_i##S, const float *invstd_i##S, const float *gamma_i##S,                    \
+        const float *beta_i##S, const double *sums_bwd_i##S, int sums_ld##S, const float *w##S, int ldw##S, const float *yp##S,        \
+        int ldyp##S, const float *mean_p##S, const float *invstd_p##S, const float *gamma_p##S, const float *beta_p##S, float *gp##S,  \
+        int ldgp##S, double *sums_bwd_p##S, float *partial##S, long partial_floats##S, float *dw##S, const float *g_add##S, int ldga##S, \
+        int raw_out##S
+#define PN2_TGB_ARGS(S)                                                                                                                \
+    rows##S, n##S, k##S, gmode##S, g##S, ldg##S, arg##S, ldarg##S, kmax##S, yi##S, ldyi##S, mean_i##S, invstd_i##S, gamma_i##S, beta_i##S, \
+        sums_bwd_i##S, sums_ld##S, w##S, ldw##S, yp##S, ldyp##S, mean_p##S, invstd_p##S, gamma_p##S, beta_p##S, gp##S, ldgp##S,        \
+        sums_bwd_p##S, partial##S, partial_floats##S, dw##S, g_add##S, ldga##S, raw_out##S
+
+// validation + kernel arguments of one problem (grid-independent part)
+static int fill_bwd(PN2_TGB_PARAMS(), BwdArgs &a, Shape &s) {
     if (rows < 1 || rows > 0x7fffffffL || !find_shape(k, n, s) || gmode < 0 || gmode > 2 || sums_ld < n) return PN2_EINVAL;
     if (gmode == 2 && (kmax < 1 || rows % kmax || ldarg < n || ldarg % 4)) return PN2_EINVAL;
     if ((gmode == 2 && !arg) || (gmode != 0 && !beta_i)) return PN2_ENULL;
@@ -499,14 +521,23 @@ extern "C" int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float
         !gp || !sums_bwd_p || !partial || !dw)
         return PN2_ENULL;
     if (((uintptr_t)g | (uintptr_t)yi | (uintptr_t)yp | (uintptr_t)gp) % 16) return PN2_EINVAL;
-    const int grid = grid_of(rows, s);
-    if (partial_floats < (long)grid * s.ks_w * n * k) return PN2_ESCRATCH;
-    BwdArgs a{rows, g, ldg, arg, ldarg, kmax, kshift_of(kmax), yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, sums_ld, g_add, ldga, raw_out ? 1 : 0, w, ldw, yp, ldyp, mean_p, invstd_p, gamma_p, beta_p,
-              gp, ldgp, sums_bwd_p, partial, dw
+    (void)partial_floats;
+    a = BwdArgs{rows, g, ldg, arg, ldarg, kmax, kshift_of(kmax), yi, ldyi, mean_i, invstd_i, gamma_i, beta_i, sums_bwd_i, sums_ld, g_add, ldga, raw_out ? 1 : 0, w, ldw, yp, ldyp, mean_p, invstd_p, gamma_p, beta_p,
+                gp, ldgp, sums_bwd_p, partial, dw
 #ifdef PN2_TGB_PROFILE
-              , g_prof
+                , g_prof
 #endif
     };
+    return PN2_OK;
+}
+
+extern "C" int pn2x_tg_bwd_slice(PN2_TGB_PARAMS(), void *stream) {
+    Shape s;
+    BwdArgs a;
+    const int rc = fill_bwd(PN2_TGB_ARGS(), a, s);
+    if (rc != PN2_OK) return rc;
+    const int grid = grid_of(rows, s);
+    if (partial_floats < (long)grid * s.ks_w * n * k) return PN2_ESCRATCH;
     hipStream_t st = (hipStream_t)stream;
     const int nb = k / 32, kb = n / 32;
 #define PN2_TGB_LAUNCH(NB_, KB_, GM_)                                                                                  \
@@ -524,6 +555,57 @@ extern "C" int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float
         else PN2_TGB_LAUNCH(NB_, KB_, 2);                                                                             \
     }
     PN2_TGB_SHAPES(X)
+#undef X
+#undef PN2_TGB_LAUNCH
+    return check_launch();
+}
+
+// the pair kernel is instantiated for the 128-channel layers of the keypoint-query modules only (128 -> 128, 128 -> 192)
+extern "C" int pn2x_tg_bwd_pair_supported(int c_in, int c_out) { return (c_in == 128 && (c_out == 128 || c_out == 192)) ? 1 : 0; }
+
+// Two problems of the same layer shape and gradient source in ONE launch (the two neighbourhood sizes of a keypoint-query
+// module): the persistent workgroups are split in proportion to the tile counts.  n_partials[2] receives the number of partial
+// weight-gradient tiles each problem wrote (its share of the grid x the row slices per workgroup): the caller's reduction must
+// sum exactly those.  Each partial buffer must hold what the problem would need alone (pn2x_tg_bwd_partials).
+extern "C" int pn2x_tg_bwd_slice_pair(PN2_TGB_PARAMS(0), PN2_TGB_PARAMS(1), int *n_partials, void *stream) {
+    Shape s0, s1;
+    BwdArgs a0, a1;
+    if (!n_partials) return PN2_ENULL;
+    int rc = fill_bwd(PN2_TGB_ARGS(0), a0, s0);
+    if (rc != PN2_OK) return rc;
+    rc = fill_bwd(PN2_TGB_ARGS(1), a1, s1);
+    if (rc != PN2_OK) return rc;
+    if (n0 != n1 || k0 != k1 || gmode0 != gmode1) return PN2_EINVAL;
+    if (!pn2x_tg_bwd_pair_supported(k0, n0)) return PN2_ERANGE;
+    const long t0 = (rows0 + BM - 1) / BM, t1 = (rows1 + BM - 1) / BM;
+    long cap = (long)num_compute_units() * (s0.lds * 2 <= 160 * 1024 ? 2 : 1);
+    if (cap < 2) cap = 2;
+    long rounds = (t0 + t1 + cap - 1) / cap, wg0, wg1;
+    for (;; ++rounds) {  // the same number of rounds for both shares
+        wg0 = (t0 + rounds - 1) / rounds;
+        wg1 = (t1 + rounds - 1) / rounds;
+        if (wg0 + wg1 <= cap || rounds > t0 + t1) break;
+    }
+    if (partial_floats0 < wg0 * s0.ks_w * n0 * k0 || partial_floats1 < wg1 * s1.ks_w * n1 * k1) return PN2_ESCRATCH;
+    n_partials[0] = (int)wg0 * s0.ks_w;
+    n_partials[1] = (int)wg1 * s1.ks_w;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = k0 / 32, kb = n0 / 32, gmode = gmode0;
+#define PN2_TGB_LAUNCH(NB_, KB_, GM_)                                                                                  \
+    do {                                                                                                              \
+        static PerDeviceOnce once;                                                                                    \
+        if (once.first_use())                                                                                         \
+            (void)hipFuncSetAttribute((const void *)tg_bwd_pair_kernel<NB_, KB_, GM_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)s0.lds);                                                                   \
+        hipLaunchKernelGGL((tg_bwd_pair_kernel<NB_, KB_, GM_>), dim3((unsigned)(wg0 + wg1)), dim3(kT), s0.lds, st, a0, a1, (int)wg0); \
+    } while (0)
+#define X(NB_, KB_)                                                                                                   \
+    if (nb == NB_ && kb == KB_) {                                                                                     \
+        if (gmode == 0) PN2_TGB_LAUNCH(NB_, KB_, 0);                                                                  \
+        else if (gmode == 1) PN2_TGB_LAUNCH(NB_, KB_, 1);                                                             \
+        else PN2_TGB_LAUNCH(NB_, KB_, 2);                                                                             \
+    }
+    X(4, 4) X(4, 6)
 #undef X
 #undef PN2_TGB_LAUNCH
     return check_launch();

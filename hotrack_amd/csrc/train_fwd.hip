@@ -47,9 +47,11 @@ struct Plan {
     static constexpr int lds_floats = 4 * K + BM * LDK + NW * LDK + WAVES * 64;
 };
 
+// The tile loop of one problem, run by workgroup `wg` of the `nwg` workgroups (per column group) assigned to it: a whole launch
+// (tgf_kernel), or one share of a launch that serves two problems of the same layer shape at once (tgf_pair_kernel: the two
+// neighbourhood sizes of a keypoint-query module -- same widths, different weights and row counts).
 template <int KB, int NBLK>
-__global__ void __launch_bounds__(128 * NBLK)
-tgf_kernel(FwdArgs a) {
+__device__ __forceinline__ void tgf_body(const FwdArgs &a, const int wg, const int nwg) {
     using P = Plan<KB, NBLK>;
     constexpr int K = P::K, NW = P::NW, LDK = P::LDK, T = P::T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -59,7 +61,7 @@ tgf_kernel(FwdArgs a) {
     float *red = Ws + NW * LDK;    // [WAVES][2][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
     const int n0 = blockIdx.y * NW;
-    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    const bool first = wg == 0 && blockIdx.y == 0;
     const long tiles = (a.R + BM - 1) / BM;
     // tile operands: a wave fetches 8 rows x 8 float4 (128 contiguous bytes per row) per step; the first 8 waves (all of
     // them where there are fewer) cover the tile's eight 8-row groups
@@ -76,7 +78,7 @@ tgf_kernel(FwdArgs a) {
             for (int i = 0; i < KB; ++i) px[g * KB + i] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + 4 * (8 * i + aq));
         }
     };
-    long tile = blockIdx.x;
+    long tile = wg;
     if (tile < tiles) prefetch(tile);  // the first tile's operands travel while the constants and W_i are set up
     // W_i's slice: requested now, stored to LDS after the constants (one memory round trip for both instead of two in a row)
     constexpr int WCNT = NW * (K / 4) / T;
@@ -147,7 +149,7 @@ tgf_kernel(FwdArgs a) {
     while (tile < tiles) {
         commit(tile);
         __syncthreads();
-        const long ntile = tile + gridDim.x;
+        const long ntile = tile + nwg;
         if (ntile < tiles) prefetch(ntile);  // nothing else of this tile reads global memory
         f32x16 acc;
 #pragma unroll
@@ -214,11 +216,25 @@ tgf_kernel(FwdArgs a) {
             const int b = tid >> 5, c = tid & 31;  // column block b: waves b (rows 0..31) and NBLK + b (rows 32..63)
             const double sd = (double)red[b * 64 + c] + (double)red[(NBLK + b) * 64 + c];
             const double qd = (double)red[b * 64 + 32 + c] + (double)red[(NBLK + b) * 64 + 32 + c];
-            double *dst = a.sums_out + (size_t)((blockIdx.x + blockIdx.y) % kBnRep) * 2 * a.N;
+            double *dst = a.sums_out + (size_t)((wg + blockIdx.y) % kBnRep) * 2 * a.N;
             unsafeAtomicAdd(dst + n0 + tid, sd);
             unsafeAtomicAdd(dst + a.N + n0 + tid, qd);
         }
     }
+}
+
+template <int KB, int NBLK>
+__global__ void __launch_bounds__(128 * NBLK)
+tgf_kernel(FwdArgs a) {
+    tgf_body<KB, NBLK>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// workgroups [0, n0) of every column group run problem 0, the rest problem 1
+template <int KB, int NBLK>
+__global__ void __launch_bounds__(128 * NBLK)
+tgf_pair_kernel(FwdArgs a0, FwdArgs a1, int n0) {
+    if ((int)blockIdx.x < n0) tgf_body<KB, NBLK>(a0, (int)blockIdx.x, n0);
+    else tgf_body<KB, NBLK>(a1, (int)blockIdx.x - n0, (int)gridDim.x - n0);
 }
 
 // column blocks per workgroup for n output channels: 6 (192 columns) where that divides n and 128 does not leave fewer
@@ -285,5 +301,62 @@ extern "C" int pn2x_tg_fwd2(long rows, int k, int n, const float *x, int ldx, co
         else PN2_TGF_LAUNCH(2, 2);
     }
 #undef PN2_TGF_LAUNCH
+    return check_launch();
+}
+
+// instantiated for the 128-channel layers of the keypoint-query modules (128 -> 128, 128 -> 192)
+extern "C" int pn2x_tg_fwd2_pair_supported(int c_in, int c_out) {
+    return (c_in == 128 && (c_out == 128 || c_out == 192) && blocks_for_k(c_in, c_out) != 0) ? 1 : 0;
+}
+
+// Two problems of the SAME layer shape (k -> n) in one launch: the persistent workgroups are split in proportion to the
+// problems' tile counts, so both shares run the same number of rounds.  The two neighbourhood sizes of a keypoint-query module
+// (10752 and 43008 rows at 32 clouds) as two launches were 168 one-tile workgroups + 3 ragged rounds, each launch paying its own
+// constants / W_i prologue and tail.
+extern "C" int pn2x_tg_fwd2_pair(long rows0, int k, int n, const float *x0, int ldx0, const float *w0, int ldw0, float *y0, int ldy0,
+                                 const double *sums_in0, const float *gamma0, const float *beta0, const float *conv_bias0, float eps0,
+                                 float momentum0, float *running_mean0, float *running_var0, long long *nbt0, float *save_mean0,
+                                 float *save_invstd0, double *sums_out0,
+                                 long rows1, const float *x1, int ldx1, const float *w1, int ldw1, float *y1, int ldy1,
+                                 const double *sums_in1, const float *gamma1, const float *beta1, const float *conv_bias1, float eps1,
+                                 float momentum1, float *running_mean1, float *running_var1, long long *nbt1, float *save_mean1,
+                                 float *save_invstd1, double *sums_out1, void *stream) {
+    if (rows0 < 1 || rows1 < 1) return PN2_EINVAL;
+    if (!pn2x_tg_fwd2_pair_supported(k, n)) return PN2_ERANGE;
+    if (ldx0 < k || ldx0 % 4 || ldw0 < k || ldw0 % 4 || ldy0 < n || ldx1 < k || ldx1 % 4 || ldw1 < k || ldw1 % 4 || ldy1 < n) return PN2_EINVAL;
+    if (!x0 || !w0 || !y0 || !sums_in0 || !gamma0 || !beta0 || !save_mean0 || !save_invstd0) return PN2_ENULL;
+    if (!x1 || !w1 || !y1 || !sums_in1 || !gamma1 || !beta1 || !save_mean1 || !save_invstd1) return PN2_ENULL;
+    if (((uintptr_t)x0 | (uintptr_t)w0 | (uintptr_t)x1 | (uintptr_t)w1) % 16) return PN2_EINVAL;
+    FwdArgs a0{rows0, n, x0, ldx0, w0, ldw0, y0, ldy0, sums_in0, gamma0, beta0, conv_bias0, eps0, momentum0, running_mean0, running_var0,
+               nbt0, save_mean0, save_invstd0, sums_out0};
+    FwdArgs a1{rows1, n, x1, ldx1, w1, ldw1, y1, ldy1, sums_in1, gamma1, beta1, conv_bias1, eps1, momentum1, running_mean1, running_var1,
+               nbt1, save_mean1, save_invstd1, sums_out1};
+    const int nblk = blocks_for_k(k, n), kb = k / 32;
+    const int ny = n / (32 * nblk);
+    const long t0 = (rows0 + BM - 1) / BM, t1 = (rows1 + BM - 1) / BM;
+    hipStream_t st = (hipStream_t)stream;
+#define PN2_TGF_PAIR(KB_, NBLK_)                                                                                        \
+    do {                                                                                                              \
+        using P = Plan<KB_, NBLK_>;                                                                                   \
+        const size_t lds = (size_t)P::lds_floats * sizeof(float);                                                     \
+        static PerDeviceOnce once;                                                                                    \
+        if (once.first_use())                                                                                         \
+            (void)hipFuncSetAttribute((const void *)tgf_pair_kernel<KB_, NBLK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        long per_cu = (long)(160 * 1024 / lds);                                                                       \
+        if (per_cu > 2) per_cu = 2;                                                                                   \
+        if (per_cu < 1) per_cu = 1;                                                                                   \
+        long cap = (long)num_compute_units() * per_cu / ny;                                                           \
+        if (cap < 2) cap = 2;                                                                                         \
+        long rounds = (t0 + t1 + cap - 1) / cap, g0, g1;                                                              \
+        for (;; ++rounds) {  /* same number of rounds for both shares */                                              \
+            g0 = (t0 + rounds - 1) / rounds;                                                                          \
+            g1 = (t1 + rounds - 1) / rounds;                                                                          \
+            if (g0 + g1 <= cap || rounds > t0 + t1) break;                                                            \
+        }                                                                                                             \
+        hipLaunchKernelGGL((tgf_pair_kernel<KB_, NBLK_>), dim3((unsigned)(g0 + g1), ny), dim3(P::T), lds, st, a0, a1, (int)g0); \
+    } while (0)
+    if (nblk == 6) PN2_TGF_PAIR(4, 6);
+    else PN2_TGF_PAIR(4, 4);
+#undef PN2_TGF_PAIR
     return check_launch();
 }

@@ -59,6 +59,15 @@ _lib.pn2x_tg_bwd.argtypes = [_cl, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _
 _lib.pn2x_tg_bwd_slice.argtypes = [_cl, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp,
                                    _vp, _vp, _vp, _ci, _vp, _vp, _cl, _vp, _vp, _ci, _ci, _vp]
 _lib.pn2x_tg_bwd_slice.restype = _ci
+_lib.pn2x_tg_fwd2_pair_supported.argtypes = [_ci, _ci]
+_lib.pn2x_tg_fwd2_pair_supported.restype = _ci
+_lib.pn2x_tg_bwd_pair_supported.argtypes = [_ci, _ci]
+_lib.pn2x_tg_bwd_pair_supported.restype = _ci
+_lib.pn2x_tg_fwd2_pair.argtypes = _lib.pn2x_tg_fwd.argtypes[:-1] + [_cl] + _lib.pn2x_tg_fwd.argtypes[3:-1] + [_vp]  # (k, n once)
+_lib.pn2x_tg_fwd2_pair.restype = _ci
+_lib.pn2x_tg_bwd_slice_pair.argtypes = _lib.pn2x_tg_bwd_slice.argtypes[:-1] * 2 + [ctypes.POINTER(_ci), _vp]
+_lib.pn2x_tg_bwd_slice_pair.restype = _ci
+PAIR_LAUNCH = _os.environ.get("HOTRACK_STACK_PAIR_LAUNCH", "1") != "0"  # one launch for equal-shaped layers of two sibling stacks
 _lib.pn2x_tg_reduce_multi2.argtypes = [_ci, ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_vp),
                                        ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_vp),
                                        ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]
@@ -200,9 +209,14 @@ class Layer:
         self.weight, self.bn, self.conv_bias = weight, bn, conv_bias
 
 
-class _Stack(torch.autograd.Function):
+# The forward / backward of ONE stack are generators: wherever a launch could be grouped with the same launch of a sibling stack
+# (the W-resident forward and the one-kernel layer backward of csrc/train_fwd.hip / train_bwd.hip), they yield the launch request
+# instead of issuing it; _drive() advances one or two stacks in lockstep and issues each request alone or, for two stacks of
+# the same layer shape, as one pair launch (pn2x_tg_fwd2_pair / pn2x_tg_bwd_slice_pair: the two neighbourhood sizes of a
+# keypoint-query module).  Everything else is launched where it stands.
+class _Fwd:
     @staticmethod
-    def forward(ctx, y1, K, ws, metas, aux, *tensors):
+    def gen(y1, K, ws, metas, aux, tensors):
         # tensors: per layer (weight | placeholder, gamma, beta, conv bias | placeholder); metas: per layer (running_mean, running_var, nbt, eps, momentum)
         L = len(metas)
         R, C1 = y1.shape
@@ -225,11 +239,13 @@ class _Stack(torch.autograd.Function):
                 y = torch.empty((R, N), dtype=_f32, device=dev)
                 sv = torch.empty((2, Kc), dtype=_f32, device=dev)
                 x = ys[-1]
-                fwd = _lib.pn2x_tg_fwd2 if (FWD2 and _lib.pn2x_tg_fwd2_supported(Kc, N)) else _lib.pn2x_tg_fwd
-                _native._check(fwd(R, Kc, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), N,
-                                                ws_f[i - 1].data_ptr(), gamma_p.data_ptr(), beta_p.data_ptr(), _p(bias_p), float(eps),
-                                                float(mom), _p(rm), _p(rv), _p(nbt), sv[0].data_ptr(), sv[1].data_ptr(),
-                                                ws_f[i].data_ptr(), st), "tg_fwd")
+                fargs = (R, Kc, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), N,
+                         ws_f[i - 1].data_ptr(), gamma_p.data_ptr(), beta_p.data_ptr(), _p(bias_p), float(eps),
+                         float(mom), _p(rm), _p(rv), _p(nbt), sv[0].data_ptr(), sv[1].data_ptr(), ws_f[i].data_ptr())
+                if FWD2 and _lib.pn2x_tg_fwd2_supported(Kc, N):
+                    yield ("fwd2", fargs, st, dev)  # (issued by _drive: alone, or grouped with a sibling stack's)
+                else:
+                    _native._check(_lib.pn2x_tg_fwd(*fargs, st), "tg_fwd")
                 ys.append(y)
                 saved.append(sv)
             # top of the stack: the streaming kernels (they also finalise the last layer's statistics)
@@ -253,16 +269,22 @@ class _Stack(torch.autograd.Function):
                                                        beta.data_ptr(), _p(bias), float(eps), float(mom), _p(rm), _p(rv), _p(nbt),
                                                        sv[0].data_ptr(), sv[1].data_ptr(), out.data_ptr(), C, 1, st), "bn_relu_apply")
             saved.append(sv)
-        ctx.save_for_backward(*ys, *saved, *([arg] if arg is not None else []), *tensors)
-        ctx.L, ctx.K, ctx.aux = L, K, aux
-        ctx.has_bias = [tensors[4 * i + 3].numel() > 0 for i in range(L)]
-        ctx.ws, ctx.ws_gen, ctx.ws_b_all = ws, ws.generation, ws_b
-        return out
+        info = _Info()
+        info.L, info.K, info.aux = L, K, aux
+        info.has_bias = [tensors[4 * i + 3].numel() > 0 for i in range(L)]
+        info.ws, info.ws_gen, info.ws_b_all = ws, ws.generation, ws_b
+        return out, [*ys, *saved, *([arg] if arg is not None else []), *tensors], info
 
+
+class _Info:
+    """What a stack's backward needs besides its saved tensors (the `ctx` attributes of a single-stack Function)."""
+    ws_used = False
+
+
+class _Bwd:
     @staticmethod
-    def backward(ctx, dout):
+    def gen(ctx, t, dout):
         L, K = ctx.L, ctx.K
-        t = ctx.saved_tensors
         ys, saved = t[:L], t[L:2 * L]
         off = 2 * L
         arg = None
@@ -342,14 +364,17 @@ class _Stack(torch.autograd.Function):
                         np_ = int(_lib.pn2x_tg_bwd_partials(R, wd, Kc))
                         partial = torch.empty(np_ * wd * Kc, dtype=_f32, device=dev)
                         o4 = 4 * off
-                        _native._check(_lib.pn2x_tg_bwd_slice(
+                        bargs = (
                             R, wd, Kc, gmode, g.data_ptr() + o4, g.stride(0), (arg.data_ptr() + o4) if gmode == 2 else None,
                             arg.stride(0) if gmode == 2 else 4, K if gmode == 2 else 1, yi.data_ptr() + o4, yi.stride(0), svi[0].data_ptr() + o4, svi[1].data_ptr() + o4,
                             gam(i).data_ptr() + o4, bet(i).data_ptr() + o4, sums[i].data_ptr() + 8 * off, N,
                             wc.data_ptr() + o4 * wc.stride(0), wc.stride(0), yp.data_ptr(), yp.stride(0), svp[0].data_ptr(),
                             svp[1].data_ptr(), gam(i - 1).data_ptr(), bet(i - 1).data_ptr(), gp.data_ptr(), Kc, sums[i - 1].data_ptr(),
                             partial.data_ptr(), partial.numel(), dw.data_ptr() + o4 * Kc, gp.data_ptr() if j else None, Kc,
-                            1 if j + 1 < len(slices) else 0, st), "tg_bwd")
+                            1 if j + 1 < len(slices) else 0)
+                        # issued by _drive; the answer is the number of partial tiles actually written (a pair launch gives this
+                        # problem a share of the grid, fewer workgroups than it would get alone)
+                        np_ = yield ("bwd", bargs, st, dev, np_)
                         item = (partial, np_, dw[off:off + wd], sums[i][off:], dpar[:, off:off + wd], st, N)
                         if defer:
                             _defer(item)
@@ -405,7 +430,90 @@ class _Stack(torch.autograd.Function):
             grads[1], grads[2] = dpar[0], dpar[1]
             if ctx.has_bias[0]:
                 grads[3] = dpar[2]
+        return dy1, grads
+
+
+def _pairable(a, b):
+    """Two launch requests that one pair launch can serve: same kind, same layer shape (and gradient source), same stream."""
+    if a[0] != b[0] or a[2] != b[2] or a[3] != b[3] or not PAIR_LAUNCH:
+        return False
+    if a[0] == "fwd2":
+        return a[1][1:3] == b[1][1:3] and bool(_lib.pn2x_tg_fwd2_pair_supported(a[1][1], a[1][2]))
+    return a[1][1:4] == b[1][1:4] and bool(_lib.pn2x_tg_bwd_pair_supported(a[1][2], a[1][1]))
+
+
+def _issue(req):
+    kind, args, st, dev = req[:4]
+    with torch.cuda.device(dev):
+        if kind == "fwd2":
+            _native._check(_lib.pn2x_tg_fwd2(*args, st), "tg_fwd2")
+            return None
+        _native._check(_lib.pn2x_tg_bwd_slice(*args, st), "tg_bwd")
+        return req[4]
+
+
+def _issue_pair(a, b):
+    kind, st, dev = a[0], a[2], a[3]
+    with torch.cuda.device(dev):
+        if kind == "fwd2":
+            _native._check(_lib.pn2x_tg_fwd2_pair(*a[1], b[1][0], *b[1][3:], st), "tg_fwd2_pair")
+            return None, None
+        nparts = (_ci * 2)()
+        _native._check(_lib.pn2x_tg_bwd_slice_pair(*a[1], *b[1], nparts, st), "tg_bwd_pair")
+        return int(nparts[0]), int(nparts[1])
+
+
+def _drive(gens):
+    """Run the stack generators in lockstep; returns their return values."""
+    n = len(gens)
+    results, answer, alive = [None] * n, [None] * n, list(range(n))
+    while alive:
+        reqs = {}
+        for i in list(alive):
+            try:
+                reqs[i] = gens[i].send(answer[i])
+            except StopIteration as stop:
+                results[i] = stop.value
+                alive.remove(i)
+            answer[i] = None
+        if len(reqs) == 2 and _pairable(*reqs.values()):
+            (i, a), (j, b) = reqs.items()
+            answer[i], answer[j] = _issue_pair(a, b)
+        else:
+            for i, r in reqs.items():
+                answer[i] = _issue(r)
+    return results
+
+
+class _Stack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y1, K, ws, metas, aux, *tensors):
+        (out, saved, info), = _drive([_Fwd.gen(y1, K, ws, metas, aux, tensors)])
+        ctx.save_for_backward(*saved)
+        ctx.info = info
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (dy1, grads), = _drive([_Bwd.gen(ctx.info, ctx.saved_tensors, dout)])
         return (dy1, None, None, None, None, *grads)
+
+
+class _StackPair(torch.autograd.Function):
+    """Two stacks of the same layer widths (different weights, different row counts) whose fused launches are grouped."""
+
+    @staticmethod
+    def forward(ctx, y1a, y1b, Ka, Kb, ws, metas_a, metas_b, aux_a, aux_b, n_a, *tensors):
+        ra, rb = _drive([_Fwd.gen(y1a, Ka, ws, metas_a, aux_a, tensors[:n_a]), _Fwd.gen(y1b, Kb, ws, metas_b, aux_b, tensors[n_a:])])
+        ctx.save_for_backward(*ra[1], *rb[1])
+        ctx.split, ctx.infos = len(ra[1]), (ra[2], rb[2])
+        return ra[0], rb[0]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        t = ctx.saved_tensors
+        ra, rb = _drive([_Bwd.gen(ctx.infos[0], t[:ctx.split], da), _Bwd.gen(ctx.infos[1], t[ctx.split:], db)])
+        return (ra[0], rb[0], None, None, None, None, None, None, None, None, *ra[1], *rb[1])
 
 
 def mlp_stack(y1: torch.Tensor, layers, ws, max_over: int = 0, aux=None) -> torch.Tensor:
@@ -430,6 +538,32 @@ def mlp_stack(y1: torch.Tensor, layers, ws, max_over: int = 0, aux=None) -> torc
         none = y1.new_empty(0)
         tensors += [l.weight if i else none, bn.weight, bn.bias, l.conv_bias if l.conv_bias is not None else none]
     return _Stack.apply(y1, int(max_over), ws, metas, aux, *tensors)
+
+
+def _stack_inputs(y1, layers):
+    metas, tensors = [], []
+    for i, l in enumerate(layers):
+        bn = l.bn
+        track = bn.track_running_stats and bn.running_mean is not None
+        metas.append((bn.running_mean if track else None, bn.running_var if track else None,
+                      bn.num_batches_tracked if track else None, bn.eps, bn.momentum if bn.momentum is not None else 0.1))
+        none = y1.new_empty(0)
+        tensors += [l.weight if i else none, bn.weight, bn.bias, l.conv_bias if l.conv_bias is not None else none]
+    return metas, tensors
+
+
+def mlp_stack_pair(y1a, y1b, layers_a, layers_b, ws, max_over_a: int = 0, max_over_b: int = 0, aux_a=None, aux_b=None):
+    """mlp_stack for TWO stacks at once: (mlp_stack(y1a, layers_a, ...), mlp_stack(y1b, layers_b, ...)), with the fused launches of
+    layers of equal shape grouped into one launch each (forward and backward).  For the neighbourhood sizes of a multi-scale
+    module: same widths, different weights, different row counts."""
+    if len(layers_a) < 2 or len(layers_b) < 2:
+        return mlp_stack(y1a, layers_a, ws, max_over_a, aux_a), mlp_stack(y1b, layers_b, ws, max_over_b, aux_b)
+    for y, k in ((y1a, max_over_a), (y1b, max_over_b)):
+        if k and y.shape[0] % k:
+            raise ValueError("mlp_stack_pair: rows must be a multiple of max_over")
+    metas_a, tensors_a = _stack_inputs(y1a, layers_a)
+    metas_b, tensors_b = _stack_inputs(y1b, layers_b)
+    return _StackPair.apply(y1a, y1b, int(max_over_a), int(max_over_b), ws, metas_a, metas_b, aux_a, aux_b, len(tensors_a), *tensors_a, *tensors_b)
 
 
 def stack_supported(c1: int, widths) -> bool:

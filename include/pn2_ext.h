@@ -520,6 +520,30 @@ int pn2x_tg_bwd_slice(long rows, int n, int k, int gmode, const float *g, int ld
                       int sums_ld, const float *w, int ldw, const float *yp, int ldyp, const float *mean_p, const float *invstd_p,
                       const float *gamma_p, const float *beta_p, float *gp, int ldgp, double *sums_bwd_p, float *partial,
                       long partial_floats, float *dw, const float *g_add, int ldga, int raw_out, void *stream);
+/* Two problems of the same layer shape (and gradient source) in ONE launch -- the two neighbourhood sizes of a keypoint-query
+ * module: same widths, different weights and row counts (reference pointnet_utils.py:566-581 runs them as separate Conv2d stacks).
+ * Arguments: those of pn2x_tg_bwd_slice / pn2x_tg_fwd2 twice (n, k and gmode must agree); the persistent workgroups are split in
+ * proportion to the tile counts.  n_partials[2] receives the number of weight-gradient partial tiles each problem wrote. */
+int pn2x_tg_bwd_pair_supported(int c_in, int c_out);
+int pn2x_tg_fwd2_pair_supported(int c_in, int c_out);
+int pn2x_tg_bwd_slice_pair(long rows0, int n0, int k0, int gmode0, const float *g0, int ldg0, const int *arg0, int ldarg0, int kmax0,
+                           const float *yi0, int ldyi0, const float *mean_i0, const float *invstd_i0, const float *gamma_i0,
+                           const float *beta_i0, const double *sums_bwd_i0, int sums_ld0, const float *w0, int ldw0, const float *yp0,
+                           int ldyp0, const float *mean_p0, const float *invstd_p0, const float *gamma_p0, const float *beta_p0, float *gp0,
+                           int ldgp0, double *sums_bwd_p0, float *partial0, long partial_floats0, float *dw0, const float *g_add0, int ldga0,
+                           int raw_out0,
+                           long rows1, int n1, int k1, int gmode1, const float *g1, int ldg1, const int *arg1, int ldarg1, int kmax1,
+                           const float *yi1, int ldyi1, const float *mean_i1, const float *invstd_i1, const float *gamma_i1,
+                           const float *beta_i1, const double *sums_bwd_i1, int sums_ld1, const float *w1, int ldw1, const float *yp1,
+                           int ldyp1, const float *mean_p1, const float *invstd_p1, const float *gamma_p1, const float *beta_p1, float *gp1,
+                           int ldgp1, double *sums_bwd_p1, float *partial1, long partial_floats1, float *dw1, const float *g_add1, int ldga1,
+                           int raw_out1, int *n_partials, void *stream);
+int pn2x_tg_fwd2_pair(long rows0, int k, int n, const float *x0, int ldx0, const float *w0, int ldw0, float *y0, int ldy0,
+                      const double *sums_in0, const float *gamma0, const float *beta0, const float *conv_bias0, float eps0, float momentum0,
+                      float *running_mean0, float *running_var0, long long *nbt0, float *save_mean0, float *save_invstd0, double *sums_out0,
+                      long rows1, const float *x1, int ldx1, const float *w1, int ldw1, float *y1, int ldy1, const double *sums_in1,
+                      const float *gamma1, const float *beta1, const float *conv_bias1, float eps1, float momentum1, float *running_mean1,
+                      float *running_var1, long long *nbt1, float *save_mean1, float *save_invstd1, double *sums_out1, void *stream);
 int pn2x_tg_bwd_supported(int c_in, int c_out);
 int pn2x_tg_bwd_partials(long rows, int c_out, int c_in);
 int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi, int ldyi,

@@ -147,12 +147,34 @@ class FastTrain:
         aux = {} if self.use_fused_stacks else None  # relative coordinates -> the stacks, d(W_xyz) <- the stacks (train_ops.sa_layer1)
         y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1], invs=invs, aux=aux)
         outs = []
-        for i, y1 in enumerate(y1s):
-            K = idxs[i].shape[2]
-            h = self._stack(y1.view(B * S * K, -1), mod.conv_blocks[i], mod.bn_blocks[i], first_done=True, max_over=K,
-                            aux=None if aux is None else (aux, i))
-            outs.append(h.view(B, S, -1))
+        pair = self._pair_stacks(mod, y1s, idxs, aux) if len(y1s) == 2 else None
+        if pair is not None:  # both neighbourhood sizes layer by layer, equal-shaped fused launches grouped (train_stack.mlp_stack_pair)
+            outs = [h.view(B, S, -1) for h in pair]
+        else:
+            for i, y1 in enumerate(y1s):
+                K = idxs[i].shape[2]
+                h = self._stack(y1.view(B * S * K, -1), mod.conv_blocks[i], mod.bn_blocks[i], first_done=True, max_over=K,
+                                aux=None if aux is None else (aux, i))
+                outs.append(h.view(B, S, -1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
+
+    def _pair_stacks(self, mod, y1s, idxs, aux):
+        """The two scales of a module as ONE pair of fused stacks when their layer widths agree and the kernels cover them."""
+        if not self.use_fused_stacks:
+            return None
+        from hotrack_amd import train_stack
+        widths = [[c.weight.shape[0] for c in convs] for convs in mod.conv_blocks]
+        if widths[0] != widths[1] or len(widths[0]) < 2 or not train_stack.stack_supported(widths[0][0], widths[0][1:]):
+            return None
+        stacks = []
+        for i, y1 in enumerate(y1s):
+            convs, bns = mod.conv_blocks[i], mod.bn_blocks[i]
+            layers = [train_stack.Layer(None, bns[0], convs[0].bias)]
+            layers += [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(convs[1:], bns[1:])]
+            stacks.append((y1.view(-1, y1.shape[-1]), layers, idxs[i].shape[2]))
+        (ya, la, ka), (yb, lb, kb) = stacks
+        return train_stack.mlp_stack_pair(ya, yb, la, lb, self.ws, ka, kb, aux_a=None if aux is None else (aux, 0),
+                                          aux_b=None if aux is None else (aux, 1))
 
     def _fp(self, mod, xyz1, xyz2, points1, points2, extra=None, nn3=None):
         """xyz1 (B,N,3), xyz2 (B,S,3), points1 (B,N,D1)|None, points2 (B,S,D2) -> (B*N, D') rows.

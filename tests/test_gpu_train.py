@@ -785,3 +785,56 @@ def test_fast_tail_equals_module_tail():
         scale = float(b[3][k].abs().max()) + 1e-12
         assert float((a[3][k] - b[3][k]).abs().max()) / scale < 1e-4, k
     assert float((a[2] - b[2]).abs().max()) / float(b[2].abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("widths,Ka,Kb,G", [([128, 128, 192], 16, 64, 21 * 32), ([128, 128, 192], 16, 64, 21 * 3), ([64, 64, 128], 32, 32, 40),
+                                            ([128, 128, 128], 16, 32, 50)])
+def test_mlp_stack_pair_equals_two_stacks(widths, Ka, Kb, G):
+    """train_stack.mlp_stack_pair -- the fused launches of two sibling stacks grouped into pair launches (csrc/train_fwd.hip
+    tgf_pair_kernel, train_bwd.hip tg_bwd_pair_kernel: the two neighbourhood sizes of a keypoint-query module, reference
+    pointnet_utils.py:566-581) -- against the same two stacks run one after the other: outputs, arg-max routing, every
+    gradient, running statistics.  The 64-channel case has no pair kernel (lockstep single launches), the last one pairs 128 ->
+    128 layers of different group sizes."""
+    from hotrack_amd import train_stack
+    from hotrack_amd.train_ops import Workspace
+    g = torch.Generator(device="cuda").manual_seed(G + Ka)
+
+    def make():
+        gg = torch.Generator(device="cuda").manual_seed(7)
+        convs = [torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])]
+        bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in widths]
+        with torch.no_grad():
+            for bn in bns:
+                bn.weight.copy_(1 + 0.3 * torch.randn(bn.weight.shape, device="cuda", generator=gg))
+                bn.bias.copy_(0.2 * torch.randn(bn.bias.shape, device="cuda", generator=gg))
+        return convs, bns
+
+    ya0 = torch.randn(G * Ka, widths[0], device="cuda", generator=g) * 1.5 + 0.3
+    yb0 = torch.randn(G * Kb, widths[0], device="cuda", generator=g) * 0.7 - 0.2
+    goa = torch.randn(G, widths[-1], device="cuda", generator=g)
+    gob = torch.randn(G, widths[-1], device="cuda", generator=g)
+    res = {}
+    for paired in (False, True):
+        torch.manual_seed(3)
+        (ca, ba), (cb, bb) = make(), make()
+        with torch.no_grad():  # the two scales have DIFFERENT weights
+            for c in cb:
+                c.weight.mul_(0.5).add_(0.01)
+        la = [train_stack.Layer(None, ba[0], None)] + [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(ca, ba[1:])]
+        lb = [train_stack.Layer(None, bb[0], None)] + [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(cb, bb[1:])]
+        ws = Workspace("cuda")
+        ya, yb = ya0.clone().requires_grad_(True), yb0.clone().requires_grad_(True)
+        if paired:
+            oa, ob = train_stack.mlp_stack_pair(ya, yb, la, lb, ws, Ka, Kb)
+        else:
+            oa, ob = train_stack.mlp_stack(ya, la, ws, Ka), train_stack.mlp_stack(yb, lb, ws, Kb)
+        ((oa * goa).sum() + (ob * gob).sum()).backward()
+        params = [p for m in ca + ba + cb + bb for p in m.parameters()]
+        bufs = [b_ for m in ba + bb for b_ in (m.running_mean, m.running_var)]
+        res[paired] = ([oa.detach(), ob.detach(), ya.grad, yb.grad] + [p.grad for p in params], bufs)
+    for i, (a, b) in enumerate(zip(res[False][0], res[True][0])):
+        assert (a is None) == (b is None), i
+        if a is not None:  # same kernels, same per-tile arithmetic; only the order of the partial sums differs
+            torch.testing.assert_close(b, a, rtol=2e-4, atol=2e-5 * max(1.0, float(a.abs().max())), msg=lambda m: f"tensor {i}: {m}")
+    for a, b in zip(res[False][1], res[True][1]):
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
