@@ -685,7 +685,8 @@ tg_reduce_multi_kernel(ReduceMulti a) {
         add(q, red[3][el]);
         add(r, q);
         float *dst = a.dW[t] + 4 * (size_t)e;
-        atomicAdd(dst + 0, r.x); atomicAdd(dst + 1, r.y); atomicAdd(dst + 2, r.z); atomicAdd(dst + 3, r.w);
+        // hardware fp32 atomics (global_atomic_add_f32): the plain atomicAdd compiles to a compare-and-swap loop
+        unsafeAtomicAdd(dst + 0, r.x); unsafeAtomicAdd(dst + 1, r.y); unsafeAtomicAdd(dst + 2, r.z); unsafeAtomicAdd(dst + 3, r.w);
     }
     const int c = bx * kT + threadIdx.x;
     if (by == 0 && c < N && a.sums[t]) {
