@@ -24,5 +24,12 @@ python $R/scripts/trace_window.py $(find /tmp/ts -name "*kernel_trace.csv" | hea
 rm -rf /tmp/tst && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tst -o t -- python $R/scripts/bench_stress.py > /dev/null 2>&1
 cp $(find /tmp/tst -name "*kernel_stats.csv" | head -1) $O/${tag}_stress_kernel_stats.csv
 cd $R
+python scripts/probes/two_graph_overlap.py 2>/dev/null | grep "ms / step" > $O/${tag}_two_graph_overlap.txt
+python scripts/probes/train_host_timing.py 2>/dev/null | grep "step " > $O/${tag}_train_prefetch_vs_inline.txt
+HOTRACK_STACK_PAIR_LAUNCH=0 python scripts/bench_train.py --graph > $O/${tag}_bench_train_graph_no_pair_launch.json 2>/dev/null
+HOTRACK_PREFETCH_GEOMETRY=0 python scripts/bench_train.py --graph > $O/${tag}_bench_train_graph_no_prefetch.json 2>/dev/null
+python scripts/bench_legs.py stress > $O/${tag}_stress_leg.json 2>/dev/null
+python scripts/bench_legs.py latency > $O/${tag}_latency_leg.json 2>/dev/null
+python scripts/kernel_resources.py > $O/${tag}_kernel_resources.txt 2>&1
 bash scripts/scale_selftest.sh 2 > $O/${tag}_scale_selftest.log 2>&1
 tail -3 $O/${tag}_pytest_gpu.log; cat $O/${tag}_bench_train_graph.json; tail -2 $O/${tag}_scale_selftest.log
