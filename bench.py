@@ -434,7 +434,11 @@ def main():
                     sk.bind(("127.0.0.1", 0))
                     port[0] = sk.getsockname()[1]
             dist.broadcast(port, src=0)
-            env = dict(os.environ, MASTER_PORT=str(int(port[0])), MASTER_ADDR="127.0.0.1", PN2_DIST_BACKEND=backend, HOTRACK_KEEP_GRAPH="1")
+            # the children rendezvous among themselves: without the launcher's agent-store variables (TORCHELASTIC_USE_AGENT_STORE
+            # makes a worker CONNECT to a store the elastic agent serves at MASTER_PORT -- nobody serves the fresh port, and the
+            # children would wait for one until the leg's timeout), rank 0's child hosts the TCP store itself
+            env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC", "GROUP_", "ROLE_"))}
+            env.update(MASTER_PORT=str(int(port[0])), MASTER_ADDR="127.0.0.1", PN2_DIST_BACKEND=backend, HOTRACK_KEEP_GRAPH="1")
             cmd = [sys.executable, os.path.join(ROOT, "scripts", "bench_train.py"), "--steps", str(args.train_steps), "--warmup", "5",
                    "--batch", "32", "--graph"]
             got = bench_legs.run_child(cmd, float(os.environ.get("PN2_BENCH_LEG_TIMEOUT", "600")), env=env, expect_json=(rank == 0))

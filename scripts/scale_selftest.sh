@@ -12,7 +12,7 @@ export HOTRACK_DATA_ROOT=${HOTRACK_DATA_ROOT:-/tmp/hotrack_selftest}
 one=$(python bench.py --gpus 1 --steps 5 --warmup 2 --min-time 0.2 --no-cpu-baseline | grep '^{')
 for N in $Ns; do
   port=$((29600 + N))
-  line=$(PN2_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
+  line=$(PN2_BENCH_BACKEND=gloo PN2_BENCH_LEG_TIMEOUT=240 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
          --master-port $port bench.py --gpus $N --steps 5 --warmup 2 --min-time 0.2 --train-steps 5 --no-cpu-baseline | grep '^{')
   python - "$N" "$line" "$one" <<'PY'
 import json, sys
@@ -22,6 +22,7 @@ assert d["config"]["global_batch"] == n * d["config"]["per_gpu_batch"] and d["sc
 assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
 # the multi-GPU extras: per-rank spread of the headline and the data-parallel training leg that shows the gradient all-reduce
 pr, tr = d["per_rank_frames_per_s"], d["train"]
+assert "error" not in tr, tr
 assert len(pr["ranks"]) == n and pr["min"] <= pr["max"]
 assert d["world_size_seen_by_backend"] == n, d
 assert tr["n_gpus"] == n and tr["world_size_seen_by_backend"] == n and tr["dp_mode"] == "flat" and tr["graph_step"] is True, tr
