@@ -441,7 +441,7 @@ def main():
             env.update(MASTER_PORT=str(int(port[0])), MASTER_ADDR="127.0.0.1", PN2_DIST_BACKEND=backend, HOTRACK_KEEP_GRAPH="1")
             cmd = [sys.executable, os.path.join(ROOT, "scripts", "bench_train.py"), "--steps", str(args.train_steps), "--warmup", "5",
                    "--batch", "32", "--graph"]
-            got = bench_legs.run_child(cmd, float(os.environ.get("PN2_BENCH_LEG_TIMEOUT", "600")), env=env, expect_json=(rank == 0))
+            got = bench_legs.run_child(cmd, float(os.environ.get("PN2_BENCH_LEG_TIMEOUT", "300")), env=env, expect_json=(rank == 0))
             # every parent is alive here whatever its child did; one small collective tells rank 0 whether any child failed
             bad = torch.tensor([1 if "error" in got else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(bad, op=dist.ReduceOp.SUM)
