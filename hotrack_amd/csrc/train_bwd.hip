@@ -57,13 +57,13 @@ struct BwdArgs {
     float *partial;             // out: [gridDim.x * KS_W][C_i][C_{i-1}]
     float *dW;                  // zeroed by workgroup 0 (tg_reduce_multi accumulates into it)
 #ifdef PN2_TGB_PROFILE
-    long long *prof;            // tuning builds: [gridDim.x][8] cycle counts of thread 0 (scripts/probes/tgb_profile.py)
+    long long *prof;            // tuning builds: [gridDim.x][8 waves][8] cycle counts of each wave's lane 0 (scripts/probes/tgb_profile.py)
 #endif
 };
 
 #ifdef PN2_TGB_PROFILE
 #define TGB_T(var) const long long var = clock64()
-#define TGB_ADD(slot, t1, t0) do { if (tid == 0) pacc[slot] += (t1) - (t0); } while (0)
+#define TGB_ADD(slot, t1, t0) do { if (lane == 0) pacc[slot] += (t1) - (t0); } while (0)
 #else
 #define TGB_T(var)
 #define TGB_ADD(slot, t1, t0)
@@ -293,7 +293,12 @@ __device__ __forceinline__ void tg_bwd_body(const BwdArgs &a, const int wg, cons
                 for (int s = 0; s < steps_d; ++s)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s * N], acc, 0, 0, 0);
             } else {
-                // W_i is the same for every tile: the buffer for batch 0 is refilled by the last pair of this tile
+                // W_i is the same for every tile: the buffer for batch 0 is refilled by the last pair of this tile.
+                // (Round 4, per-wave cycle counts -- scripts/probes/tgb_profile.py: the two waves of a SIMD leave this phase at
+                // 39 k and 52 k cycles for 32 k of matrix instructions, the early ones then wait 13 k at the barrier: the phase
+                // runs at ~66 % because W_i arrives from L2 one batch ahead only.  Requesting the LDS operand half a batch
+                // ahead behind scheduling fences changed nothing -- the partner wave already covers that latency -- and cost
+                // the narrow layers 4-10 %; a deeper W_i buffer does not fit the register file of the 128 -> 192 layer.)
                 constexpr int NBATCH = steps_d / U;
 #pragma unroll 1
                 for (int b = 0; b < NBATCH; b += 2) {
@@ -408,9 +413,9 @@ __device__ __forceinline__ void tg_bwd_body(const BwdArgs &a, const int wg, cons
         unsafeAtomicAdd(dst + N + tid, q);
     }
 #ifdef PN2_TGB_PROFILE
-    if (tid == 0 && a.prof) {
+    if (lane == 0 && a.prof) {  // lane 0 of EVERY wave: [workgroup][wave][8 phases]
         pacc[7] = clock64() - t_loop;
-        for (int k = 0; k < 8; ++k) a.prof[(size_t)wg * 8 + k] = pacc[k];
+        for (int k = 0; k < 8; ++k) a.prof[((size_t)wg * 8 + wave) * 8 + k] = pacc[k];
     }
 #endif
 }

@@ -1,8 +1,9 @@
 """Where a tg_bwd_kernel workgroup spends its cycles (csrc/train_bwd.hip).  Needs a tuning build of the library:
     PN2_EXTRA_HIPCC_FLAGS=-DPN2_TGB_PROFILE python -c "from hotrack_amd import _build; _build.build(force=True)"
     python scripts/probes/tgb_profile.py
-Prints, per layer shape, the mean cycle counts of thread 0 over all workgroups:
-prologue | commit | barrier 1 | data gradient | weight gradient | barrier 2 | epilogue | tail.  Rebuild without the flag afterwards."""
+Prints, per layer shape, the mean cycle counts over all workgroups of wave 0 and, per wave, of the two matrix phases and the two
+barrier waits: prologue | commit | barrier 1 | data gradient | weight gradient | barrier 2 | epilogue | tail.  Rebuild without the
+flag afterwards."""
 import ctypes
 import json
 import os
@@ -24,7 +25,7 @@ def main():
         raise SystemExit("library built without -DPN2_TGB_PROFILE")
     lib.pn2x_tg_bwd_set_profile.argtypes = [ctypes.c_void_p]
     lib.pn2x_tg_bwd_set_profile.restype = None
-    prof = torch.zeros(1024 * 8, dtype=torch.int64, device="cuda")
+    prof = torch.zeros(1024 * 8 * 8, dtype=torch.int64, device="cuda")
     lib.pn2x_tg_bwd_set_profile(prof.data_ptr())
     names = ["prologue", "commit", "barrier1", "dgrad", "wgrad", "barrier2", "epilogue", "tail"]
     out = {}
@@ -41,10 +42,12 @@ def main():
             ws_gen = torch.autograd.grad(o, y, torch.ones_like(o), retain_graph=True)
         torch.cuda.synchronize()
         grid = int(lib.pn2x_tg_bwd_partials(R, cout, cin))
-        p = prof.view(-1, 8)[:min(grid, 1024)].double()
-        p = p[p.sum(dim=1) > 0]
+        pw = prof.view(-1, 8, 8)[:min(grid, 1024)].double()   # [workgroup][wave][phase]
+        pw = pw[pw[:, 0].sum(dim=1) > 0]
+        p = pw[:, 0]
         out[name] = {"workgroups": int(p.shape[0]), "tiles": (R + 63) // 64,
-                     **{n: round(float(p[:, i].mean())) for i, n in enumerate(names)}, "total": round(float(p.sum(dim=1).mean()))}
+                     **{n: round(float(p[:, i].mean())) for i, n in enumerate(names)}, "total": round(float(p.sum(dim=1).mean())),
+                     "per_wave": {n: [round(float(pw[:, w, i].mean())) for w in range(8)] for i, n in enumerate(names) if n in ("barrier1", "dgrad", "wgrad", "barrier2", "commit", "epilogue")}}
     print(json.dumps(out, indent=1))
 
 
