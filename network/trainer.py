@@ -442,8 +442,8 @@ class Trainer(nn.Module):
                     for k, v in d.items()}
 
         self._graph, self._static = None, clone(data)
-        if self._geo_ready_for is not None:  # a prefetch of the previous capture's graph may still be running
-            torch.cuda.current_stream().wait_event(self._geo_done)
+        if self._geo_ready_for is not None:  # a prefetch of the previous capture's graph may still be running: its graph, its
+            self._geo_done.synchronize()     # pool and its pack buffers are about to be dropped (host wait: captures are rare)
         self._geo_graph = self._static_geo = self._geo_ready_for = None
         # Warm-up on a side stream (MIOpen / BLAS pick their algorithms, autograd builds its buffers, Adam creates its
         # state) -- then put every value back, IN PLACE, so the captured step starts from the state update() was called

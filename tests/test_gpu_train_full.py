@@ -202,3 +202,53 @@ def test_geometry_prefetch_equals_inline_geometry(tmp_path, monkeypatch):
     assert all(max(v) - min(v) <= 2e-5 * max(v) for v in by_batch.values()), by_batch
     firsts = sorted(v[0] for v in by_batch.values())
     assert all(b_ - a_ > 1e-3 * a_ for a_, b_ in zip(firsts, firsts[1:])), by_batch
+
+
+def test_geometry_prefetch_survives_recapture_and_shape_changes(tmp_path, monkeypatch):
+    """The transitions around the prefetch: a re-capture while a prefetch is in flight (epoch boundary: learning rate and BN
+    momentum are baked into the graphs), a batch of another shape announced as `next_data` (ignored: that batch re-captures and
+    runs its geometry in line), and back.  Parameters frozen, so every step's loss must equal the loss of the same batch in a
+    trainer without prefetch."""
+    monkeypatch.setenv("HOTRACK_DATA_ROOT", str(tmp_path))
+    from configs.config import get_config
+    from datasets.synthetic import make_frame
+    from parse_args import add_args
+    from trainer import Trainer
+
+    def build(prefetch):
+        a = add_args(argparse.ArgumentParser()).parse_args(["--config", "handtracknet_train_SimGrasp.yml"])
+        a.num_points, a.batch_size = 512, 8
+        cfg = get_config(a, save=False)
+        cfg["graph_step"], cfg["prefetch_geometry"], cfg["learning_rate"] = True, prefetch, 0.0
+        torch.manual_seed(0)
+        tr = Trainer(cfg)
+        tr.step_epoch()
+        for m in tr.model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        return tr
+
+    def batch(seed, n):
+        b = torch.utils.data.default_collate([make_frame(seed + i, 512, 0.02) for i in range(n)])
+        return {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in b.items()}
+
+    big = [batch(100, 8), batch(200, 8), batch(300, 8)]
+    small = batch(400, 5)
+    a, b = build(True), build(False)
+    b.load_state_dict(a.state_dict())
+    seq = [big[0], big[1], "epoch", big[2], big[0], small, big[1], big[2]]
+    steps = [x for x in seq if not isinstance(x, str)]
+    la, lb, k = [], [], 0
+    for x in seq:
+        if isinstance(x, str):   # epoch boundary: both trainers drop their graphs (the prefetch of big[2] is in flight in `a`)
+            a.step_epoch(); b.step_epoch()
+            continue
+        nxt = steps[k + 1] if k + 1 < len(steps) else None
+        la.append(a.update(x, next_data=nxt)["total_loss"].item())
+        lb.append(b.update(x)["total_loss"].item())
+        k += 1
+    torch.cuda.synchronize()
+    assert a.graph_step and b.graph_step
+    for i, (x, y) in enumerate(zip(la, lb)):
+        assert abs(x - y) <= 2e-5 * max(1.0, abs(y)), (i, la, lb)
+    assert abs(la[0] - la[4]) <= 2e-5 * abs(la[0]) and abs(la[1] - la[6]) <= 2e-5 * abs(la[1])   # big[0], big[1] come round again
