@@ -251,4 +251,4 @@ def test_geometry_prefetch_survives_recapture_and_shape_changes(tmp_path, monkey
     assert a.graph_step and b.graph_step
     for i, (x, y) in enumerate(zip(la, lb)):
         assert abs(x - y) <= 2e-5 * max(1.0, abs(y)), (i, la, lb)
-    assert abs(la[0] - la[4]) <= 2e-5 * abs(la[0]) and abs(la[1] - la[6]) <= 2e-5 * abs(la[1])   # big[0], big[1] come round again
+    assert abs(la[0] - la[3]) <= 2e-5 * abs(la[0]) and abs(la[1] - la[5]) <= 2e-5 * abs(la[1])   # big[0], big[1] come round again
