@@ -235,14 +235,28 @@ query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__
                         }
                     ncand = 0;
                 }
-                for (int f0 = 0; f0 < ncand; f0 += 64) {
-                    int f = f0 + lane, p = -1;
+                // flat candidate f -> record: f + (start of its run - candidates in front of the run).  The run boundaries are
+                // wave-uniform (scalar registers), so a lane adds the step of every boundary it lies behind: three VALU
+                // instructions per run, half of what the select / subtract chain over (start, length) pairs cost -- the kernel
+                // is VALU-bound on exactly this arithmetic since the cell table left LDS
+                int cum[9], step[9];
+                {
+                    int c = 0, dprev = 0;
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        p = (f >= 0 && f < rlen[r]) ? rp0[r] + f : p;
-                        f -= rlen[r];
+                        const int d = rp0[r] - c;  // record index = f + d inside run r
+                        cum[r] = c;
+                        step[r] = d - dprev;
+                        dprev = d;
+                        c += rlen[r];
                     }
-                    if (p >= 0) {
+                }
+                for (int f0 = 0; f0 < ncand; f0 += 64) {
+                    const int f = f0 + lane;
+                    int p = f + step[0];
+#pragma unroll
+                    for (int r = 1; r < 9; ++r) p += f >= cum[r] ? step[r] : 0;
+                    if (f < ncand) {
                         const float4 r = rec[p];
                         if (sqdist(qx, qy, qz, r.x, r.y, r.z) < radius2) {
                             const int k = __builtin_bit_cast(int, r.w) & (NB - 1);
