@@ -295,25 +295,17 @@ def test_graph_captured_data_parallel_step_two_ranks_one_gpu():
 
 
 # ---- fused BatchNorm GEMM stacks (csrc/train_gemm.hip, hotrack_amd/train_stack.py) ---------------------------------------------
-@pytest.mark.parametrize("R,widths,K", [
-    (32 * 64, [32, 32, 64], 32),        # sa1 widths: 32-column tiles, wgrad with four row groups per workgroup
-    (4000, [64, 64, 128], 0),           # ragged last row tile (4000 = 31 * 128 + 32), dense top
-    (21 * 16 * 5, [128, 128, 192], 16), # keypoint-query widths: 192 = three 64-column tiles, max over K = 16
-    (21 * 64 * 2, [128, 128, 192], 64),
-    (1500, [128, 128, 512], 0),         # four 128-column tiles
-    (999, [256, 256], 0),               # two-layer stack (feature propagation), K = 256: eight reduction chunks
-    (2048, [128, 128, 384], 0),         # fp1 + conv1
-    (128 * 3, [128, 128, 512], 128),    # sa3: max over all 128 points of a cloud
-])
-def test_mlp_stack_matches_torch(R, widths, K):
-    """train_stack.mlp_stack (fused BatchNorm GEMMs) vs the same stack as torch modules in fp64: forward, running statistics,
-    and every gradient (dY_1, weights, gamma / beta; conv biases get exact zeros)."""
-    from hotrack_amd import train_stack
-    from hotrack_amd.train_ops import Workspace
-    g = torch.Generator(device="cuda").manual_seed(R + sum(widths) + K)
+def _stack_draw(R, widths, K, seed):
+    """Inputs, modules and the fp64 reference of one seeded draw of a stack case, plus the reference's KINK MARGIN: the smallest
+    |pre-activation| in front of any ReLU.  An element whose fp32 pre-activation has the other sign than the fp64 one flips one
+    mask bit, and the gradient of a ReLU is discontinuous there: one flipped bit moves a row of dW by ~ 1 / sqrt(R) (percents)
+    and a row of dY_1 by as much -- a property of comparing fp32 with fp64, not of the kernel under test."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
     C1 = widths[0]
     y1 = (torch.randn(R, C1, device="cuda", generator=g) * 1.5 + 0.3)
-    convs = [torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])]
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)  # Conv1d draws its weights from the global CPU generator
+        convs = [torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])]
     bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in widths]
     bias1 = torch.randn(C1, device="cuda", generator=g).requires_grad_(True)
     with torch.no_grad():
@@ -328,6 +320,51 @@ def test_mlp_stack_matches_torch(R, widths, K):
     for b, rb in zip(bns, ref_bns):
         rb.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in b.state_dict().items()})
         rb.momentum = b.momentum
+    # reference forward (fp64 torch modules; the layer-1 bias enters in front of its BatchNorm as in the network)
+    yb = y1.double().clone().requires_grad_(True)
+    b1 = bias1.detach().double().clone().requires_grad_(True)
+    pre = ref_bns[0](yb + b1)
+    margin = float(pre.detach().abs().min())
+    h = torch.relu(pre)
+    for rc, rb in zip(ref_convs, ref_bns[1:]):
+        pre = rb(rc(h.t().unsqueeze(0)).squeeze(0).t())
+        margin = min(margin, float(pre.detach().abs().min()))
+        h = torch.relu(pre)
+    ref = h.view(R // K, K, -1).max(dim=1)[0] if K else h
+    return g, y1, convs, bns, bias1, ref_convs, ref_bns, yb, ref, margin
+
+
+KINK_MARGIN = 2e-6  # ~ 5x the fp32 round-off of a BatchNorm output of O(1) behind a 128-term dot product
+
+
+@pytest.mark.parametrize("R,widths,K", [
+    (32 * 64, [32, 32, 64], 32),        # sa1 widths: 32-column tiles, wgrad with four row groups per workgroup
+    (4000, [64, 64, 128], 0),           # ragged last row tile (4000 = 31 * 128 + 32), dense top
+    (21 * 16 * 5, [128, 128, 192], 16), # keypoint-query widths: 192 = three 64-column tiles, max over K = 16
+    (21 * 64 * 2, [128, 128, 192], 64),
+    (1500, [128, 128, 512], 0),         # four 128-column tiles
+    (999, [256, 256], 0),               # two-layer stack (feature propagation), K = 256: eight reduction chunks
+    (2048, [128, 128, 384], 0),         # fp1 + conv1
+    (128 * 3, [128, 128, 512], 128),    # sa3: max over all 128 points of a cloud
+])
+def test_mlp_stack_matches_torch(R, widths, K, seed_offset=0):
+    """train_stack.mlp_stack (fused BatchNorm GEMMs) vs the same stack as torch modules in fp64: forward, running statistics,
+    and every gradient (dY_1, weights, gamma / beta; conv biases get exact zeros).
+
+    Every input is seeded, and the draw is the first one whose fp64 reference keeps all ~10^6 ReLU inputs at least KINK_MARGIN
+    away from zero (decided from the reference alone, see _stack_draw): with unseeded conv weights this test used to fail about
+    once in 12 suite runs on a single flipped mask bit (scripts/probes/stack_flake.py, stack_determinism.py: the fused path
+    itself is bit-for-bit repeatable)."""
+    from hotrack_amd import train_stack
+    from hotrack_amd.train_ops import Workspace
+    C1 = widths[0]
+    for attempt in range(400):
+        seed = R + sum(widths) + K + 7919 * seed_offset + 104729 * attempt
+        g, y1, convs, bns, bias1, ref_convs, ref_bns, yb, ref, margin = _stack_draw(R, widths, K, seed)
+        if margin >= KINK_MARGIN:
+            break
+    else:
+        raise AssertionError("no draw with a kink margin >= %g" % KINK_MARGIN)
     assert train_stack.stack_supported(C1, widths[1:])
     import copy
     convs_c, bns_c = copy.deepcopy(convs), copy.deepcopy(bns)  # for the round-2 baseline below
@@ -339,13 +376,6 @@ def test_mlp_stack_matches_torch(R, widths, K):
     out = train_stack.mlp_stack(ya, layers, ws, max_over=K)
     go = torch.randn(out.shape, device="cuda", generator=g)
     out.backward(go)
-    # reference (fp64 torch modules; the layer-1 bias enters in front of its BatchNorm as in the network)
-    yb = y1.double().clone().requires_grad_(True)
-    b1 = bias1.detach().double().clone().requires_grad_(True)
-    h = torch.relu(ref_bns[0](yb + b1))
-    for rc, rb in zip(ref_convs, ref_bns[1:]):
-        h = torch.relu(rb(rc(h.t().unsqueeze(0)).squeeze(0).t()))
-    ref = h.view(R // K, K, -1).max(dim=1)[0] if K else h
     ref.backward(go.double())
     torch.testing.assert_close(out.double(), ref, rtol=2e-4, atol=2e-4)
     for b, rb in zip(bns, ref_bns):
