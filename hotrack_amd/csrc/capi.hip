@@ -12,6 +12,9 @@ void set_last_hip_error(int e) { g_last_hip_error = e; }
 int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t st, int force_threads,
                  const int *skip_flags, int nflags, float *radii);
 int fps_tie_check(int b, int n, int m, int m1, const float *xyz, const int *idx, const float *radii, int *flags, hipStream_t st);
+bool fps_knn_supported(int n, int nq, int k);
+int fps_knn_dispatch(int b, int n, int m, const float *xyz, int *idx, float *radii, int nq, int k, int k2, const float *query,
+                     int *kidx, int *kidx2, hipStream_t st);
 int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                         int *idx, hipStream_t st, const int *picks, float *new_xyz_out, float *new_xyz_copy, int copy_ld);
 int three_nn_dispatch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
@@ -75,6 +78,17 @@ int pn2x_furthest_point_sampling_radii(int b, int n, int m, const float *xyz, in
     PN2_REQ(xyz && idx && radii, PN2_ENULL);
     PN2_REQ(fits_int((long)n * 3), PN2_ERANGE);
     return fps_dispatch(b, n, m, xyz, nullptr, idx, (hipStream_t)stream, 0, nullptr, 0, radii);
+}
+
+int pn2x_fps_radii_knn_supported(int n, int nq, int k) { return fps_knn_supported(n, nq, k) ? 1 : 0; }
+
+int pn2x_fps_radii_knn(int b, int n, int m, const float *xyz, int *idx, float *radii, int nq, int k, int k2, const float *query,
+                       int *knn_idx, int *knn_idx2, void *stream) {
+    PN2_REQ(b >= 0 && n >= 1 && m >= 1 && nq >= 1 && k >= 1 && k2 >= 0 && k2 <= k, PN2_EINVAL);
+    if (b == 0) return PN2_OK;
+    PN2_REQ(xyz && idx && radii && query && knn_idx && (k2 == 0 || knn_idx2), PN2_ENULL);
+    PN2_REQ(m <= n && fits_int((long)n * 3) && fits_int((long)b * nq * k), PN2_ERANGE);
+    return fps_knn_dispatch(b, n, m, xyz, idx, radii, nq, k, k2, query, knn_idx, k2 ? knn_idx2 : nullptr, (hipStream_t)stream);
 }
 
 int pn2x_fps_prefix_ties(int b, int n, int m1, int m2, const float *xyz, const int *idx1, const float *radii, int *flags, void *stream) {

@@ -15,6 +15,7 @@
 //   * all waves redundantly combine the <=16 wave candidates with DPP inside one row and
 //     pull the winner's coordinates into SGPRs with v_readlane.
 #include "pn2_common.h"
+#include "knn_wave.h"
 
 namespace pn2 {
 
@@ -23,24 +24,26 @@ enum { kCentEntry = 0, kCentLds = 1, kCentGlobal = 2 };
 // skip_flags (pn2x_furthest_point_sampling_prefix, pn2_ext.h): `nflags` ints per cloud; if given and all of a cloud's
 // are zero, the sample is known to be 0..m-1 and the workgroup writes that and returns.
 // RAD: also record radii (pn2x_furthest_point_sampling_radii); a template flag so the plain kernel's loop is untouched.
+// The sampling of cloud `cloud` by one workgroup of T threads (a whole fps_kernel workgroup, or one of the first b workgroups of
+// fps_knn_kernel below).
 template <int T, int P, int CENT, bool RAD>
-__global__ void __launch_bounds__(T)
-fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_all, int *__restrict__ idx_all,
-           const int *__restrict__ skip_flags, int nflags, float *__restrict__ radii_all) {
+__device__ __forceinline__ void fps_body(const int cloud, int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_all,
+                                         int *__restrict__ idx_all, const int *__restrict__ skip_flags, int nflags,
+                                         float *__restrict__ radii_all) {
     constexpr int W = T / kWave;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // entries: [parity][field][wave]   field: 0 dist, 1 k, 2 x, 3 y, 4 z
     float *ent = smem;
     float *lxyz = smem + 2 * 5 * 16;
 
-    const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
-    int *__restrict__ idx = idx_all + (size_t)blockIdx.x * m;
+    const float *__restrict__ xyz = xyz_all + (size_t)cloud * n * 3;
+    int *__restrict__ idx = idx_all + (size_t)cloud * m;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
     if (skip_flags) {  // wave-uniform
         int any = 0;
-        for (int f = 0; f < nflags; ++f) any |= skip_flags[(size_t)blockIdx.x * nflags + f];
+        for (int f = 0; f < nflags; ++f) any |= skip_flags[(size_t)cloud * nflags + f];
         if (!any) {
             for (int i = tid; i < m; i += T) idx[i] = i;
             return;
@@ -167,7 +170,7 @@ fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_al
         if (tid == 0) {
             idx[it] = kstar;
             // the winning (maximum) running distance of this pick -- input of the post-hoc tie check
-            if constexpr (RAD) radii_all[(size_t)blockIdx.x * m + it] = i2f(gbits);
+            if constexpr (RAD) radii_all[(size_t)cloud * m + it] = i2f(gbits);
         }
 #if defined(PN2_FPS_PROBE) && PN2_FPS_PROBE == 1   /* timing probe: no dependent centroid read */
         if constexpr (CENT == kCentLds) {
@@ -184,6 +187,32 @@ fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_al
             cz = xyz[3 * kstar + 2];
         }
     }
+}
+
+template <int T, int P, int CENT, bool RAD>
+__global__ void __launch_bounds__(T)
+fps_kernel(int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_all, int *__restrict__ idx_all,
+           const int *__restrict__ skip_flags, int nflags, float *__restrict__ radii_all) {
+    fps_body<T, P, CENT, RAD>((int)blockIdx.x, n, m, bs, lg, Q, xyz_all, idx_all, skip_flags, nflags, radii_all);
+}
+
+// First sampling level of the inference path (1024 slots: T = 256, P = 4, centroids from LDS, radii recorded) AND the k-NN lists
+// of `nq` query points per cloud (the keypoints) among the same n points, in one launch: workgroups [0, b) sample, the rest run
+// one query per wave (knn_wave.h).  The sampling is a 0.35 us-per-pick dependency chain on ONE compute unit per cloud; the
+// k-NN search (21 us as its own launch at B = 1, on the critical path of the tracking loop) only needs the same coordinates.
+template <int KP>
+__global__ void __launch_bounds__(256)
+fps_knn_kernel(int b, int n, int m, int bs, int lg, int Q, const float *__restrict__ xyz_all, int *__restrict__ idx_all,
+               float *__restrict__ radii_all, int nq, int k, const float *__restrict__ query_all, int *__restrict__ kidx_all, int k2,
+               int *__restrict__ kidx2_all) {
+    if ((int)blockIdx.x < b) {  // workgroup-uniform
+        fps_body<256, 4, kCentLds, true>((int)blockIdx.x, n, m, bs, lg, Q, xyz_all, idx_all, nullptr, 0, radii_all);
+        return;
+    }
+    const int e = (int)blockIdx.x - b, qb = (nq + 3) / 4;
+    const int cloud = e / qb, q = (e - cloud * qb) * 4 + (int)(threadIdx.x >> 6);
+    if (q >= nq) return;  // wave-uniform; this role has no workgroup barrier
+    knn_wave_body<KP>(cloud, q, nq, n, k, query_all, xyz_all, nullptr, kidx_all, k2, kidx2_all);
 }
 
 // Large-cloud fallback (n > 16384): running distances in the caller's `temp` (HBM), the
@@ -357,6 +386,38 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
 #undef PN2_FPS_ROW
 #undef PN2_FPS_CASE
     return PN2_ERANGE;
+}
+
+// pn2x_fps_radii_knn: the co-launch above, for the one geometry it is built for (everything else: PN2_ERANGE, the caller runs
+// the two launches)
+static int fps_block_size(int n) {  // reference block size: cuda_utils.h:10-14 (as fps_dispatch)
+    int bs = 1;
+    while (bs * 2 <= n && bs * 2 <= 1024) bs *= 2;
+    return bs;
+}
+
+bool fps_knn_supported(int n, int nq, int k) {
+    if (n < 1) return false;
+    const int bs = fps_block_size(n);
+    const int Q = (n + bs - 1) / bs;
+    const int slots = bs * Q;
+    return slots > 512 && slots <= 1024 && n <= 1024 && nq >= 1 && k >= 1 && k <= n && k <= PN2_KNN_MAX_K &&
+           2 * 5 * 16 * sizeof(float) + (size_t)n * 12 <= 64 * 1024;
+}
+
+int fps_knn_dispatch(int b, int n, int m, const float *xyz, int *idx, float *radii, int nq, int k, int k2, const float *query,
+                     int *kidx, int *kidx2, hipStream_t st) {
+    if (!fps_knn_supported(n, nq, k)) return PN2_ERANGE;
+    const int bs = fps_block_size(n);
+    int lg = 0;
+    while ((1 << lg) < bs) ++lg;
+    const int Q = (n + bs - 1) / bs;
+    const size_t need = 2 * 5 * 16 * sizeof(float) + (size_t)n * 3 * sizeof(float);
+    const long grid = (long)b + (long)b * ((nq + 3) / 4);
+    if (grid > 2147483647L) return PN2_ERANGE;
+    hipLaunchKernelGGL(fps_knn_kernel<16>, dim3((unsigned)grid), dim3(256), need, st, b, n, m, bs, lg, Q, xyz, idx, radii, nq, k, query,
+                       kidx, k2, kidx2);
+    return check_launch();
 }
 
 }  // namespace pn2

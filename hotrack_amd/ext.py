@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -445,6 +446,10 @@ def knn_indices(k: int, unknown: torch.Tensor, known: torch.Tensor, k2: int = 0)
 
 _lib.pn2x_furthest_point_sampling_radii.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_furthest_point_sampling_radii.restype = _ci
+_lib.pn2x_fps_radii_knn.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp]
+_lib.pn2x_fps_radii_knn.restype = _ci
+_lib.pn2x_fps_radii_knn_supported.argtypes = [_ci, _ci, _ci]
+_lib.pn2x_fps_radii_knn_supported.restype = _ci
 _lib.pn2x_fps_prefix_ties.argtypes = [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_fps_prefix_ties.restype = _ci
 _lib.pn2x_fps_prefix_flags.argtypes = [_ci]
@@ -474,22 +479,33 @@ def ball_query_picks(radius: float, nsample: int, xyz: torch.Tensor, picks: torc
     return idx, new_xyz
 
 
-def fps_two_level(xyz: torch.Tensor, m1: int, m2: int, query=None):
+FPS_KNN_COLAUNCH = os.environ.get("HOTRACK_FPS_KNN_COLAUNCH", "1") != "0"
+
+
+def fps_two_level(xyz: torch.Tensor, m1: int, m2: int, query=None, knn=None):
     """The reference's two chained samplings  i1 = FPS(xyz, m1); l1 = xyz[i1]; i2 = FPS(l1, m2)  (backbones.py:98-104)
     -> (i1 (B,m1), l1 (B,m1,3), i2 (B,m2)) int32/float32, bit-identical to running both.  The second pass is
     skipped per cloud when level 1 had no tied arg-max among its first m2 picks (include/pn2_ext.h).
     query=(radius, nsample): level 1's ball query is done by the launch that produces l1 (ball_query_picks) and its
-    index tensor (B,m1,nsample) is returned as a fourth value."""
+    index tensor (B,m1,nsample) is returned as a fourth value.
+    knn=(points (B,nq,3), k, k2): also knn_indices(k, points, xyz, k2) -- appended to the result as one more value, the pair
+    (idx (B,nq,k), idx2 (B,nq,k2) | None) -- in the launch of the first sampling level when the kernels cover the sizes
+    (include/pn2_ext.h: pn2x_fps_radii_knn), as its own launch otherwise."""
     from . import pointnet2_utils as ops
     B, N, _ = xyz.shape
     if not 1 <= m2 <= m1:
         raise ValueError("fps_two_level: need 1 <= m2 <= m1")
     xyz = xyz.contiguous()
+
+    def knn_alone():
+        r = knn_indices(knn[1], knn[0], xyz, k2=knn[2])
+        return r if knn[2] else (r, None)
     if m2 > 1024 or N > 16384:  # beyond the shortcut's kernels: two plain passes
         i1 = ops.furthest_point_sample(xyz, m1)
         l1 = gather_rows(xyz, i1)
         i2 = ops.furthest_point_sample(l1, m2)
-        return (i1, l1, i2) if query is None else (i1, l1, i2, ops.ball_query(query[0], query[1], xyz, l1))
+        res = (i1, l1, i2) if query is None else (i1, l1, i2, ops.ball_query(query[0], query[1], xyz, l1))
+        return res if knn is None else res + (knn_alone(),)
     px = _native._ptr(xyz, "xyz", torch.float32, B * N * 3)
     nf = _lib.pn2x_fps_prefix_flags(N)
     i1 = torch.empty((B, m1), dtype=torch.int32, device=xyz.device)
@@ -498,8 +514,19 @@ def fps_two_level(xyz: torch.Tensor, m1: int, m2: int, query=None):
     i2 = torch.empty((B, m2), dtype=torch.int32, device=xyz.device)
     with torch.cuda.device(xyz.device):
         st = _native._stream(xyz)
-        _native._check(_native._call(_lib.pn2x_furthest_point_sampling_radii, "fps_kernel", None, B, N, m1, px, i1.data_ptr(),
-                                     radii.data_ptr(), st), "fps_two_level/1")
+        lists = None
+        if knn is not None and FPS_KNN_COLAUNCH and _lib.pn2x_fps_radii_knn_supported(N, knn[0].shape[1], knn[1]):
+            pts, k, k2 = knn
+            nq = pts.shape[1]
+            gi = torch.empty((B, nq, k), dtype=torch.int32, device=xyz.device)
+            gi2 = torch.empty((B, nq, k2), dtype=torch.int32, device=xyz.device) if k2 else None
+            _native._check(_native._call(_lib.pn2x_fps_radii_knn, "fps_knn_kernel", None, B, N, m1, px, i1.data_ptr(), radii.data_ptr(),
+                                         nq, k, k2, _native._ptr(pts, "knn points", torch.float32, B * nq * 3), gi.data_ptr(),
+                                         None if gi2 is None else gi2.data_ptr(), st), "fps_two_level/1+knn")
+            lists = (gi, gi2)
+        else:
+            _native._check(_native._call(_lib.pn2x_furthest_point_sampling_radii, "fps_kernel", None, B, N, m1, px, i1.data_ptr(),
+                                         radii.data_ptr(), st), "fps_two_level/1")
         if query is None:
             l1 = gather_rows(xyz, i1)
         else:
@@ -507,7 +534,10 @@ def fps_two_level(xyz: torch.Tensor, m1: int, m2: int, query=None):
         _native._check(_lib.pn2x_fps_prefix_ties(B, N, m1, m2, px, i1.data_ptr(), radii.data_ptr(), flags.data_ptr(), st), "fps_two_level/ties")
         _native._check(_native._call(_lib.pn2x_furthest_point_sampling_prefix, "fps_prefix_kernel", None, B, m1, m2, l1.data_ptr(),
                                      flags.data_ptr(), nf, i2.data_ptr(), st), "fps_two_level/2")
-    return (i1, l1, i2) if query is None else (i1, l1, i2, idx1)
+    res = (i1, l1, i2) if query is None else (i1, l1, i2, idx1)
+    if knn is None:
+        return res
+    return res + (lists if lists is not None else knn_alone(),)
 
 
 _lib.pn2x_hand_losses.argtypes = [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp]

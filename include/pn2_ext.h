@@ -132,6 +132,17 @@ int pn2x_three_interpolate_pm(int b, int c, int m, int n, const float *points, i
  * They cover m2 <= 1024 and the register-resident sampling kernels (n <= 16384 points after padding).
  */
 int pn2x_furthest_point_sampling_radii(int b, int n, int m, const float *xyz, int *idx, float *radii, void *stream);
+/*
+ * pn2x_fps_radii_knn: pn2x_furthest_point_sampling_radii AND pn2x_knn_indices (the nq query points per cloud `query` (b,nq,3) among
+ * the same xyz; knn_idx (b,nq,k) sorted by (distance, index), knn_idx2 (b,nq,k2) its prefix when k2 > 0) in ONE launch: the first b
+ * workgroups sample, the others search.  The sampling is a serial chain on one compute unit per cloud (pointnet_utils.py:368 ->
+ * sampling_gpu.cu:94-209); the keypoints' neighbour lists (pointnet_utils.py:551-556) need nothing but the coordinates, so at small
+ * batch (the tracking loop, track_network.py:159-217) they ride along instead of costing 21 us + a launch of their own.
+ * Same results as the two calls.  PN2_ERANGE unless pn2x_fps_radii_knn_supported(n, nq, k): 512 < padded n <= 1024.
+ */
+int pn2x_fps_radii_knn_supported(int n, int nq, int k);
+int pn2x_fps_radii_knn(int b, int n, int m, const float *xyz, int *idx, float *radii, int nq, int k, int k2, const float *query,
+                       int *knn_idx, int *knn_idx2, void *stream);
 int pn2x_fps_prefix_ties(int b, int n, int m1, int m2, const float *xyz, const int *idx1, const float *radii, int *flags, void *stream);
 int pn2x_fps_prefix_flags(int n);
 int pn2x_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz, const int *flags, int nflags, int *idx, void *stream);

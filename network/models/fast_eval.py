@@ -262,8 +262,13 @@ class FastEval:
         if self.two_level_fps:
             # sampling level 1 -> ball query level 1 (which also emits the centroids' coordinates) -> tie check ->
             # sampling level 2 (a no-op launch unless an arg-max tied): no gather launches
-            _, l1_xyz, i_l2, idx1 = ext.fps_two_level(xyz2, S1, bh.sa2.npoint, query=(bh.sa1.radius_list[0], K1))
+            # ... and the keypoints' kNN lists (sorted by (distance, index): the K = 16 list is the prefix of the K = 64 list) ride
+            # in the launch of sampling level 1, which keeps one compute unit per cloud busy and nothing else
+            qK = [P["q"][("q1", i)]["K"] for i in range(2)]
+            knn_req = (xyz1, max(qK), min(qK) if min(qK) < max(qK) else 0)
+            _, l1_xyz, i_l2, idx1, knn_lists = ext.fps_two_level(xyz2, S1, bh.sa2.npoint, query=(bh.sa1.radius_list[0], K1), knn=knn_req)
         else:
+            knn_lists = None
             l1_xyz = ext.gather_rows(xyz2, ops.furthest_point_sample(xyz2, S1))
             i_l2 = ops.furthest_point_sample(l1_xyz, bh.sa2.npoint)
             idx1 = ops.ball_query(bh.sa1.radius_list[0], K1, xyz2, l1_xyz)
@@ -326,7 +331,10 @@ class FastEval:
         # kNN lists are sorted by (distance, index): the K=16 list is the prefix of the K=64 list -> one search
         Ks = [q[("q1", i)]["K"] for i in range(2)]
         kmin, kmax = min(Ks), max(Ks)
-        gi, gi_small = ext.knn_indices(kmax, xyz1, xyz2, k2=kmin) if kmin < kmax else (ext.knn_indices(kmax, xyz1, xyz2), None)
+        if knn_lists is not None:
+            gi, gi_small = knn_lists
+        else:
+            gi, gi_small = ext.knn_indices(kmax, xyz1, xyz2, k2=kmin) if kmin < kmax else (ext.knn_indices(kmax, xyz1, xyz2), None)
         c_q = q[("q1", 0)]["l3"][0].shape[0]
         c1q = q[("q1", 0)]["l2"][0].shape[1]
         src3 = src2.view(B, N, C)

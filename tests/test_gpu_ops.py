@@ -302,6 +302,44 @@ def test_ball_query_picks_matches_gather_then_query():
     assert torch.equal(idx1, ops.ball_query(0.1, 32, d, l1)) and torch.equal(l1, ext.gather_rows(d, i1))
 
 
+def test_fps_knn_colaunch_equals_separate_launches(monkeypatch):
+    """pn2x_fps_radii_knn: sampling level 1 and the keypoints' k-NN lists in one launch == the two launches, index for index
+    (uniform / hand / lattice / duplicated clouds, ragged query counts, k2 = 0, the oracle's lists), and the entry is really
+    the one that ran for the covered sizes."""
+    from _cases import cloud
+    from hotrack_amd import ext, pointnet2_utils as ops
+    from oracle import pn2_oracle as O
+    used = []
+    real = ext._lib.pn2x_fps_radii_knn
+    assert ext.FPS_KNN_COLAUNCH
+    g = torch.Generator().manual_seed(5)
+    cases = [(1, 1024, 256, 128, 21, 64, 16, "hand"), (8, 1024, 256, 128, 21, 64, 16, "uniform"), (64, 1024, 256, 128, 21, 64, 16, "hand"),
+             (3, 1000, 256, 128, 21, 64, 16, "uniform"), (2, 600, 100, 50, 5, 16, 0, "uniform"), (2, 1024, 256, 128, 3, 200, 7, "lattice"),
+             (2, 1024, 256, 128, 9, 64, 64, "dup"), (2, 513, 64, 64, 1, 1, 0, "uniform"),
+             (2, 512, 128, 64, 21, 64, 16, "uniform"), (2, 2560, 512, 128, 21, 64, 16, "uniform")]  # last two: not covered -> own launch
+    for seed, (B, N, m1, m2, nq, k, k2, kind) in enumerate(cases):
+        xyz = cloud(6000 + seed, B, N, kind)
+        d = torch.from_numpy(xyz).cuda()
+        q = (torch.rand(B, nq, 3, generator=g) * 0.4 - 0.2).cuda()
+        if kind == "dup":
+            q[:, 0] = d[:, 0]  # a query ON a (duplicated) point: zero distances, index order decides
+        i1, l1, i2, idx1, (gi, gi2) = ext.fps_two_level(d, m1, m2, query=(0.1, 32), knn=(q, k, k2))
+        monkeypatch.setattr(ext, "FPS_KNN_COLAUNCH", False)
+        r1, rl1, r2, ridx1, (rgi, rgi2) = ext.fps_two_level(d, m1, m2, query=(0.1, 32), knn=(q, k, k2))
+        monkeypatch.setattr(ext, "FPS_KNN_COLAUNCH", True)
+        assert torch.equal(i1, r1) and torch.equal(l1, rl1) and torch.equal(i2, r2) and torch.equal(idx1, ridx1), (seed, kind)
+        assert torch.equal(gi, rgi) and torch.equal(gi, ops.knn(k, q, d)[1]), (seed, kind)
+        assert (gi2 is None and rgi2 is None and k2 == 0) or torch.equal(gi2, gi[:, :, :k2].contiguous())
+        assert np.array_equal(i1.cpu().numpy(), O.furthest_point_sample(xyz, m1))
+        if B * nq * N <= 200000:
+            assert np.array_equal(gi.cpu().numpy(), O.knn(k, q.cpu().numpy(), xyz)[1])
+        used.append(bool(ext._lib.pn2x_fps_radii_knn_supported(N, nq, k)))
+    assert used == [True] * 8 + [False] * 2
+    assert real(1, 1024, 4, None, None, None, 21, 64, 16, None, None, None, None) == -2      # NULL pointers
+    assert real(1, 1024, 4, None, None, None, 21, 16, 64, None, None, None, None) == -1      # k2 > k
+    assert real(0, 1024, 4, None, None, None, 21, 64, 16, None, None, None, None) == 0       # empty batch
+
+
 def test_knn_indices_prefix_output():
     from hotrack_amd import ext, pointnet2_utils as ops
     g = torch.Generator().manual_seed(21)
