@@ -13,6 +13,9 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
                  const int *skip_flags, int nflags, float *radii);
 int fps_tie_check(int b, int n, int m, int m1, const float *xyz, const int *idx, const float *radii, int *flags, hipStream_t st);
 bool fps_knn_supported(int n, int nq, int k);
+bool three_nn_interp_supported(long b, long n, long m, long c, long ldp, long ldo);
+int three_nn_interp_dispatch(int b, int n, int m, int c, const float *unknown, const float *known, const float *points, int ldp,
+                             float *out, int ldo, hipStream_t st);
 int fps_knn_dispatch(int b, int n, int m, const float *xyz, int *idx, float *radii, int nq, int k, int k2, const float *query,
                      int *kidx, int *kidx2, hipStream_t st);
 int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
@@ -237,6 +240,19 @@ int pn2x_three_nn_weights(int b, int n, int m, const float *unknown, const float
     PN2_REQ(unknown && known && weight && idx, PN2_ENULL);
     PN2_REQ(b <= 65535 && fits_int((long)n * 3) && fits_int((long)m * 3), PN2_ERANGE);
     return three_nn_dispatch(b, n, m, unknown, known, weight, idx, (hipStream_t)stream, true);
+}
+
+int pn2x_three_nn_interpolate_pm_supported(int b, int n, int m, int c, int ldp, int ldo) {
+    return three_nn_interp_supported(b, n, m, c, ldp, ldo) ? 1 : 0;
+}
+
+int pn2x_three_nn_interpolate_pm(int b, int n, int m, int c, const float *unknown, const float *known, const float *points, int ldp,
+                                 float *out, int ldo, void *stream) {
+    PN2_REQ(b >= 0 && n >= 0 && m >= 3 && c >= 1 && ldp >= c && ldo >= c, PN2_EINVAL);
+    if (b == 0 || n == 0) return PN2_OK;
+    PN2_REQ(unknown && known && points && out, PN2_ENULL);
+    PN2_REQ(b <= 65535 && fits_int((long)n * 3) && fits_int((long)m * 3), PN2_ERANGE);
+    return three_nn_interp_dispatch(b, n, m, c, unknown, known, points, ldp, out, ldo, (hipStream_t)stream);
 }
 
 int pn2x_three_interpolate_pm(int b, int c, int m, int n, const float *points, int ldp, const int *idx,

@@ -143,6 +143,95 @@ three_nn_split_kernel(int n, int m, const float *__restrict__ unknown_all, const
     oi[0] = i1; oi[1] = i2; oi[2] = i3;
 }
 
+// pn2x_three_nn_interpolate_pm: the search above (weights form) AND the interpolation of the feature rows it selects, in one
+// launch.  Feature propagation needs (weight, index) for nothing else (pointnet_utils.py:440-453), so they stay in LDS: wave 0
+// finishes the 64 queries of the workgroup, then all four waves blend the three source rows of each query, 16 bytes per lane --
+// the same fma order as interp_pm_kernel (interpolate.hip), hence the same floats as the two launches.
+__global__ void __launch_bounds__(256)
+three_nn_interp_kernel(int n, int m, int c4, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
+                       const float *__restrict__ points_all, int ldp, float *__restrict__ out_all, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) float4 sk[];
+    __shared__ float sd[3][3][64];
+    __shared__ int si[3][3][64];
+    __shared__ float fw[3][64];
+    __shared__ int fi[3][64];
+    const int b = blockIdx.y;
+    const float *__restrict__ known = known_all + (size_t)b * m * 3;
+    const int ql = threadIdx.x & 63, c = threadIdx.x >> 6;  // c is wave-uniform
+    const int q = blockIdx.x * 64 + ql;
+    const bool active = q < n;
+    const float *__restrict__ u = unknown_all + ((size_t)b * n + (active ? q : 0)) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    for (int p = threadIdx.x; p < m; p += 256) {
+        const float *src = known + (size_t)3 * p;
+        sk[p] = make_float4(src[0], src[1], src[2], 0.f);
+    }
+    __syncthreads();
+    float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
+    int i1 = 0, i2 = 0, i3 = 0;
+    auto insert = [&](float d, int k) {
+        const bool lt1 = d < b1, lt2 = d < b2, lt3 = d < b3;  // strict: ties keep the lower index
+        b3 = lt2 ? b2 : (lt3 ? d : b3);
+        i3 = lt2 ? i2 : (lt3 ? k : i3);
+        b2 = lt1 ? b1 : (lt2 ? d : b2);
+        i2 = lt1 ? i1 : (lt2 ? k : i2);
+        b1 = lt1 ? d : b1;
+        i1 = lt1 ? k : i1;
+    };
+    const int len = (m + 3) / 4, p0 = c * len, p1 = min(m, p0 + len);
+#pragma unroll 4
+    for (int p = p0; p < p1; ++p) {
+        const float4 kp = sk[p];  // wave-uniform address -> LDS broadcast
+        insert(sqdist(ux, uy, uz, kp.x, kp.y, kp.z), p);
+    }
+    if (c > 0) {
+        sd[c - 1][0][ql] = b1; sd[c - 1][1][ql] = b2; sd[c - 1][2][ql] = b3;
+        si[c - 1][0][ql] = i1; si[c - 1][1][ql] = i2; si[c - 1][2][ql] = i3;
+    }
+    __syncthreads();
+    if (c == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) insert(sd[cc][e][ql], si[cc][e][ql]);  // +inf placeholders never insert
+        const float r1 = 1.0f / (__builtin_sqrtf(b1) + 1e-8f), r2 = 1.0f / (__builtin_sqrtf(b2) + 1e-8f),
+                    r3 = 1.0f / (__builtin_sqrtf(b3) + 1e-8f);
+        const float norm = (r1 + r2) + r3;  // torch.sum over 3 elements adds left to right
+        fw[0][ql] = r1 / norm; fw[1][ql] = r2 / norm; fw[2][ql] = r3 / norm;
+        fi[0][ql] = i1; fi[1][ql] = i2; fi[2][ql] = i3;
+    }
+    __syncthreads();
+    const int rows = min(64, n - (int)blockIdx.x * 64);
+    const float *__restrict__ src = points_all + (size_t)b * m * ldp;
+    float *__restrict__ dst = out_all + ((size_t)b * n + (size_t)blockIdx.x * 64) * ldo;
+    for (int e = threadIdx.x; e < rows * c4; e += 256) {
+        const int r = e / c4, col = e - r * c4;
+        const float w0 = fw[0][r], w1 = fw[1][r], w2 = fw[2][r];
+        const float4 a0 = *reinterpret_cast<const float4 *>(src + (size_t)fi[0][r] * ldp + 4 * col);
+        const float4 a1 = *reinterpret_cast<const float4 *>(src + (size_t)fi[1][r] * ldp + 4 * col);
+        const float4 a2 = *reinterpret_cast<const float4 *>(src + (size_t)fi[2][r] * ldp + 4 * col);
+        float4 o;
+        o.x = __builtin_fmaf(w2, a2.x, __builtin_fmaf(w0, a0.x, w1 * a1.x));
+        o.y = __builtin_fmaf(w2, a2.y, __builtin_fmaf(w0, a0.y, w1 * a1.y));
+        o.z = __builtin_fmaf(w2, a2.z, __builtin_fmaf(w0, a0.z, w1 * a1.z));
+        o.w = __builtin_fmaf(w2, a2.w, __builtin_fmaf(w0, a0.w, w1 * a1.w));
+        *reinterpret_cast<float4 *>(dst + (size_t)r * ldo + 4 * col) = o;
+    }
+}
+
+bool three_nn_interp_supported(long b, long n, long m, long c, long ldp, long ldo) {
+    return b * n < 256L * 1024 && m >= 16 && m <= kNnTile && c >= 4 && c % 4 == 0 && ldp % 4 == 0 && ldo % 4 == 0;
+}
+
+int three_nn_interp_dispatch(int b, int n, int m, int c, const float *unknown, const float *known, const float *points, int ldp,
+                             float *out, int ldo, hipStream_t st) {
+    if (b == 0 || n == 0) return PN2_OK;
+    if (!three_nn_interp_supported(b, n, m, c, ldp, ldo) || (((uintptr_t)points | (uintptr_t)out) % 16) != 0) return PN2_ERANGE;
+    dim3 grid((n + 63) / 64, b);
+    hipLaunchKernelGGL(three_nn_interp_kernel, grid, dim3(256), (size_t)m * sizeof(float4), st, n, m, c / 4, unknown, known, points, ldp, out, ldo);
+    return check_launch();
+}
+
 int three_nn_dispatch(int b, int n, int m, const float *unknown, const float *known, float *dist2,
                       int *idx, hipStream_t st, bool weights) {
     if (b == 0 || n == 0) return PN2_OK;

@@ -255,6 +255,31 @@ def three_interpolate_pm(points: torch.Tensor, idx: torch.Tensor, weight: torch.
     return out
 
 
+_lib.pn2x_three_nn_interpolate_pm.argtypes = [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp]
+_lib.pn2x_three_nn_interpolate_pm.restype = _ci
+_lib.pn2x_three_nn_interpolate_pm_supported.argtypes = [_ci] * 6
+_lib.pn2x_three_nn_interpolate_pm_supported.restype = _ci
+NN_INTERP_FUSED = os.environ.get("HOTRACK_NN_INTERP_FUSED", "1") != "0"
+
+
+def three_nn_interpolate_pm(unknown: torch.Tensor, known: torch.Tensor, points: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out (B,n,C) rows <- three_interpolate_pm(points, *three_nn_weights(unknown, known)[::-1]) -- one launch when the sizes are
+    covered (include/pn2_ext.h: pn2x_three_nn_interpolate_pm), the two launches otherwise; same floats either way."""
+    B, n, _ = unknown.shape
+    m, C = known.shape[1], points.shape[2]
+    pp, ldp = _rows(points, "points", C)
+    po, ldo = _rows(out, "out", C)
+    f32 = torch.float32
+    if (NN_INTERP_FUSED and _lib.pn2x_three_nn_interpolate_pm_supported(B, n, m, C, ldp, ldo) and pp % 16 == 0 and po % 16 == 0):
+        with torch.cuda.device(points.device):
+            _native._check(_native._call(_lib.pn2x_three_nn_interpolate_pm, "three_nn_interp_kernel", None, B, n, m, C,
+                                         _native._ptr(unknown, "unknown", f32, B * n * 3), _native._ptr(known, "known", f32, B * m * 3),
+                                         pp, ldp, po, ldo, _native._stream(points)), "three_nn_interpolate_pm")
+        return out
+    w, i3 = three_nn_weights(unknown, known)
+    return three_interpolate_pm(points, i3, w, out)
+
+
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """src (B,N,C) contiguous, idx (B,M) int32 -> (B,M,C)."""
     B, N, C = src.shape

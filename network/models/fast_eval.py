@@ -305,8 +305,7 @@ class FastEval:
         l2_out = x.view(B, S2, -1)
 
         # ---- fp2: interpolate l2 -> l1, [l1_feat | interp] -> MLP ---------------------------------------
-        w, i3 = ext.three_nn_weights(l1_xyz, l2_xyz)
-        ext.three_interpolate_pm(l2_out, i3, w, fp2_in[:, :, c_l1:])
+        ext.three_nn_interpolate_pm(l1_xyz, l2_xyz, l2_out, fp2_in[:, :, c_l1:])  # search + blend: one launch
         x = fp2_in.view(B * S1, fp2_w)
         for W, b in P["fp2"]:
             x = _lin_relu(x, W, b)
@@ -314,8 +313,7 @@ class FastEval:
 
         # ---- fp1: interpolate l1 -> l0, [interp | xyz] (weights permuted to match) -> MLP; conv1 ----------
         assert c_i == l1_out.shape[2]
-        w, i3 = ext.three_nn_weights(xyz2, l1_xyz)
-        ext.three_interpolate_pm(l1_out, i3, w, fp1_in[:, :, :c_i])
+        ext.three_nn_interpolate_pm(xyz2, l1_xyz, l1_out, fp1_in[:, :, :c_i])
         f = P["fp1_fused"]
         if f is not None:  # both fp1 layers in one launch (pn2x_mlp2_rows): rows [interp | xyz | pad] -> 128 -> 128
             x = ext.mlp2_rows(fp1_in.view(B * N, c_i + 4), f["w2"], f["b2"], f["w3"], f["b3"], w2e=f["w2e"])

@@ -340,6 +340,34 @@ def test_fps_knn_colaunch_equals_separate_launches(monkeypatch):
     assert real(0, 1024, 4, None, None, None, 21, 64, 16, None, None, None, None) == 0       # empty batch
 
 
+def test_three_nn_interpolate_one_launch_equals_two(monkeypatch):
+    """pn2x_three_nn_interpolate_pm == pn2x_three_nn_weights + pn2x_three_interpolate_pm, bit for bit (ragged query counts, known sets
+    that do not divide by four, lattice ties, column blocks of wider buffers untouched outside), incl. the sizes it hands back."""
+    from _cases import cloud
+    from hotrack_amd import ext
+    g = torch.Generator().manual_seed(8)
+    fused = []
+    cases = [(1, 1024, 256, 128, 132, 0, "hand"), (64, 256, 128, 256, 320, 64, "hand"), (3, 1000, 100, 12, 16, 4, "uniform"),
+             (2, 343, 343, 64, 64, 0, "lattice"), (2, 70, 17, 4, 8, 0, "uniform"), (1, 1, 16, 8, 8, 0, "uniform"),
+             (2, 300, 8, 16, 16, 0, "uniform"), (1, 500, 3000, 8, 8, 0, "uniform"), (2, 64, 64, 6, 8, 0, "uniform")]  # last three: two launches
+    for seed, (B, n, m, C, ldo, col0, kind) in enumerate(cases):
+        known = torch.from_numpy(cloud(7000 + seed, B, m, kind)).cuda()
+        unknown = torch.from_numpy(cloud(7100 + seed, B, n, "lattice" if kind == "lattice" else "uniform")).cuda()
+        pts = torch.randn(B, m, C, generator=g).cuda()
+        buf_a, buf_b = torch.full((B, n, ldo), 5.0).cuda(), torch.full((B, n, ldo), 5.0).cuda()
+        a = ext.three_nn_interpolate_pm(unknown, known, pts, buf_a[:, :, col0:col0 + C])
+        w, i3 = ext.three_nn_weights(unknown, known)
+        b = ext.three_interpolate_pm(pts, i3, w, buf_b[:, :, col0:col0 + C])
+        assert torch.equal(buf_a, buf_b), (seed, float((a - b).abs().max()))
+        assert float((buf_a[:, :, :col0] - 5.0).abs().max() if col0 else 0.0) == 0.0
+        fused.append(bool(ext._lib.pn2x_three_nn_interpolate_pm_supported(B, n, m, C, C, ldo)))
+    assert fused == [True] * 6 + [False] * 3
+    real = ext._lib.pn2x_three_nn_interpolate_pm
+    assert real(1, 8, 2, 4, None, None, None, 4, None, 4, None) == -1     # fewer than three known points
+    assert real(1, 8, 16, 4, None, None, None, 4, None, 4, None) == -2    # NULL pointers
+    assert real(0, 8, 16, 4, None, None, None, 4, None, 4, None) == 0
+
+
 def test_knn_indices_prefix_output():
     from hotrack_amd import ext, pointnet2_utils as ops
     g = torch.Generator().manual_seed(21)
