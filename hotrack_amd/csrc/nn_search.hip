@@ -219,8 +219,10 @@ three_nn_interp_kernel(int n, int m, int c4, const float *__restrict__ unknown_a
     }
 }
 
+// From 16384 queries up: below that the blend of a workgroup's 64 rows by its own four waves is a longer chain than the
+// many-workgroup interpolation launch it replaces (B = 1 tracking step, same box: 0.3965 ms with, 0.3931 ms without).
 bool three_nn_interp_supported(long b, long n, long m, long c, long ldp, long ldo) {
-    return b * n < 256L * 1024 && m >= 16 && m <= kNnTile && c >= 4 && c % 4 == 0 && ldp % 4 == 0 && ldo % 4 == 0;
+    return b * n >= 16384 && b * n < 256L * 1024 && m >= 16 && m <= kNnTile && c >= 4 && c % 4 == 0 && ldp % 4 == 0 && ldo % 4 == 0;
 }
 
 int three_nn_interp_dispatch(int b, int n, int m, int c, const float *unknown, const float *known, const float *points, int ldp,

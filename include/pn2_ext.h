@@ -112,7 +112,7 @@ int pn2x_three_nn_weights(int b, int n, int m, const float *unknown, const float
  * pn2x_three_nn_interpolate_pm: pn2x_three_nn_weights followed by pn2x_three_interpolate_pm in ONE launch, for callers that need
  * the (weight, index) pair for nothing else (the forward of feature propagation, pointnet_utils.py:440-453): out (b, n, ldo) rows
  * <- the inverse-distance blend of the three nearest `known` (b,m,3) points' rows of `points` (b, m, ldp), c columns.  Same floats
- * as the two calls.  PN2_ERANGE unless pn2x_three_nn_interpolate_pm_supported (b n < 2^18 queries, 16 <= m <= 2048 known points in
+ * as the two calls.  PN2_ERANGE unless pn2x_three_nn_interpolate_pm_supported (2^14 <= b n < 2^18 queries, 16 <= m <= 2048 known points in
  * one LDS tile, c / ldp / ldo multiples of 4, points / out 16-byte aligned): the caller then runs the two launches.
  */
 int pn2x_three_nn_interpolate_pm_supported(int b, int n, int m, int c, int ldp, int ldo);

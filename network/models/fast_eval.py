@@ -179,7 +179,10 @@ class FastEval:
         """Cache of the per-scale layer-1 feature weights [q1 scale i | q2 scale i] (lives in P: rebuilt with the parameters)."""
         c = self.P.setdefault("_wcat", {})
         if i not in c:
-            c[i] = torch.cat([self.P["wq"][i], self.P["wq"][2 + i]], dim=0).contiguous()
+            if isinstance(i, tuple):  # several scales stacked (one GEMM over the points for all of them)
+                c[i] = torch.cat([self._wcat(j) for j in i], dim=0).contiguous()
+            else:
+                c[i] = torch.cat([self.P["wq"][i], self.P["wq"][2 + i]], dim=0).contiguous()
         return c[i]
 
     def _perm_idx(self, perm, B):
@@ -338,16 +341,26 @@ class FastEval:
         src3 = src2.view(B, N, C)
         # per scale i: neighbour index, feature rows the layer-1 GEMM runs over, the coordinates that go with them
         plan = []
+        # few slots and a batch large enough that the GEMM, not the launch count, is what costs (measured: pays from B ~ 32)
+        gathered = [J * K * 2 <= N and B * N >= 32768 for K in Ks]
+        over_points = [i for i, gth in enumerate(gathered) if not gth]
+        a_all = None
+        if len(over_points) > 1:  # small batch: the scales' per-point GEMMs read the same rows -> one GEMM, column blocks per scale
+            a_all = _lin(src2, self._wcat(tuple(over_points))).view(B, N, -1)
         for i, K in enumerate(Ks):
             W = self._wcat(i)  # (2*c1q, C): layer-1 feature weights of q1 | q2 at this scale
-            # few slots and a batch large enough that the GEMM, not the launch count, is what costs (measured: pays from B ~ 32)
-            if J * K * 2 <= N and B * N >= 32768:  # gather the J*K feature rows, then the GEMM (slot-major rows, identity index)
+            if gathered[i]:  # gather the J*K feature rows, then the GEMM (slot-major rows, identity index)
                 flat = (gi_small if K == kmin and gi_small is not None else gi[:, :, :K].contiguous()).view(B, J * K)
                 a = _lin(ext.gather_rows(src3, flat).view(B * J * K, C), W).view(B, J * K, -1)
                 plan.append((self._ident(B, J, K, dev), a, ext.gather_rows(xyz2, flat)))
             else:
                 idx = gi if K == kmax else (gi_small if K == kmin and gi_small is not None else gi[:, :, :K].contiguous())
-                plan.append((idx, _lin(src2, W).view(B, N, -1), xyz2))
+                if a_all is not None:
+                    j = over_points.index(i)
+                    a = a_all[:, :, j * W.shape[0]:(j + 1) * W.shape[0]]
+                else:
+                    a = _lin(src2, W).view(B, N, -1)
+                plan.append((idx, a, xyz2))
         f11 = torch.empty((B, J, 2 * c_q), **f32)
         self._q_scales(ext, "q1", plan, q, xyz1, c1q, 0, None, f11, c_q)
         Wr, br, perm = P["r1"]

@@ -347,9 +347,10 @@ def test_three_nn_interpolate_one_launch_equals_two(monkeypatch):
     from hotrack_amd import ext
     g = torch.Generator().manual_seed(8)
     fused = []
-    cases = [(1, 1024, 256, 128, 132, 0, "hand"), (64, 256, 128, 256, 320, 64, "hand"), (3, 1000, 100, 12, 16, 4, "uniform"),
-             (2, 343, 343, 64, 64, 0, "lattice"), (2, 70, 17, 4, 8, 0, "uniform"), (1, 1, 16, 8, 8, 0, "uniform"),
-             (2, 300, 8, 16, 16, 0, "uniform"), (1, 500, 3000, 8, 8, 0, "uniform"), (2, 64, 64, 6, 8, 0, "uniform")]  # last three: two launches
+    cases = [(16, 1024, 256, 128, 132, 0, "hand"), (64, 256, 128, 256, 320, 64, "hand"), (17, 1000, 100, 12, 16, 4, "uniform"),
+             (48, 343, 343, 64, 64, 0, "lattice"), (300, 70, 17, 4, 8, 0, "uniform"), (1, 16384, 16, 8, 8, 0, "uniform"),
+             (1, 1024, 256, 128, 132, 0, "hand"), (60, 300, 8, 16, 16, 0, "uniform"), (40, 500, 3000, 8, 8, 0, "uniform"),
+             (300, 64, 64, 6, 8, 0, "uniform")]  # last four: two launches (few queries / tiny or huge known set / odd width)
     for seed, (B, n, m, C, ldo, col0, kind) in enumerate(cases):
         known = torch.from_numpy(cloud(7000 + seed, B, m, kind)).cuda()
         unknown = torch.from_numpy(cloud(7100 + seed, B, n, "lattice" if kind == "lattice" else "uniform")).cuda()
@@ -361,7 +362,7 @@ def test_three_nn_interpolate_one_launch_equals_two(monkeypatch):
         assert torch.equal(buf_a, buf_b), (seed, float((a - b).abs().max()))
         assert float((buf_a[:, :, :col0] - 5.0).abs().max() if col0 else 0.0) == 0.0
         fused.append(bool(ext._lib.pn2x_three_nn_interpolate_pm_supported(B, n, m, C, C, ldo)))
-    assert fused == [True] * 6 + [False] * 3
+    assert fused == [True] * 6 + [False] * 4
     real = ext._lib.pn2x_three_nn_interpolate_pm
     assert real(1, 8, 2, 4, None, None, None, 4, None, 4, None) == -1     # fewer than three known points
     assert real(1, 8, 16, 4, None, None, None, 4, None, 4, None) == -2    # NULL pointers
