@@ -10,6 +10,7 @@
 //   * every element of the output row is written (hits, then first-hit padding, or zeros),
 //     so the caller does not have to pre-zero idx (pointnet2_utils.py:262).
 #include "pn2_common.h"
+#include "fps_tie.h"
 
 namespace pn2 {
 
@@ -17,16 +18,17 @@ constexpr int kBqThreads = 256;
 constexpr int kBqWaves = kBqThreads / kWave;
 constexpr int kBqTile = 4096;  // points per LDS tile: 48 KiB -> 3 workgroups / CU
 
+// workgroup (bx, by) of a (ceil(m / (waves CPW)), b) grid
 template <int CPW, bool JOINT>  // centroids per wave; JOINT: they walk the candidates together (shared LDS reads, packed distances)
-__global__ void __launch_bounds__(kBqThreads)
-ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz_all,
-                  const float *__restrict__ xyz_all, int *__restrict__ idx_all, const int *__restrict__ picks_all,
-                  float *__restrict__ new_xyz_out_all, float *__restrict__ new_xyz_copy, int copy_ld) {
+__device__ __forceinline__ void ball_query_body(const int bx, const int by, int n, int m, float radius2, int nsample,
+                                                const float *__restrict__ new_xyz_all, const float *__restrict__ xyz_all,
+                                                int *__restrict__ idx_all, const int *__restrict__ picks_all,
+                                                float *__restrict__ new_xyz_out_all, float *__restrict__ new_xyz_copy, int copy_ld) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile_cap = n < kBqTile ? n : kBqTile;
     float *sx = smem, *sy = smem + tile_cap, *sz = smem + 2 * tile_cap;
 
-    const int b = blockIdx.y;
+    const int b = by;
     const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
     // centroids either given by coordinates (the reference operator) or as indices into this cloud (`picks`, the
     // output of FPS -- pn2x_ball_query_picks), in which case their coordinates are also written out: the gather
@@ -38,7 +40,7 @@ ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
-    const int c_base = blockIdx.x * (kBqWaves * CPW);
+    const int c_base = bx * (kBqWaves * CPW);
 
     float cx[CPW], cy[CPW], cz[CPW];
     int cnt[CPW], first[CPW];
@@ -147,6 +149,34 @@ ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restr
     }
 }
 
+template <int CPW, bool JOINT>
+__global__ void __launch_bounds__(kBqThreads)
+ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz_all,
+                  const float *__restrict__ xyz_all, int *__restrict__ idx_all, const int *__restrict__ picks_all,
+                  float *__restrict__ new_xyz_out_all, float *__restrict__ new_xyz_copy, int copy_ld) {
+    ball_query_body<CPW, JOINT>((int)blockIdx.x, (int)blockIdx.y, n, m, radius2, nsample, new_xyz_all, xyz_all, idx_all, picks_all,
+                                new_xyz_out_all, new_xyz_copy, copy_ld);
+}
+
+// The level-1 ball query around the picks of a sampling run AND that run's tie check (fps_tie.h) in one launch: both need the
+// picks and nothing of each other.  Workgroups [0, nb_ball) query, the rest check (pn2x_ball_query_picks_ties).
+template <int CPW>
+__global__ void __launch_bounds__(kBqThreads)
+ball_tie_kernel(int nbx_ball, int nb_ball, int nbx_tie, int n, int m, float radius2, int nsample, const float *__restrict__ xyz_all,
+                int *__restrict__ idx_all, const int *__restrict__ picks_all, float *__restrict__ new_xyz_out_all,
+                float *__restrict__ new_xyz_copy, int copy_ld, int m2, const float *__restrict__ radii_all, int *__restrict__ flags) {
+    const int L = (int)blockIdx.x;
+    if (L < nb_ball) {  // workgroup-uniform
+        const int by = L / nbx_ball;
+        // (new_xyz_all is unused with picks; a literal nullptr here crashes the inliner of this hipcc)
+        ball_query_body<CPW, false>(L - by * nbx_ball, by, n, m, radius2, nsample, xyz_all, xyz_all, idx_all, picks_all, new_xyz_out_all,
+                                    new_xyz_copy, copy_ld);
+    } else {
+        const int T = L - nb_ball, by = T / nbx_tie;
+        fps_tie_body(T - by * nbx_tie, by, nbx_tie, n, m2, m, xyz_all, picks_all, radii_all, flags);
+    }
+}
+
 int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                         const float *xyz, int *idx, hipStream_t st, const int *picks, float *new_xyz_out, float *new_xyz_copy,
                         int copy_ld) {
@@ -172,6 +202,28 @@ int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const fl
         hipLaunchKernelGGL((ball_query_kernel<2, false>), grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out, new_xyz_copy, copy_ld);
     else
         hipLaunchKernelGGL((ball_query_kernel<1, false>), grid, dim3(kBqThreads), lds, st, n, m, radius2, nsample, new_xyz, xyz, idx, picks, new_xyz_out, new_xyz_copy, copy_ld);
+    return check_launch();
+}
+
+// pn2x_ball_query_picks_ties: the co-launch above where it applies (the per-centroid scan variants, tie check within its pick limit)
+// Small batches only (the tracking loop): there the two launches are two links of a dependent chain of ~4 us launches; with
+// many clouds in flight the query workgroups do better without the check's 21 KB of static LDS (headline, same box: 88.5 k
+// frames/s with, 88.8 k without).
+bool ball_tie_supported(long b, long n, long m, long m2) {
+    return b >= 1 && m >= 1 && b * n <= 16384 && b * m < 2L * kBqWaves * 2048 && m2 >= 1 && m2 <= m && m2 <= kTieMaxM;
+}
+
+int ball_tie_dispatch(int b, int n, int m, float radius, int nsample, const float *xyz, int *idx, const int *picks, float *new_xyz_out,
+                      float *new_xyz_copy, int copy_ld, int m2, const float *radii, int *flags, hipStream_t st) {
+    if (!ball_tie_supported(b, n, m, m2)) return PN2_ERANGE;
+    const float radius2 = radius * radius;
+    const int tile_cap = n < kBqTile ? n : kBqTile;
+    const size_t lds = (size_t)3 * tile_cap * sizeof(float);
+    const int per_block = kBqWaves;  // one centroid per wave (what ball_query_dispatch picks at these sizes)
+    const int nbx_ball = (m + per_block - 1) / per_block, nbx_tie = (n + kTiePts - 1) / kTiePts;
+    const long grid = (long)b * nbx_ball + (long)b * nbx_tie;
+    hipLaunchKernelGGL(ball_tie_kernel<1>, dim3((unsigned)grid), dim3(kBqThreads), lds, st, nbx_ball, b * nbx_ball, nbx_tie, n, m, radius2, nsample,
+                       xyz, idx, picks, new_xyz_out, new_xyz_copy, copy_ld, m2, radii, flags);
     return check_launch();
 }
 

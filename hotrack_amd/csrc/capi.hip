@@ -13,6 +13,9 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
                  const int *skip_flags, int nflags, float *radii);
 int fps_tie_check(int b, int n, int m, int m1, const float *xyz, const int *idx, const float *radii, int *flags, hipStream_t st);
 bool fps_knn_supported(int n, int nq, int k);
+bool ball_tie_supported(long b, long n, long m, long m2);
+int ball_tie_dispatch(int b, int n, int m, float radius, int nsample, const float *xyz, int *idx, const int *picks, float *new_xyz_out,
+                      float *new_xyz_copy, int copy_ld, int m2, const float *radii, int *flags, hipStream_t st);
 bool three_nn_interp_supported(long b, long n, long m, long c, long ldp, long ldo);
 int three_nn_interp_dispatch(int b, int n, int m, int c, const float *unknown, const float *known, const float *points, int ldp,
                              float *out, int ldo, hipStream_t st);
@@ -155,6 +158,19 @@ int pn2x_ball_query_picks2(int b, int n, int m, float radius, int nsample, const
     PN2_REQ(b <= 65535, PN2_ERANGE);
     PN2_REQ(fits_int((long)n * 3) && fits_int((long)m * nsample), PN2_ERANGE);
     return ball_query_dispatch(b, n, m, radius, nsample, nullptr, xyz, idx, (hipStream_t)stream, picks, new_xyz, new_xyz_copy, copy_ld);
+}
+
+int pn2x_ball_query_picks_ties_supported(int b, int n, int m, int m2) { return ball_tie_supported(b, n, m, m2) ? 1 : 0; }
+
+int pn2x_ball_query_picks_ties(int b, int n, int m, float radius, int nsample, const float *xyz, const int *picks, float *new_xyz,
+                               int *idx, float *new_xyz_copy, int copy_ld, int m2, const float *radii, int *flags, void *stream) {
+    PN2_REQ(!new_xyz_copy || copy_ld >= 3, PN2_EINVAL);
+    PN2_REQ(b >= 0 && n >= 1 && m >= 1 && nsample >= 1 && m2 >= 1 && m2 <= m, PN2_EINVAL);
+    PN2_REQ(radius == radius, PN2_EINVAL);
+    if (b == 0) return PN2_OK;
+    PN2_REQ(xyz && picks && new_xyz && idx && radii && flags, PN2_ENULL);
+    PN2_REQ(b <= 65535 && fits_int((long)n * 3) && fits_int((long)m * nsample), PN2_ERANGE);
+    return ball_tie_dispatch(b, n, m, radius, nsample, xyz, idx, picks, new_xyz, new_xyz_copy, copy_ld, m2, radii, flags, (hipStream_t)stream);
 }
 
 int pn2_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,

@@ -16,6 +16,7 @@
 //     pull the winner's coordinates into SGPRs with v_readlane.
 #include "pn2_common.h"
 #include "knn_wave.h"
+#include "fps_tie.h"
 
 namespace pn2 {
 
@@ -281,62 +282,11 @@ static int launch_fps(int b, int n, int m, int bs, int lg, int Q, const float *x
     return check_launch();
 }
 
-// ---- were the first m picks of a finished FPS run unique arg-maxima?  (pn2x_fps_prefix_ties, pn2_ext.h) ----------------
-// With the picks known there is no dependency chain left: every point replays its own running minimum against the
-// picks in order (the same sqdist / min chain as the sampling kernel, hence the same floats) and compares it with
-// the value the sampling kernel recorded for that pick (radii[i] = the maximum it selected at step i).  A point other
-// than pick i that reaches radii[i] at step i means that arg-max was tied.  One workgroup per 256 points.
-constexpr int kTieMaxM = 1024;
-constexpr int kTieChunks = 4, kTiePts = 256 / kTieChunks;  // a workgroup = 64 points x 4 chunks of the pick sequence
-// The running minimum is a prefix-min, and min is associative: chunk c of the picks is replayed by its own thread
-// (wave c of the workgroup; pick reads are wave-uniform LDS broadcasts), first to get the chunk's total, then -- with
-// the minimum of the earlier chunks' totals as the starting value -- again with the comparison.  Two passes over a
-// quarter of the picks instead of one over all of them: the per-thread latency chain halves.
+// the post-hoc tie check (pn2x_fps_prefix_ties): fps_tie.h
 __global__ void __launch_bounds__(256)
 fps_tie_check_kernel(int n, int m, int m1, const float *__restrict__ xyz_all, const int *__restrict__ idx_all,
                      const float *__restrict__ radii_all, int *__restrict__ flags) {
-    __shared__ float4 pick[kTieMaxM];  // x, y, z of pick i, radius of pick i+1 (what a point is compared with after meeting pick i)
-    __shared__ int ck[kTieMaxM];
-    __shared__ float tot[kTieChunks][kTiePts];
-    __shared__ int tie_any;
-    const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.y * n * 3;
-    const int *__restrict__ idx = idx_all + (size_t)blockIdx.y * m1;
-    const float *__restrict__ radii = radii_all + (size_t)blockIdx.y * m1;
-    const int tid = threadIdx.x;
-    if (tid == 0) tie_any = 0;
-    for (int i = tid; i < m; i += 256) {
-        const int k = idx[i];
-        ck[i] = k;
-        pick[i] = make_float4(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2], i + 1 < m ? radii[i + 1] : -1.0f);
-    }
-    __syncthreads();
-    const int q = tid & (kTiePts - 1), c = tid / kTiePts;  // c is wave-uniform
-    const int k = blockIdx.x * kTiePts + q;
-    const int steps = m - 1;                                 // picks 0 .. m-2 are met, pick i is compared with radius i+1
-    const int len = (steps + kTieChunks - 1) / kTieChunks;
-    const int i0 = c * len, i1 = min(steps, i0 + len);
-    const bool live = k < n;
-    const float px = live ? xyz[3 * k] : 0.f, py = live ? xyz[3 * k + 1] : 0.f, pz = live ? xyz[3 * k + 2] : 0.f;
-    float d = 1e10f;
-#pragma unroll 8
-    for (int i = i0; i < i1; ++i) {
-        const float4 p = pick[i];
-        d = fmin_raw(sqdist(px, py, pz, p.x, p.y, p.z), d);
-    }
-    tot[c][q] = d;
-    __syncthreads();
-    d = 1e10f;
-    for (int cc = 0; cc < c; ++cc) d = fmin_raw(tot[cc][q], d);  // min is exact: any association gives the same float
-    bool tie = false;
-#pragma unroll 8
-    for (int i = i0; i < i1; ++i) {
-        const float4 p = pick[i];
-        d = fmin_raw(sqdist(px, py, pz, p.x, p.y, p.z), d);
-        if (d == p.w) tie |= live && (k != ck[i + 1]);  // rarely true: the pick itself, or a tie
-    }
-    if (__ballot(tie) != 0 && (tid & 63) == 0) tie_any = 1;
-    __syncthreads();
-    if (tid == 0) flags[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tie_any;
+    fps_tie_body((int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, n, m, m1, xyz_all, idx_all, radii_all, flags);
 }
 
 int fps_tie_check(int b, int n, int m, int m1, const float *xyz, const int *idx, const float *radii, int *flags, hipStream_t st) {

@@ -11,6 +11,9 @@ namespace pn2 {
 // re-normalised in fp64 with Newton steps (multiplies only): every applied rotation is orthogonal to ~1e-16, an
 // inexact angle merely leaves a tiny off-diagonal for the next sweep.  No fp64 divide / sqrt in the loop
 // (they made the first version of this kernel 20 us; this one is ~4 us).
+// FAST = false: the Jacobi sweep only (the loss kernel runs 1024 threads per workgroup: 128 registers per lane, the fast path's
+// extra live values would spill)
+template <bool FAST = true>
 __device__ void kabsch_solve(int num, const float *x, const float *y, int ystride, double (&R)[3][3], double (&t)[3]) {
     double cx[3] = {0, 0, 0}, cy[3] = {0, 0, 0};
     for (int p = 0; p < num; ++p)
@@ -35,11 +38,72 @@ __device__ void kabsch_solve(int num, const float *x, const float *y, int ystrid
     A[3][3] = -S[0][0] - S[1][1] + S[2][2];
     for (int r = 1; r < 4; ++r)
         for (int c = 0; c < r; ++c) A[r][c] = A[c][r];
+    double q0 = 1.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    // Fast path: the largest eigenvalue as the largest root of the characteristic polynomial (Newton from an upper bound: the
+    // polynomial is convex beyond its largest root, so the iteration descends monotonically onto it) and its eigenvector as a
+    // column of adj(N - lambda I) -- about 300 flops against the ~30 dependent rotations of the Jacobi sweep below (~12 us of the
+    // 18.6 us this launch takes at the head of every frame).  adj(N - lambda I) = prod_{k != max}(lambda_k - lambda) v v^T: when
+    // the top eigenvalue is not well separated (near-degenerate fits) its columns lose digits, and the Jacobi sweep takes over.
+    bool solved = false;
+    if constexpr (FAST) {
+        double gx = 0, gy = 0;
+        for (int p = 0; p < num; ++p)
+            for (int a = 0; a < 3; ++a) {
+                const double dx = (double)x[3 * p + a] - cx[a], dy = (double)y[(size_t)ystride * p + a] - cy[a];
+                gx += dx * dx;
+                gy += dy * dy;
+            }
+        double s2 = 0;
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) s2 += S[a][c] * S[a][c];
+        const double detS = S[0][0] * (S[1][1] * S[2][2] - S[1][2] * S[2][1]) - S[0][1] * (S[1][0] * S[2][2] - S[1][2] * S[2][0]) +
+                            S[0][2] * (S[1][0] * S[2][1] - S[1][1] * S[2][0]);
+        // 3x3 minors of a 4x4 matrix M: rows r0<r1<r2, columns c0<c1<c2
+        auto det3 = [](const double (&M)[4][4], int r0, int r1, int r2, int c0, int c1, int c2) {
+            return M[r0][c0] * (M[r1][c1] * M[r2][c2] - M[r1][c2] * M[r2][c1]) - M[r0][c1] * (M[r1][c0] * M[r2][c2] - M[r1][c2] * M[r2][c0]) +
+                   M[r0][c2] * (M[r1][c0] * M[r2][c1] - M[r1][c1] * M[r2][c0]);
+        };
+        const double C2 = -2.0 * s2, C1 = -8.0 * detS;
+        const double C0 = A[0][0] * det3(A, 1, 2, 3, 1, 2, 3) - A[0][1] * det3(A, 1, 2, 3, 0, 2, 3) + A[0][2] * det3(A, 1, 2, 3, 0, 1, 3) -
+                          A[0][3] * det3(A, 1, 2, 3, 0, 1, 2);
+        double lam = 0.5 * (gx + gy);  // >= the largest eigenvalue (Cauchy-Schwarz on the correlation)
+        bool conv = false;
+        for (int it = 0; it < 40 && lam > 0.0; ++it) {
+            const double l2 = lam * lam;
+            const double pv = (l2 + C2) * l2 + C1 * lam + C0, dp = (4.0 * l2 + 2.0 * C2) * lam + C1;
+            if (!(dp > 0.0)) break;
+            const double ln = lam - pv / dp;
+            conv = fabs(ln - lam) <= 1e-15 * fabs(ln);
+            lam = ln;
+            if (conv) break;
+        }
+        if (conv) {
+            double (&M)[4][4] = A;  // N - lambda I in place (the diagonal is put back for the Jacobi sweep if this path gives up)
+            const double d0 = A[0][0], d1 = A[1][1], d2 = A[2][2], d3 = A[3][3];
+            A[0][0] = d0 - lam; A[1][1] = d1 - lam; A[2][2] = d2 - lam; A[3][3] = d3 - lam;
+            double best = -1.0, v[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // column j of the adjugate = the cofactors of row j
+                const int r0 = j == 0 ? 1 : 0, r1 = j <= 1 ? 2 : 1, r2 = j <= 2 ? 3 : 2;
+                const double w0 = det3(M, r0, r1, r2, 1, 2, 3), w1 = -det3(M, r0, r1, r2, 0, 2, 3), w2 = det3(M, r0, r1, r2, 0, 1, 3),
+                             w3 = -det3(M, r0, r1, r2, 0, 1, 2);
+                const double sg = (j & 1) ? -1.0 : 1.0;
+                const double n2 = w0 * w0 + w1 * w1 + w2 * w2 + w3 * w3;
+                if (n2 > best) { best = n2; v[0] = sg * w0; v[1] = sg * w1; v[2] = sg * w2; v[3] = sg * w3; }
+            }
+            const double l3 = lam * lam * lam;
+            if (best > 1e-12 * l3 * l3) {  // product of the three eigenvalue gaps >~ 1e-6 lambda^3: the column carries >= 9 digits
+                q0 = v[0]; q1 = v[1]; q2 = v[2]; q3 = v[3];
+                solved = true;
+            }
+            A[0][0] = d0; A[1][1] = d1; A[2][2] = d2; A[3][3] = d3;
+        }
+    }
     double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
     double diag2 = 0;
     for (int p = 0; p < 4; ++p)
         for (int q = 0; q < 4; ++q) diag2 += A[p][q] * A[p][q];
-    for (int sweep = 0; sweep < 16; ++sweep) {
+    for (int sweep = 0; sweep < 16 && !solved; ++sweep) {
         double off = 0;
         for (int p = 0; p < 3; ++p)
             for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
@@ -78,10 +142,13 @@ __device__ void kabsch_solve(int num, const float *x, const float *y, int ystrid
                 }
             }
     }
-    double q0 = V[0][0], q1 = V[1][0], q2 = V[2][0], q3 = V[3][0], best = A[0][0];
+    if (!solved) {
+        double best = A[0][0];
+        q0 = V[0][0]; q1 = V[1][0]; q2 = V[2][0]; q3 = V[3][0];
 #pragma unroll
-    for (int k = 1; k < 4; ++k)
-        if (A[k][k] > best) { best = A[k][k]; q0 = V[0][k]; q1 = V[1][k]; q2 = V[2][k]; q3 = V[3][k]; }
+        for (int k = 1; k < 4; ++k)
+            if (A[k][k] > best) { best = A[k][k]; q0 = V[0][k]; q1 = V[1][k]; q2 = V[2][k]; q3 = V[3][k]; }
+    }
     const double nq = 1.0 / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
     q0 *= nq; q1 *= nq; q2 *= nq; q3 *= nq;
     R[0][0] = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3;
@@ -254,7 +321,7 @@ hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const flo
             float y[kHlPalm * 3];
             for (int e = 0; e < kHlPalm * 3; ++e) y[e] = yl[i][role][e];
             double R[3][3], t[3];
-            kabsch_solve(kHlPalm, palm + (size_t)(pb == 1 ? 0 : b) * kHlPalm * 3, y, 3, R, t);
+            kabsch_solve<false>(kHlPalm, palm + (size_t)(pb == 1 ? 0 : b) * kHlPalm * 3, y, 3, R, t);
             float *dst = saved + 87 * (size_t)b + (role == 0 ? 75 : 63);
             for (int a = 0; a < 3; ++a) {
                 for (int c = 0; c < 3; ++c) dst[3 * a + c] = fit[i][role][3 * a + c] = (float)R[a][c];

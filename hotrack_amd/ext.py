@@ -505,6 +505,11 @@ def ball_query_picks(radius: float, nsample: int, xyz: torch.Tensor, picks: torc
 
 
 FPS_KNN_COLAUNCH = os.environ.get("HOTRACK_FPS_KNN_COLAUNCH", "1") != "0"
+BALL_TIE_COLAUNCH = os.environ.get("HOTRACK_BALL_TIE_COLAUNCH", "1") != "0"
+_lib.pn2x_ball_query_picks_ties.argtypes = [_ci, _ci, _ci, ctypes.c_float, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp]
+_lib.pn2x_ball_query_picks_ties.restype = _ci
+_lib.pn2x_ball_query_picks_ties_supported.argtypes = [_ci] * 4
+_lib.pn2x_ball_query_picks_ties_supported.restype = _ci
 
 
 def fps_two_level(xyz: torch.Tensor, m1: int, m2: int, query=None, knn=None):
@@ -552,11 +557,19 @@ def fps_two_level(xyz: torch.Tensor, m1: int, m2: int, query=None, knn=None):
         else:
             _native._check(_native._call(_lib.pn2x_furthest_point_sampling_radii, "fps_kernel", None, B, N, m1, px, i1.data_ptr(),
                                          radii.data_ptr(), st), "fps_two_level/1")
-        if query is None:
-            l1 = gather_rows(xyz, i1)
+        if query is not None and BALL_TIE_COLAUNCH and _lib.pn2x_ball_query_picks_ties_supported(B, N, m1, m2):
+            # level 1's ball query and the tie check of the sampling run both start from the picks: one launch
+            idx1 = torch.empty((B, m1, query[1]), dtype=torch.int32, device=xyz.device)
+            l1 = torch.empty((B, m1, 3), dtype=torch.float32, device=xyz.device)
+            _native._check(_native._call(_lib.pn2x_ball_query_picks_ties, "ball_tie_kernel", None, B, N, m1, float(query[0]), query[1], px,
+                                         i1.data_ptr(), l1.data_ptr(), idx1.data_ptr(), None, 0, m2, radii.data_ptr(), flags.data_ptr(), st),
+                           "fps_two_level/query+ties")
         else:
-            idx1, l1 = ball_query_picks(query[0], query[1], xyz, i1)
-        _native._check(_lib.pn2x_fps_prefix_ties(B, N, m1, m2, px, i1.data_ptr(), radii.data_ptr(), flags.data_ptr(), st), "fps_two_level/ties")
+            if query is None:
+                l1 = gather_rows(xyz, i1)
+            else:
+                idx1, l1 = ball_query_picks(query[0], query[1], xyz, i1)
+            _native._check(_lib.pn2x_fps_prefix_ties(B, N, m1, m2, px, i1.data_ptr(), radii.data_ptr(), flags.data_ptr(), st), "fps_two_level/ties")
         _native._check(_native._call(_lib.pn2x_furthest_point_sampling_prefix, "fps_prefix_kernel", None, B, m1, m2, l1.data_ptr(),
                                      flags.data_ptr(), nf, i2.data_ptr(), st), "fps_two_level/2")
     res = (i1, l1, i2) if query is None else (i1, l1, i2, idx1)

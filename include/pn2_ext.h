@@ -154,6 +154,15 @@ int pn2x_fps_radii_knn_supported(int n, int nq, int k);
 int pn2x_fps_radii_knn(int b, int n, int m, const float *xyz, int *idx, float *radii, int nq, int k, int k2, const float *query,
                        int *knn_idx, int *knn_idx2, void *stream);
 int pn2x_fps_prefix_ties(int b, int n, int m1, int m2, const float *xyz, const int *idx1, const float *radii, int *flags, void *stream);
+/*
+ * pn2x_ball_query_picks_ties: pn2x_ball_query_picks2 (ball query around the picks (b, m) of a sampling run + their coordinates) AND
+ * pn2x_fps_prefix_ties (was an arg-max among the first m2 picks tied?  radii (b, m) from the sampling run, flags as above) in ONE
+ * launch -- both consume the picks and nothing of each other.  Same outputs as the two calls.  PN2_ERANGE unless
+ * pn2x_ball_query_picks_ties_supported(b, n, m, m2): small batches (b n <= 16384, the tracking loop), m2 <= 1024.
+ */
+int pn2x_ball_query_picks_ties_supported(int b, int n, int m, int m2);
+int pn2x_ball_query_picks_ties(int b, int n, int m, float radius, int nsample, const float *xyz, const int *picks, float *new_xyz,
+                               int *idx, float *new_xyz_copy, int copy_ld, int m2, const float *radii, int *flags, void *stream);
 int pn2x_fps_prefix_flags(int n);
 int pn2x_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz, const int *flags, int nflags, int *idx, void *stream);
 

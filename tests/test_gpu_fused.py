@@ -45,6 +45,43 @@ def test_kabsch_matches_svd(B, num, shared):
     assert torch.allclose(torch.det(R.cpu()), torch.ones(B), atol=1e-5)
 
 
+def test_kabsch_degenerate_and_ill_separated_fits():
+    """The fit's fast path (largest root of the characteristic polynomial + an adjugate column) hands ill-separated problems to the
+    Jacobi sweep: planar / collinear / coincident point sets, mirrored targets (the SVD's det fix-up case), near-symmetric sets, tiny
+    and huge scales.  Wherever the optimum is unique R must equal the fp64 SVD's; always R is a proper rotation and the residual the
+    optimum's."""
+    from hotrack_amd import ext
+    g = torch.Generator().manual_seed(77)
+    sets = []
+    x = torch.randn(6, 3, generator=g) * 0.05
+    planar = x.clone(); planar[:, 2] = 0
+    line = torch.linspace(-1, 1, 6).view(6, 1) * torch.tensor([[0.03, 0.01, -0.02]])
+    sets += [("generic", x, True), ("planar", planar, True), ("collinear", line, False), ("coincident", torch.zeros(6, 3) + 0.1, False),
+             ("tiny", x * 1e-4, True), ("huge", x * 1e3, True),
+             ("tetra", torch.tensor([[1., 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1], [1., 1, 1], [1, -1, -1]]) * 0.04, True)]
+    q = torch.randn(4, generator=g); q = q / q.norm()
+    w_, a, b_, c = q
+    Rgt = torch.tensor([[1 - 2 * (b_ * b_ + c * c), 2 * (a * b_ - c * w_), 2 * (a * c + b_ * w_)],
+                        [2 * (a * b_ + c * w_), 1 - 2 * (a * a + c * c), 2 * (b_ * c - a * w_)],
+                        [2 * (a * c - b_ * w_), 2 * (b_ * c + a * w_), 1 - 2 * (a * a + b_ * b_)]])
+    for name, xs, unique in sets:
+        for mirror in (False, True):
+            y = xs @ Rgt.t() + torch.tensor([0.3, -0.2, 0.5]) + (0.0 if name in ("collinear", "coincident") else 1e-3) * xs.abs().max() * torch.randn(6, 3, generator=g)
+            if mirror:
+                y = y * torch.tensor([1.0, 1.0, -1.0])  # the best ROTATION onto a mirrored copy: the smallest singular direction flips
+            R, t = ext.kabsch(xs[None].cuda(), y[None].cuda())
+            R, t = R.cpu()[0].double(), t.cpu()[0].double().view(3)
+            assert torch.isfinite(R).all() and torch.isfinite(t).all(), (name, mirror)
+            assert float((R @ R.t() - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-5 and abs(float(torch.det(R)) - 1) < 1e-5, (name, mirror)
+            Rr, tr = _kabsch_ref(xs[None], y[None])
+            Rr, tr = Rr[0].double(), tr[0].double().view(3)
+            res = lambda RR, tt: float(((xs.double() @ RR.t() + tt - y.double()) ** 2).sum())
+            scale = float((y.double() - y.double().mean(0)).pow(2).sum()) + 1e-30
+            assert res(R, t) <= res(Rr, tr) + 1e-6 * scale + 1e-12, (name, mirror, res(R, t), res(Rr, tr))
+            if unique and not (mirror and name in ("planar", "tetra")):  # (a mirrored planar / symmetric set has a family of optima)
+                assert float((R - Rr).abs().max()) < 5e-6, (name, mirror, float((R - Rr).abs().max()))
+
+
 def test_hand_frame_matches_kabsch_plus_canonicalize():
     from hotrack_amd import ext
     from models.hand_utils import canonicalize

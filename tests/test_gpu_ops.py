@@ -302,6 +302,32 @@ def test_ball_query_picks_matches_gather_then_query():
     assert torch.equal(idx1, ops.ball_query(0.1, 32, d, l1)) and torch.equal(l1, ext.gather_rows(d, i1))
 
 
+def test_ball_query_tie_check_colaunch_equals_separate_launches(monkeypatch):
+    """pn2x_ball_query_picks_ties == pn2x_ball_query_picks2 + pn2x_fps_prefix_ties: neighbour lists, centroid coordinates and (through
+    the second sampling level they steer) the tie flags, on tie-free and tied clouds, one and two centroids per wave."""
+    from _cases import cloud
+    from hotrack_amd import ext, pointnet2_utils as ops
+    assert ext.BALL_TIE_COLAUNCH
+    cases = [(1, 1024, 256, 128, 0.1, 32, "hand"), (16, 1024, 256, 128, 0.1, 32, "hand"), (3, 1000, 256, 128, 0.2, 16, "uniform"),
+             (2, 1024, 256, 128, 0.15, 32, "lattice"), (2, 512, 128, 64, 0.3, 8, "dup"), (2, 343, 100, 100, 0.5, 64, "lattice"),
+             (6, 2560, 512, 128, 0.1, 32, "uniform"), (1, 21, 8, 4, 1.0, 4, "uniform"), (64, 1024, 256, 128, 0.1, 32, "hand")]
+    seen = []
+    for seed, (B, N, m1, m2, r, K, kind) in enumerate(cases):
+        d = torch.from_numpy(cloud(9000 + seed, B, N, kind)).cuda()
+        a = ext.fps_two_level(d, m1, m2, query=(r, K))
+        monkeypatch.setattr(ext, "BALL_TIE_COLAUNCH", False)
+        b = ext.fps_two_level(d, m1, m2, query=(r, K))
+        monkeypatch.setattr(ext, "BALL_TIE_COLAUNCH", True)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), (seed, kind)
+        assert torch.equal(a[3], ops.ball_query(r, K, d, a[1])) and torch.equal(a[2], ops.furthest_point_sample(a[1], m2))
+        seen.append(bool(ext._lib.pn2x_ball_query_picks_ties_supported(B, N, m1, m2)))
+    assert seen == [True] * 8 + [False]   # many clouds: two launches
+    real = ext._lib.pn2x_ball_query_picks_ties
+    assert real(1, 1024, 256, 0.1, 32, None, None, None, None, None, 0, 128, None, None, None) == -2   # NULL pointers
+    assert real(1, 1024, 256, 0.1, 32, None, None, None, None, None, 0, 300, None, None, None) == -1   # m2 > m
+
+
 def test_fps_knn_colaunch_equals_separate_launches(monkeypatch):
     """pn2x_fps_radii_knn: sampling level 1 and the keypoints' k-NN lists in one launch == the two launches, index for index
     (uniform / hand / lattice / duplicated clouds, ragged query counts, k2 = 0, the oracle's lists), and the entry is really
