@@ -23,7 +23,10 @@ python $R/scripts/trace_one_step.py $(find /tmp/ts -name "*kernel_trace.csv" | h
 python $R/scripts/trace_window.py $(find /tmp/ts -name "*kernel_trace.csv" | head -1) --frac 0.3 --steps-in-window 0 > $O/${tag}_train_graph_window.csv
 rm -rf /tmp/tst && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tst -o t -- python $R/scripts/bench_stress.py > /dev/null 2>&1
 cp $(find /tmp/tst -name "*kernel_stats.csv" | head -1) $O/${tag}_stress_kernel_stats.csv
+rm -rf /tmp/tl && rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o t -- python $R/scripts/bench_legs.py latency > /dev/null 2>&1
+python $R/scripts/trace_graph_replays.py $(find /tmp/tl -name "*kernel_trace.csv" | head -1) --marker hand_frame_kernel > $O/${tag}_latency_b1_replay.csv 2>&1
 cd $R
+python scripts/probes/hand_frame_timing.py 2>/dev/null | grep hand_frame > $O/${tag}_hand_frame_timing.txt
 python scripts/probes/two_graph_overlap.py 2>/dev/null | grep "ms / step" > $O/${tag}_two_graph_overlap.txt
 python scripts/probes/train_host_timing.py 2>/dev/null | grep "step " > $O/${tag}_train_prefetch_vs_inline.txt
 HOTRACK_STACK_PAIR_LAUNCH=0 python scripts/bench_train.py --graph > $O/${tag}_bench_train_graph_no_pair_launch.json 2>/dev/null
