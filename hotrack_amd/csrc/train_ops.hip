@@ -525,7 +525,7 @@ interp_pm_bwd_kernel(int m, int n, int Q, const float *__restrict__ dOut, int ld
 __global__ void __launch_bounds__(kTT)
 sa_layer1_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int a1f_ld, const float *__restrict__ xyz,
                  const float *__restrict__ cxyz, const float *__restrict__ wx, int wx_ld, const float *__restrict__ cadd, int cadd_ld,
-                 const int *__restrict__ idx, float *__restrict__ out, float *__restrict__ rel_out, int a1f_slots) {
+                 const int *__restrict__ idx, float *__restrict__ out, float *__restrict__ rel_out) {
     const int b = blockIdx.y;
     const long e = (long)blockIdx.x * kTT + threadIdx.x;
     const int sk = S * K;
@@ -534,8 +534,7 @@ sa_layer1_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int 
     const int s = r / K;
     const int j = idx[(size_t)b * sk + r];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // a1f_slots: the feature term is stored per neighbourhood SLOT (b, s*k, ld) -- the caller gathered the rows before its GEMM
-    if (a1f) acc = *reinterpret_cast<const float4 *>(a1f + (a1f_slots ? ((size_t)b * sk + r) : ((size_t)b * n + j)) * a1f_ld + 4 * q);
+    if (a1f) acc = *reinterpret_cast<const float4 *>(a1f + ((size_t)b * n + j) * a1f_ld + 4 * q);
     if (xyz) {
         const float *p = xyz + ((size_t)b * n + j) * 3, *c = cxyz + ((size_t)b * S + s) * 3;
         const float rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
@@ -1080,12 +1079,6 @@ extern "C" int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a
 extern "C" int pn2x_sa_layer1_ld(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
                                  const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
                                  void *stream) {
-    return pn2x_sa_layer1_slots(b, n, s, k, c1, a1f, a1f_ld, 0, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, stream);
-}
-
-extern "C" int pn2x_sa_layer1_slots(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, int a1f_slots, const float *xyz,
-                                    const float *cxyz, const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx,
-                                    float *out, float *rel_out, void *stream) {
     using namespace pn2;
     if (b < 0 || n < 1 || s < 0 || k < 1 || c1 < 4 || c1 % 4 || (xyz && wx_ld < 3)) return PN2_EINVAL;
     if (b == 0 || s == 0) return PN2_OK;
@@ -1096,7 +1089,7 @@ extern "C" int pn2x_sa_layer1_slots(int b, int n, int s, int k, int c1, const fl
     const int Q = c1 / 4;
     const long total = (long)s * k * Q;
     hipLaunchKernelGGL(sa_layer1_kernel, dim3((unsigned)((total + kTT - 1) / kTT), b), dim3(kTT), 0, (hipStream_t)stream, n, s, k, Q, a1f,
-                       a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, a1f_slots ? 1 : 0);
+                       a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out);
     return check_launch();
 }
 

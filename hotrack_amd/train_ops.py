@@ -28,8 +28,6 @@ _lib.pn2x_three_interpolate_pm_grad.argtypes = [_ci, _ci, _ci, _ci, _vp, _ci, _v
 _lib.pn2x_sa_layer1.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_sa_layer1_ld.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_sa_layer1_ld.restype = _ci
-_lib.pn2x_sa_layer1_slots.argtypes = [_ci] * 5 + [_vp, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp]
-_lib.pn2x_sa_layer1_slots.restype = _ci
 _lib.pn2x_rows_outer3.argtypes = [_cl, _ci, _vp, _ci, _vp, _vp, _vp, _cl, _vp]
 _lib.pn2x_rows_outer3.restype = _ci
 _lib.pn2x_rows_outer3_scratch_floats.argtypes = [_cl, _ci]
@@ -206,15 +204,28 @@ def inverse_index(idx: torch.Tensor, n_dst: int):
 
 def rows_segment_sum(dout: torch.Tensor, inv, n_dst: int, din: torch.Tensor, weight: torch.Tensor = None, accumulate: bool = False):
     """din[b, i, :] (+)= sum over the entries e of target i of (weight[b, e] *) dout[b, e (// 3), :]  -- no atomics, every row of
-    din written once.  dout (B,M,C) contiguous; inv = inverse_index(idx.view(B, -1), n_dst); din (B,n_dst,>=C) rows."""
+    din written once.  dout (B,M,C) rows (contiguous, or a column block of a wider gradient: see _row_block);
+    inv = inverse_index(idx.view(B, -1), n_dst); din (B,n_dst,>=C) rows."""
     B, M, C = dout.shape
     offsets, order = inv
     t = 1 if weight is None else 3
+    dout = _row_block(dout)
     with torch.cuda.device(dout.device):
-        _native._check(_lib.pn2x_rows_segment_sum(B, n_dst, M, t, C, _native._ptr(dout, "dout", _f32, B * M * C), C, offsets.data_ptr(),
+        _native._check(_lib.pn2x_rows_segment_sum(B, n_dst, M, t, C, dout.data_ptr(), dout.stride(1) if M > 1 else max(dout.stride(1), C), offsets.data_ptr(),
                                                   order.data_ptr(), _p(weight), din.data_ptr(), din.stride(1), 1 if accumulate else 0,
                                                   _native._stream(dout)), "rows_segment_sum")
     return din
+
+
+def _row_block(t: torch.Tensor) -> torch.Tensor:
+    """t (B,M,C) as the kernels with a row-stride argument can read it: itself when its rows are 16-byte aligned, unit-stride and
+    uniformly spaced across the batch (a column block of a wider tensor -- the half of a concatenation's gradient -- costs no copy
+    launch then), a contiguous copy otherwise."""
+    B, M, C = t.shape
+    if (t.dtype == _f32 and t.stride(2) == 1 and t.stride(1) % 4 == 0 and t.stride(1) >= C and t.data_ptr() % 16 == 0
+            and (B == 1 or t.stride(0) == M * t.stride(1))):
+        return t
+    return t.contiguous()
 
 
 def scatter_add_rows(dout: torch.Tensor, idx: torch.Tensor, din: torch.Tensor) -> torch.Tensor:
@@ -229,9 +240,7 @@ def scatter_add_rows(dout: torch.Tensor, idx: torch.Tensor, din: torch.Tensor) -
 
 
 class _SaLayer1(torch.autograd.Function):
-    """One module call = all its scales: a1f (B,N,sum C1) | None, cadd (B,S,sum C1) | None, then per scale (idx_i, wx_i, slot_i).
-    slot_i (B, S*K_i, C1_i) | None: the feature term of scale i per neighbourhood SLOT (the caller gathered the rows and ran its
-    GEMM over the slots); such a scale takes no columns of a1f, and its gradient is dY_1 of that scale as it is (no scatter)."""
+    """One module call = all its scales: a1f (B,N,sum C1) | None, cadd (B,S,sum C1) | None, then per scale (idx_i, wx_i)."""
 
     @staticmethod
     def forward(ctx, a1f, cadd, xyz, cxyz, n_scales, aux, *rest):
@@ -239,64 +248,55 @@ class _SaLayer1(torch.autograd.Function):
         # leaves the relative coordinates there (aux["rel"][i]); a stack whose first-layer backward has dY_1 in registers anyway
         # leaves d(wx_i) there (aux["dwx"][i]), which this backward then takes instead of a pass of its own over dY_1.
         # rest: idx_i (n_scales), wx_i (n_scales), then optionally the inverted neighbour lists (offsets_i, order_i) per scale
-        idxs, wxs, slots, invs = rest[:n_scales], rest[n_scales:2 * n_scales], rest[2 * n_scales:3 * n_scales], rest[3 * n_scales:]
+        idxs, wxs, invs = rest[:n_scales], rest[n_scales:2 * n_scales], rest[2 * n_scales:]
         B, N, _ = xyz.shape
         S = cxyz.shape[1]
         outs, rels = [], []
-        col = ccol = 0  # column cursors into a1f (point-major scales only) and cadd (every scale)
+        col = 0
         st = _native._stream(xyz)
-        for idx, wx, slot in zip(idxs, wxs, slots):
+        for idx, wx in zip(idxs, wxs):
             K, C1 = idx.shape[2], wx.shape[0]
-            if slot is not None and (slot.shape != (B, S * K, C1) or slot.stride(2) != 1 or slot.stride(0) != S * K * slot.stride(1)):
-                raise ValueError("sa_layer1: a slot-major feature term must be (B, S*K, C1) rows")
-            feat = slot if slot is not None else a1f
             out = torch.empty((B, S * K, C1), dtype=_f32, device=xyz.device)
             rel = torch.empty((B, S * K, 3), dtype=_f32, device=xyz.device)
             if wx.dim() != 2 or wx.shape[1] != 3 or wx.stride(1) != 1 or wx.dtype != _f32:
                 wx = wx.contiguous().float()
             with torch.cuda.device(xyz.device):  # the (C1, 3) block is read in place (a column block of the layer's weight)
-                _native._check(_lib.pn2x_sa_layer1_slots(
-                    B, N, S, K, C1, None if feat is None else feat.data_ptr() + (0 if slot is not None else 4 * col),
-                    0 if feat is None else feat.stride(1), 0 if slot is None else 1,
+                _native._check(_lib.pn2x_sa_layer1_ld(
+                    B, N, S, K, C1, None if a1f is None else a1f.data_ptr() + 4 * col, 0 if a1f is None else a1f.stride(1),
                     xyz.data_ptr(), cxyz.data_ptr(), wx.data_ptr(), wx.stride(0) if C1 > 1 else 3,
-                    None if cadd is None else cadd.data_ptr() + 4 * ccol,
+                    None if cadd is None else cadd.data_ptr() + 4 * col,
                     0 if cadd is None else cadd.stride(1), _native._ptr(idx, "idx", torch.int32, B * S * K), out.data_ptr(),
                     rel.data_ptr(), st), "sa_layer1")
             outs.append(out)
             rels.append(rel)
-            col += C1 if slot is None else 0
-            ccol += C1
+            col += C1
         ctx.aux = aux
         if aux is not None:
             aux["rel"], aux["dwx"] = list(rels), {}
         ctx.save_for_backward(*idxs, *rels, *invs)
-        ctx.meta = (n_scales, None if a1f is None else tuple(a1f.shape), None if cadd is None else tuple(cadd.shape), S,
-                    tuple(sl is not None for sl in slots))
+        ctx.meta = (n_scales, None if a1f is None else tuple(a1f.shape), None if cadd is None else tuple(cadd.shape), S)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        n, a1f_shape, cadd_shape, S, is_slot = ctx.meta
+        n, a1f_shape, cadd_shape, S = ctx.meta
         idxs, rels, invs = ctx.saved_tensors[:n], ctx.saved_tensors[n:2 * n], ctx.saved_tensors[2 * n:]
         dev = douts[0].device
         fits = a1f_shape is not None and a1f_shape[1] <= INVERSE_MAX_ROWS
         d_a1f = (torch.empty if fits else torch.zeros)(a1f_shape, dtype=_f32, device=dev) if a1f_shape is not None else None
         d_cadd = torch.empty(cadd_shape, dtype=_f32, device=dev) if cadd_shape is not None else None
-        d_wx, d_slots = [], []
-        col = ccol = 0
+        d_wx = []
+        col = 0
         for i, (dy, idx, rel) in enumerate(zip(douts, idxs, rels)):
             dy = dy.contiguous()
             B, SK, C1 = dy.shape
-            d_slots.append(dy if is_slot[i] else None)
-            if is_slot[i]:
-                pass
-            elif d_a1f is not None and fits:  # owner-computes segment sum over the inverted neighbour lists: no atomics, no pre-zeroing
+            if d_a1f is not None and fits:  # owner-computes segment sum over the inverted neighbour lists: no atomics, no pre-zeroing
                 inv = (invs[2 * i], invs[2 * i + 1]) if invs else inverse_index(idx.view(B, SK), a1f_shape[1])
                 rows_segment_sum(dy, inv, a1f_shape[1], d_a1f[:, :, col:col + C1])
             elif d_a1f is not None:
                 scatter_add_rows(dy, idx.view(B, SK), d_a1f[:, :, col:col + C1])
             if d_cadd is not None:
-                torch.sum(dy.view(B, S, SK // S, C1), dim=2, out=d_cadd[:, :, ccol:ccol + C1])
+                torch.sum(dy.view(B, S, SK // S, C1), dim=2, out=d_cadd[:, :, col:col + C1])
             ready = ctx.aux["dwx"].pop(i, None) if ctx.aux is not None else None
             if ready is not None:  # formed by the consumer's first-layer backward (pn2x_bn_bwd_apply_rel)
                 d_wx.append(ready)
@@ -309,22 +309,41 @@ class _SaLayer1(torch.autograd.Function):
                 d_wx.append(dwx)
             else:
                 d_wx.append(torch.mm(dy.view(B * SK, C1).t(), rel.view(B * SK, 3)))
-            col += 0 if is_slot[i] else C1
-            ccol += C1
-        return (d_a1f, d_cadd, None, None, None, None, *([None] * n), *d_wx, *d_slots, *([None] * len(invs)))
+            col += C1
+        return (d_a1f, d_cadd, None, None, None, None, *([None] * n), *d_wx, *([None] * len(invs)))
 
 
-def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs, invs=None, aux=None, slots=None):
+def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs, invs=None, aux=None):
     """Layer-1 pre-activations of every scale of one SA module: list of (B, S*K_i, C1_i).
     a1f (B,N,sum C1) per-point feature terms [scale 0 | scale 1 ...] or None; cadd (B,S,sum C1) per-centroid terms or None;
     xyz (B,N,3), cxyz (B,S,3) (no gradient); idxs[i] (B,S,K_i) int32; wxs[i] (C1_i, 3).
     invs[i] = inverse_index(idxs[i].view(B, -1), N), computed by a caller that feeds the same neighbour lists to several modules
     (the backward inverts them itself otherwise).  aux: an empty dict shared with train_stack.mlp_stack(aux=(aux, i)) -- see
-    _SaLayer1.forward.  slots[i] (B, S*K_i, C1_i) | None: scale i's feature term per neighbourhood slot instead of columns of a1f
-    (which then holds the other scales' columns only)."""
-    extra = [t for inv in invs for t in (inv if inv is not None else (None, None))] if invs else []
-    slots = list(slots) if slots is not None else [None] * len(idxs)
-    return list(_SaLayer1.apply(a1f, cadd, xyz, cxyz, len(idxs), aux, *idxs, *wxs, *slots, *extra))
+    _SaLayer1.forward."""
+    extra = [t for inv in invs for t in inv] if invs else []
+    return list(_SaLayer1.apply(a1f, cadd, xyz, cxyz, len(idxs), aux, *idxs, *wxs, *extra))
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx, inv_off, inv_order):
+        from . import ext
+        ctx.save_for_backward(inv_off, inv_order)
+        ctx.n = src.shape[1]
+        return ext.gather_rows(src, idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, M, C = dout.shape
+        dsrc = torch.empty((B, ctx.n, C), dtype=_f32, device=dout.device)
+        rows_segment_sum(dout, tuple(ctx.saved_tensors), ctx.n, dsrc)  # every row written once: no zero fill, no atomics
+        return dsrc, None, None, None
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, inv) -> torch.Tensor:
+    """src (B,N,C) contiguous, idx (B,M) int32, inv = inverse_index(idx, N) -> src[b, idx[b, j], :] (B,M,C); the gradient is the
+    owner-computes segment sum over the inverted lists (torch.index_select's backward: a zero fill + an atomic index_add)."""
+    return _GatherRows.apply(src.contiguous(), idx, inv[0], inv[1])
 
 
 class _InterpRows(torch.autograd.Function):
@@ -342,9 +361,10 @@ class _InterpRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         idx, weight, *inv = ctx.saved_tensors
-        dout = dout.contiguous()
         B, n, C = dout.shape
         none = (None,) * len(inv)
+        if ctx.m > INVERSE_MAX_ROWS:
+            dout = dout.contiguous()
         if ctx.m <= INVERSE_MAX_ROWS:
             dp = torch.empty((B, ctx.m, C), dtype=_f32, device=dout.device)
             rows_segment_sum(dout, tuple(inv) if inv else inverse_index(idx.view(B, n * 3), ctx.m), ctx.m, dp, weight=weight)

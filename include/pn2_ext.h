@@ -322,12 +322,6 @@ int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a1f, int a1f
 int pn2x_sa_layer1_ld(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
                       const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
                       void *stream);
-/* the same with the feature term stored per neighbourhood slot when a1f_slots != 0: a1f (b, s*k, a1f_ld) -- a caller whose
- * neighbourhoods hold fewer slots than the cloud has points gathers the feature rows first and runs the layer-1 product over the
- * slots (the small keypoint neighbourhoods: 21 x 16 slots against 1024 points) */
-int pn2x_sa_layer1_slots(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, int a1f_slots, const float *xyz,
-                         const float *cxyz, const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out,
-                         float *rel_out, void *stream);
 /*
  * Transpose of pn2x_gather_rows (group_points_grad on point-major rows, reference group_points_gpu.cu:8-25):
  *   din[b, idx[b,j], :] += dout[b, j, :]      dout (b, m, ldo), idx (b, m) int32, din (b, n, ldi) accumulated into.

@@ -75,52 +75,12 @@ class _Linear2Shared(torch.autograd.Function):
         return dx, dw1, dw2
 
 
-class _QueryFirstLayer(torch.autograd.Function):
-    """The per-point halves of layer 1 of BOTH keypoint-query modules at BOTH neighbourhood sizes.  Layer 1 is linear in the
-    backbone feature, so it commutes with the neighbour gather: the large scale (21 x 64 slots > 1024 points per cloud) runs
-    it over the POINTS (x wp^T, gathered later by train_ops.sa_layer1), the small one (21 x 16 slots) gathers its rows first and
-    runs it over the SLOTS -- a third of the rows, in forward, data gradient and weight gradient alike (round 4: all four products
-    ran over the points: 38.6 of the step's 129 GFLOP).  One Function so that the input gradient is formed once: the point
-    products accumulate into each other (addmm) and the slot products' rows are scattered on top by the owner-computes segment sum
-    (no atomics, no separate sum of two (B*N, C) tensors).
-    x (B*N, C); idx (B, M) int32 slot -> point, inv = inverse_index(idx, N); wg1 / wg2 / wp1 / wp2 (C1, C) weight blocks of
-    (module 1, 2) x (slot scale, point scale) -> (x[idx] wg1^T, x[idx] wg2^T, x wp1^T, x wp2^T)."""
-
-    @staticmethod
-    def forward(ctx, x, idx, inv_off, inv_order, B, wg1, wg2, wp1, wp2):
-        from hotrack_amd import ext
-        N, C = x.shape[0] // B, x.shape[1]
-        rows = ext.gather_rows(x.view(B, N, C), idx).view(-1, C)
-        ctx.save_for_backward(x, rows, inv_off, inv_order, wg1, wg2, wp1, wp2)
-        ctx.B = B
-        return torch.mm(rows, wg1.t()), torch.mm(rows, wg2.t()), torch.mm(x, wp1.t()), torch.mm(x, wp2.t())
-
-    @staticmethod
-    def backward(ctx, gg1, gg2, gp1, gp2):
-        from hotrack_amd.train_ops import rows_segment_sum
-        x, rows, inv_off, inv_order, wg1, wg2, wp1, wp2 = ctx.saved_tensors
-        B, C = ctx.B, x.shape[1]
-        N, M = x.shape[0] // B, rows.shape[0] // B
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.mm(gp1, wp1)
-            dx.addmm_(gp2, wp2)
-            drows = torch.mm(gg1, wg1)
-            drows.addmm_(gg2, wg2)
-            rows_segment_sum(drows.view(B, M, C), (inv_off, inv_order), N, dx.view(B, N, C), accumulate=True)
-        need = ctx.needs_input_grad
-        return (dx, None, None, None, None,
-                torch.mm(gg1.t(), rows) if need[5] else None, torch.mm(gg2.t(), rows) if need[6] else None,
-                torch.mm(gp1.t(), x) if need[7] else None, torch.mm(gp2.t(), x) if need[8] else None)
-
-
 class FastTrain:
     def __init__(self, net):
         self.net = net
         self.ws = None
         import os
         self.use_fused_stacks = os.environ.get("HOTRACK_FUSED_STACKS", "1") != "0"  # 0: round-2 path (library GEMMs + streaming BN)
-        self.gather_small_scale = os.environ.get("HOTRACK_Q_GATHER", "1") != "0"    # 0: layer 1 of every query scale over the points
 
     @staticmethod
     def supported(net) -> bool:
@@ -165,11 +125,10 @@ class FastTrain:
             wf = w1[0][0] if len(w1) == 1 else torch.cat([w[0] for w in w1], dim=0)
         return w1, wf
 
-    def _sa_scales(self, mod, xyz, cxyz, feat2d, idxs, center2d=None, pre=None, invs=None, slots=None):
+    def _sa_scales(self, mod, xyz, cxyz, feat2d, idxs, center2d=None, pre=None, invs=None):
         """All scales of one SA module.  xyz (B,N,3), cxyz (B,S,3), feat2d (B*N, D)|None, center2d (B*S, D2)|None ->
         (B, S, sum C3) point-major.  pre = (w1, a1f2d): the first-layer blocks and the per-point product feat2d wf^T computed by
-        the caller (_Linear2Shared).  slots[i] (B, S*K_i, C1) | None: scale i's feature term per neighbourhood slot (then a1f2d holds
-        the other scales' columns only; _QueryFirstLayer)."""
+        the caller (_Linear2Shared)."""
         from hotrack_amd.train_ops import sa_layer1
         B, N, _ = xyz.shape
         S = cxyz.shape[1]
@@ -186,7 +145,7 @@ class FastTrain:
             wc = w1[0][2] if len(w1) == 1 else torch.cat([w[2] for w in w1], dim=0)
             cadd = F.linear(center2d, wc).view(B, S, -1)
         aux = {} if self.use_fused_stacks else None  # relative coordinates -> the stacks, d(W_xyz) <- the stacks (train_ops.sa_layer1)
-        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1], invs=invs, aux=aux, slots=slots)
+        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1], invs=invs, aux=aux)
         outs = []
         pair = self._pair_stacks(mod, y1s, idxs, aux) if len(y1s) == 2 else None
         if pair is not None:  # both neighbourhood sizes layer by layer, equal-shaped fused launches grouped (train_stack.mlp_stack_pair)
@@ -306,28 +265,14 @@ class FastTrain:
 
         # ---- q1 -> r1 -> q2 -> r2 around the J keypoints; one kNN search for both neighbourhood sizes ------------------
         idxs, invs = geo["knn"], geo["knn_inv"]
-        # the per-point halves of both modules' first layers read src2: one Function, one input gradient
-        Ks = [i.shape[2] for i in idxs]
-        small = [J * K * 2 <= N for K in Ks]  # fewer slots than half the points: gather the rows, then the product (as fast_eval.py)
-        if self.gather_small_scale and invs is not None and len(Ks) == 2 and small[0] != small[1]:
-            g, pt = (0, 1) if small[0] else (1, 0)
-            w1_q1 = [_split_first_layer(_w2d(convs[0]), C, False) for convs in net.q1.conv_blocks]
-            w1_q2 = [_split_first_layer(_w2d(convs[0]), C, True) for convs in net.q2.conv_blocks]
-            ag1, ag2, ap1, ap2 = _QueryFirstLayer.apply(src2, idxs[g].view(B, -1), invs[g][0], invs[g][1], B,
-                                                        w1_q1[g][0], w1_q2[g][0], w1_q1[pt][0], w1_q2[pt][0])
-            slots = lambda a: [a.view(B, J * Ks[g], -1) if i == g else None for i in range(2)]
-            pinv = [None if i == g else invs[i] for i in range(2)]
-            f11 = self._sa_scales(net.q1, xyz, kp, src2, idxs, pre=(w1_q1, ap1), invs=pinv, slots=slots(ag1))   # (B,J,C)
-            f12 = self._rearrange(net.r1, f11)                                                                 # (B*J, C)
-            f13 = self._sa_scales(net.q2, xyz, kp, src2, idxs, center2d=f12, pre=(w1_q2, ap2), invs=pinv, slots=slots(ag2))
-        else:
-            w1_q1, wf_q1 = self._first_layer_blocks(net.q1, C, False)
-            w1_q2, wf_q2 = self._first_layer_blocks(net.q2, C, True)
-            a1f_q1, a1f_q2 = _Linear2Shared.apply(src2, wf_q1, wf_q2)
-            # both modules gather through the same neighbour lists: inverted once (geometry) for the two backward scatters
-            f11 = self._sa_scales(net.q1, xyz, kp, src2, idxs, pre=(w1_q1, a1f_q1), invs=invs)             # (B,J,C)
-            f12 = self._rearrange(net.r1, f11)                                                                 # (B*J, C)
-            f13 = self._sa_scales(net.q2, xyz, kp, src2, idxs, center2d=f12, pre=(w1_q2, a1f_q2), invs=invs)
+        # the per-point halves of both modules' first layers read src2: one Function, one input gradient (_Linear2Shared)
+        w1_q1, wf_q1 = self._first_layer_blocks(net.q1, C, False)
+        w1_q2, wf_q2 = self._first_layer_blocks(net.q2, C, True)
+        a1f_q1, a1f_q2 = _Linear2Shared.apply(src2, wf_q1, wf_q2)
+        # both modules gather through the same neighbour lists: inverted once (geometry) for the two backward scatters
+        f11 = self._sa_scales(net.q1, xyz, kp, src2, idxs, pre=(w1_q1, a1f_q1), invs=invs)             # (B,J,C)
+        f12 = self._rearrange(net.r1, f11)                                                                 # (B*J, C)
+        f13 = self._sa_scales(net.q2, xyz, kp, src2, idxs, center2d=f12, pre=(w1_q2, a1f_q2), invs=invs)
         f14 = self._rearrange(net.r2, f13).view(B, J, C)
         self.last_token_rows = f14.view(B * J, C)  # token-major rows for FastTail (the transposed view below is what `r2` returns)
         return f14.transpose(1, 2), src2.view(B, N, C)
@@ -335,12 +280,17 @@ class FastTrain:
     @staticmethod
     def _rearrange(mod, tok):
         """rearrange_module on token-major features tok (B,J,C) -> (B*J, C) (blocks.py: fast formula)."""
+        from hotrack_amd.train_ops import INVERSE_MAX_ROWS, gather_rows, inverse_index
         B, J, C = tok.shape
-        flat = getattr(mod, "_perm_flat", None)  # (J*re,) token indices, cached: a 2-D advanced index recomputes its
-        if flat is None or flat.device != tok.device:  # linearised offsets every step and scatters its gradient with index_put
-            flat = mod._perm.t().reshape(-1).to(tok.device).contiguous()
-            mod._perm_flat = flat
-        g = tok.index_select(1, flat)  # (B, J*re, C)
+        cache = getattr(mod, "_perm_rows", None)  # (B, J*re) token indices + their inverted lists: static, built once per batch size
+        if cache is None or cache[0].shape[0] != B or cache[0].device != tok.device:
+            idx = mod._perm.t().reshape(1, -1).to(device=tok.device, dtype=torch.int32).expand(B, -1).contiguous()
+            cache = (idx, inverse_index(idx, J) if J <= INVERSE_MAX_ROWS else None)
+            mod._perm_rows = cache
+        if cache[1] is not None:
+            g = gather_rows(tok, cache[0], cache[1])  # (B, J*re, C); backward: one segment-sum launch
+        else:
+            g = tok.index_select(1, cache[0][0].long())
         return F.linear(g.view(B * J, mod.re * C), mod.linear.weight.squeeze(-1), mod.linear.bias)
 
 

@@ -239,42 +239,28 @@ def test_fast_train_path_equals_module_path():
             torch.testing.assert_close(bb[k], ba[k], rtol=1e-4, atol=3e-5, msg=lambda m: f"{k}: {m}")
 
 
-def test_query_first_layer_over_gathered_slots_equals_over_points(monkeypatch):
-    """HOTRACK_Q_GATHER (default on): layer 1 of the small keypoint neighbourhoods as a product over the gathered slots
-    (_QueryFirstLayer + sa_layer1's slot-major feature term) vs over all points (HOTRACK_Q_GATHER=0, round 4's first form): same
-    loss, and gradients as close to the reference's fp64 gradients as the other form's."""
-    import test_network as tn
-    from models.hand_network import HandTrackNet
-    from models import fast_train
-    res, used = {}, []
-    real = fast_train._QueryFirstLayer.apply
-    monkeypatch.setattr(fast_train._QueryFirstLayer, "apply", staticmethod(lambda *a: (used.append(1), real(*a))[1]))
-    monkeypatch.setattr(HandTrackNet, "_force_fast_train", True, raising=False)
-    for flag in ("0", "1"):
-        monkeypatch.setenv("HOTRACK_Q_GATHER", flag)
-        n0 = len(used)
-        model, ret, total = tn._train_step("cuda", True)
-        assert bool(model._ftrain) and (len(used) > n0) == (flag == "1")
-        res[flag] = (model, float(total))
-    (ma, la), (mb, lb) = res["0"], res["1"]
-    assert abs(la - lb) < 2e-6 * abs(la), (la, lb)
-    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
-    err = {"0": [], "1": []}
-    for k in pa:
-        assert (pa[k].grad is None) == (pb[k].grad is None), k
-        if pa[k].grad is None:
-            continue
-        t = torch.from_numpy(tn.GOLD["g64/" + k]).cuda()
-        scale = float(t.abs().max())
-        if scale < 1e-6:
-            assert float(pb[k].grad.abs().max()) <= 1e-5, k
-            continue
-        for flag, p in (("0", pa[k]), ("1", pb[k])):
-            e = float((p.grad.flatten()[:1024].double() - t).abs().max()) / scale
-            assert e < 0.25, (k, flag, e)
-            err[flag].append(e)
-    mean = {f: sum(v) / len(v) for f, v in err.items()}
-    assert mean["1"] <= 1.25 * mean["0"] + 1e-3, mean
+def test_gather_rows_gradient_is_the_segment_sum():
+    """train_ops.gather_rows == torch.index_select along the rows, forward (bit-exact) and backward (a repeated row receives the
+    sum of its slots' gradients, an unused row exact zeros), incl. the static permutation of the rearrange modules."""
+    from hotrack_amd.train_ops import gather_rows, inverse_index
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for B, N, M, C in ((32, 21, 63, 384), (3, 1024, 336, 128), (2, 7, 40, 4), (1, 5, 1, 8)):
+        src = torch.randn(B, N, C, device="cuda", generator=g)
+        idx = torch.randint(0, N, (B, M), device="cuda", generator=g, dtype=torch.int32)
+        if N > 3:
+            idx[idx == 2] = 3  # row 2 is never read
+        wide = torch.randn(B, M, C + 8, device="cuda", generator=g)
+        go = wide[:, :, 4:4 + C]  # a column block of a wider gradient (half of a concatenation's): read in place, no copy launch
+        a = src.clone().requires_grad_(True)
+        out = gather_rows(a, idx, inverse_index(idx, N))
+        out.backward(go)
+        b = src.clone().double().requires_grad_(True)
+        ref = torch.gather(b, 1, idx.long().unsqueeze(-1).expand(B, M, C))
+        ref.backward(go.double())
+        assert torch.equal(out.detach().double(), ref.detach())
+        assert torch.allclose(a.grad.double(), b.grad, rtol=1e-6, atol=1e-6)
+        if N > 3:
+            assert float(a.grad[:, 2].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("G,K,C,ties", [(300, 32, 64, False), (21 * 5, 16, 192, False), (64, 128, 512, False), (7, 3, 4, False),
