@@ -81,15 +81,17 @@ class KernelTimer:
     def summary(self, passes):
         by = {}
         for name, a, s, e in self.records:
-            if name in ("fps_kernel", "fps_prefix_kernel"):
+            if name in ("fps_kernel", "fps_prefix_kernel", "fps_knn_kernel"):
                 key = (name, a[0], a[1], a[2])  # (b, n, m)
             elif name == "sa_mlp_max_pair_kernel":  # both scales of a query module in one launch: (b, s, (k0, k1), c1, c2, c3)
                 q0, q1 = a[4]._obj, a[5]._obj
                 key = (name, a[0], q0.s, (q0.k, q1.k), a[1], a[2], a[3])
             elif name == "mlp2_rows_kernel":  # two fused per-point layers: (rows, c1, c2, c3)
                 key = (name, a[0], a[1], a[2], a[3])
-            else:
+            elif name == "sa_mlp_max_kernel":
                 key = ("sa_mlp_max_kernel", a[0], a[2], a[3], a[4], a[5], a[6])  # (b, s, k, c1, c2, c3)
+            else:  # hooked launches without a roofline entry of their own (three_nn_interp_kernel, ball_tie_kernel, linear_small_kernel)
+                continue
             by.setdefault(key, []).append(s.elapsed_time(e) * 1e-3)
         # key -> (mean seconds per launch, launches per step)
         return {k: (sum(v) / len(v), len(v) / max(passes, 1)) for k, v in by.items()}
@@ -120,7 +122,8 @@ def roofline_of(key, sec, per_step):
                 "bytes_per_launch": kb, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step,
                 "note": "FPS over level 1's samples = level 1's first M picks unless an arg-max tied (pn2_ext.h): per cloud "
                         "the launch returns at once (no tie: all clouds of this synthetic batch) or runs the real pass"}
-    return {"bound": "hbm", "kernel": "fps_kernel (B=%d,N=%d,M=%d)" % (B, N, M), "achieved": round(kb / sec / 1e9, 3),
+    label = "fps_kernel" if name == "fps_kernel" else "fps_knn_kernel: sampling + the keypoints' k-NN lists in one launch"
+    return {"bound": "hbm", "kernel": "%s (B=%d,N=%d,M=%d)" % (label, B, N, M), "achieved": round(kb / sec / 1e9, 3),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb / sec / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
             "bytes_per_launch": kb, "us_per_launch": round(sec * 1e6, 2), "launches_per_step": per_step,
             "us_per_fps_iteration": round(sec * 1e6 / max(M - 1, 1), 4),

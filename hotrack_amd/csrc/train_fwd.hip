@@ -331,7 +331,7 @@ extern "C" int pn2x_tg_fwd2_pair(long rows0, int k, int n, const float *x0, int 
                nbt0, save_mean0, save_invstd0, sums_out0};
     FwdArgs a1{rows1, n, x1, ldx1, w1, ldw1, y1, ldy1, sums_in1, gamma1, beta1, conv_bias1, eps1, momentum1, running_mean1, running_var1,
                nbt1, save_mean1, save_invstd1, sums_out1};
-    const int nblk = blocks_for_k(k, n), kb = k / 32;
+    const int nblk = blocks_for_k(k, n);
     const int ny = n / (32 * nblk);
     const long t0 = (rows0 + BM - 1) / BM, t1 = (rows1 + BM - 1) / BM;
     hipStream_t st = (hipStream_t)stream;
