@@ -1,5 +1,6 @@
 """Soak test (not part of pytest): minutes of randomised launches looking for rare failures -- races in the SA kernel's
-two-role pipeline, the optimiser's last-workgroup protocol, the two-level FPS shortcut.  usage: python scripts/soak.py [seconds] [seed]"""
+two-role pipeline, the optimiser's last-workgroup protocol, the two-level FPS shortcut and its co-launches (k-NN inside the sampling launch,
+tie check inside the ball-query launch), the one-launch three-NN + interpolation.  usage: python scripts/soak.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -71,9 +72,25 @@ while time.time() < t_end:
         x = x.cuda()
         m1 = int(rng.integers(2, min(Nf, 512)))
         m2 = int(rng.integers(1, m1 + 1))
-        i1, l1, i2 = ext.fps_two_level(x, m1, m2)
+        # with the round-4 co-launches: level 1's ball query + tie check in one launch, the k-NN lists inside the sampling launch
+        nq, k = int(rng.integers(1, 30)), int(rng.integers(1, min(Nf, 200) + 1))
+        k2 = int(rng.integers(0, k + 1))
+        q = torch.rand(Bf, nq, 3, generator=g).cuda()
+        r, ns = float(rng.choice([0.05, 0.1, 0.3])), int(rng.choice([8, 32, 64]))
+        i1, l1, i2, idx1, (gi, gi2) = ext.fps_two_level(x, m1, m2, query=(r, ns), knn=(q, k, k2))
         r1 = ops.furthest_point_sample(x, m1)
         assert torch.equal(i1, r1) and torch.equal(i2, ops.furthest_point_sample(ext.gather_rows(x, r1), m2)), ("fps_two_level", Bf, Nf, m1, m2)
+        assert torch.equal(idx1, ops.ball_query(r, ns, x, l1)) and torch.equal(gi, ops.knn(k, q, x)[1]), ("co-launch", Bf, Nf, m1, m2, nq, k)
+        assert gi2 is None or torch.equal(gi2, gi[:, :, :k2].contiguous())
+        # three-NN + interpolation as one launch vs two (bit-identical), on sizes either side of its switch-over
+        Bq, nn, mm, Cc = int(rng.choice([1, 16, 40])), int(rng.choice([256, 1024])), int(rng.integers(16, 400)), int(rng.choice([4, 64, 128]))
+        un, kn = torch.rand(Bq, nn, 3, generator=g).cuda(), torch.rand(Bq, mm, 3, generator=g).cuda()
+        pts = torch.randn(Bq, mm, Cc, generator=g).cuda()
+        oa, ob = torch.empty(Bq, nn, Cc, device="cuda"), torch.empty(Bq, nn, Cc, device="cuda")
+        ext.three_nn_interpolate_pm(un, kn, pts, oa)
+        w3_, i3_ = ext.three_nn_weights(un, kn)
+        ext.three_interpolate_pm(pts, i3_, w3_, ob)
+        assert torch.equal(oa, ob), ("three_nn_interpolate_pm", Bq, nn, mm, Cc)
         n_fps += 1
 torch.cuda.synchronize()
 print(f"soak ok: {n_sa} SA launches x2, {n_opt} optimiser pairs, {n_fps} two-level FPS cases in {budget:.0f} s")
