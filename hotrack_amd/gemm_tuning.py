@@ -11,6 +11,7 @@ Set PN2_TUNED_GEMMS=0 to leave the library defaults in place.
 from __future__ import annotations
 
 import os
+import sys
 
 RESULTS = os.environ.get("PN2_TUNED_GEMMS_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
 _state = {"done": False, "on": False, "status": "off", "detail": None}
@@ -113,30 +114,79 @@ def enable() -> bool:
         return False
     tunable.enable(True)
     tunable.tuning_enable(False)
+    _state["ours"] = True
     # TunableOp rewrites its table to this path at process exit; keep it away from the shipped file and per process
     tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "pn2_tunableop_%d.csv" % os.getpid()))
     _state["on"] = bool(tunable.read_file(RESULTS))
+    cache = os.environ.get("HOTRACK_GEMM_CACHE")
+    if cache and os.path.exists(cache):  # solutions a previous process tuned for its own shapes (scope(tune=True))
+        _state["cache_loaded"] = bool(tunable.read_file(cache))
     tunable.enable(False)  # the table stays loaded; `scope()` switches it on around the inference path only
     _self_test(_state["on"])
     return _state["on"]
 
 
+def _tune_requested() -> bool:
+    return os.environ.get("HOTRACK_TUNE_GEMMS", "0") == "1"
+
+
 class scope:
     """`with gemm_tuning.scope():` -- the recorded solutions apply to the GEMMs issued inside (the fused inference
     forward, eager or while it is being captured into a HIP graph) and nothing else in the process (a training loop
-    that validates with the fast path keeps the library defaults and pays no per-GEMM table lookup)."""
+    that validates with the fast path keeps the library defaults and pays no per-GEMM table lookup).
+
+    `scope(tune=True)` marks EAGER warm-up work whose GEMM shapes may be tuned on the spot when the user asks for it
+    (HOTRACK_TUNE_GEMMS=1): TunableOp then times the library's candidates for every shape the loaded table does not hold and keeps
+    the winner for the rest of the process.  The shipped table covers the benchmark configurations (per-GPU batch 32 / 64 x 1024
+    points); another batch size or width issues other shapes, and the libraries' default heuristic is poor on some of them -- a
+    (128 x 32768) (32768 x 384) weight-gradient product ran at 15 TFLOP/s untuned against ~90 tuned (profiles/r04_misc_measurements.md).
+    HOTRACK_GEMM_CACHE=<file>: solutions found this way are also written there, and read back by the next process."""
+
+    def __init__(self, tune: bool = False):
+        self._tune = bool(tune)
 
     def __enter__(self):
-        self._mine = False
-        if enable():
+        self._mine = self._tuning = False
+        if enable() or (self._tune and _tune_requested() and _state["done"] and _tunable_usable()):
+            import torch
             import torch.cuda.tunable as tunable
             if not tunable.is_enabled():
                 tunable.enable(True)
                 self._mine = True
+            if self._tune and _tune_requested() and not torch.cuda.is_current_stream_capturing():
+                tunable.set_max_tuning_duration(30)
+                tunable.set_max_tuning_iterations(30)
+                tunable.tuning_enable(True)
+                self._tuning = True
         return self
 
     def __exit__(self, *exc):
+        import torch.cuda.tunable as tunable
+        if self._tuning:
+            tunable.tuning_enable(False)
+            cache = os.environ.get("HOTRACK_GEMM_CACHE")
+            if cache:
+                try:
+                    _write_results(cache)
+                except Exception as e:  # a read-only location must not take the training run down
+                    print("hotrack_amd.gemm_tuning: could not write %s (%s)" % (cache, e), file=sys.stderr)
         if self._mine:
-            import torch.cuda.tunable as tunable
             tunable.enable(False)
         return False
+
+
+def _write_results(path: str) -> None:
+    """Every solution TunableOp holds in this process (the shipped table's and the ones tuned here) in its own file format:
+    the validators of this installation, then (operator, problem, solution, time) rows."""
+    import torch.cuda.tunable as tunable
+    lines = ["Validator,%s,%s" % (k, v) for k, v in tunable.get_validators()]
+    lines += [",".join(str(f) for f in row) for row in tunable.get_results()]
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    os.replace(tmp, path)
+
+
+def _tunable_usable() -> bool:
+    """TunableOp is ours to switch (nobody else enabled it before us) even when the shipped table did not load."""
+    return _state.get("ours", False)

@@ -467,7 +467,7 @@ class Trainer(nn.Module):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             try:
-                with torch.cuda.stream(side), gemm_tuning.scope():
+                with torch.cuda.stream(side), gemm_tuning.scope(tune=True):  # (HOTRACK_TUNE_GEMMS=1: this batch shape's GEMMs are tuned here)
                     for _ in range(2):
                         self._forward_backward(self._static, geo=self._static_geo)
                         self.optimizer.step()
