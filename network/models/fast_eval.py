@@ -44,6 +44,7 @@ class FastEval:
 
     def __init__(self, net):
         self.net = net
+        self._shapes_seen = set()  # (B, N) of the forwards so far (gemm_tuning.scope(tune=...))
         self._key = None
         self.P = None
         self._consts = {}
@@ -218,7 +219,12 @@ class FastEval:
     # ------------------------------------------------------------------------------------
     def forward(self, input, flag_dict):
         from hotrack_amd import gemm_tuning
-        with gemm_tuning.scope():  # recorded GEMM solutions for this forward only
+        # recorded GEMM solutions for this forward only; the FIRST eager forward of a batch shape may tune the shapes the shipped table
+        # does not hold when the user asks for it (HOTRACK_TUNE_GEMMS=1; a forward under stream capture never tunes)
+        shape = tuple(input["hand_points"].shape[:2])
+        first = shape not in self._shapes_seen
+        self._shapes_seen.add(shape)
+        with gemm_tuning.scope(tune=first):
             return self._forward(input, flag_dict)
 
     def _forward(self, input, flag_dict):
