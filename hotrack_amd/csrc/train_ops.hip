@@ -555,6 +555,54 @@ sa_layer1_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int 
     *reinterpret_cast<float4 *>(out + ((size_t)b * sk + r) * (4 * Q) + 4 * q) = acc;
 }
 
+// The same with the BatchNorm statistics of the result taken on the way (pn2x_sa_layer1_stats): a workgroup owns rows_per_block
+// consecutive slots of one cloud, a thread a channel quad of every rpp-th of them, and the per-thread sums of y and y^2 go through
+// block_reduce_to_sums like pn2x_bn_stats' -- the separate pass over y1 (one launch per scale and step) disappears.
+__global__ void __launch_bounds__(kTT)
+sa_layer1_stats_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int a1f_ld, const float *__restrict__ xyz,
+                       const float *__restrict__ cxyz, const float *__restrict__ wx, int wx_ld, const float *__restrict__ cadd,
+                       int cadd_ld, const int *__restrict__ idx, float *__restrict__ out, float *__restrict__ rel_out,
+                       int rows_per_block, double *__restrict__ sums) {
+    const int b = blockIdx.y;
+    const int sk = S * K, rpp = kTT / Q;  // kTT % Q == 0 (checked by the launcher)
+    const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(sk, r0 + rows_per_block);
+    float w[4][3] = {{0.f}};
+    if (xyz) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[i][c] = wx[(size_t)(4 * q + i) * wx_ld + c];
+    }
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sq = sm;
+    for (int r = r0 + rr; r < r1; r += rpp) {
+        const int s = r / K;
+        const int j = idx[(size_t)b * sk + r];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a1f) acc = *reinterpret_cast<const float4 *>(a1f + ((size_t)b * n + j) * a1f_ld + 4 * q);
+        if (xyz) {
+            const float *p = xyz + ((size_t)b * n + j) * 3, *c = cxyz + ((size_t)b * S + s) * 3;
+            const float rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
+            acc.x += w[0][0] * rx + w[0][1] * ry + w[0][2] * rz;  // the expressions of sa_layer1_kernel: same floats
+            acc.y += w[1][0] * rx + w[1][1] * ry + w[1][2] * rz;
+            acc.z += w[2][0] * rx + w[2][1] * ry + w[2][2] * rz;
+            acc.w += w[3][0] * rx + w[3][1] * ry + w[3][2] * rz;
+            if (rel_out && q == 0) {
+                float *o = rel_out + ((size_t)b * sk + r) * 3;
+                o[0] = rx; o[1] = ry; o[2] = rz;
+            }
+        }
+        if (cadd) {
+            const float4 v = *reinterpret_cast<const float4 *>(cadd + ((size_t)b * S + s) * cadd_ld + 4 * q);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + ((size_t)b * sk + r) * (4 * Q) + 4 * q) = acc;
+        sm.x += acc.x; sm.y += acc.y; sm.z += acc.z; sm.w += acc.w;
+        sq.x += acc.x * acc.x; sq.y += acc.y * acc.y; sq.z += acc.z * acc.z; sq.w += acc.w * acc.w;
+    }
+    block_reduce_to_sums(sm, sq, Q, rpp, 4 * Q, sums);
+}
+
 // LDS-slab variant of the two row scatters: a workgroup owns (cloud, cc channels), accumulates every contribution to its
 // [n_dst][cc] slab with ds_add_f32 and adds the slab to the destination once with coalesced 16-byte read-modify-writes --
 // no global atomics (same idea as group_bwd_lds_kernel / interp_bwd_lds_kernel on the channel-major operators).
@@ -1090,6 +1138,35 @@ extern "C" int pn2x_sa_layer1_ld(int b, int n, int s, int k, int c1, const float
     const long total = (long)s * k * Q;
     hipLaunchKernelGGL(sa_layer1_kernel, dim3((unsigned)((total + kTT - 1) / kTT), b), dim3(kTT), 0, (hipStream_t)stream, n, s, k, Q, a1f,
                        a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out);
+    return check_launch();
+}
+
+// pn2x_sa_layer1_ld that also accumulates the BatchNorm statistics of its output into `sums` (pn2x_bn_sums_doubles(c1) doubles, zeroed
+// by the caller; the layout pn2x_bn_stats writes): in the same launch when the channel quads divide the workgroup, by a
+// pn2x_bn_stats launch behind it otherwise.
+extern "C" int pn2x_sa_layer1_stats(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
+                                    const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
+                                    double *sums, void *stream) {
+    using namespace pn2;
+    if (!sums) return PN2_ENULL;
+    const int Q = c1 >= 4 ? c1 / 4 : 1;
+    if (c1 % 4 || c1 < 4 || kTT % Q || (long)b * s * k > 2147483647L) {
+        const int rc = pn2x_sa_layer1_ld(b, n, s, k, c1, a1f, a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, stream);
+        if (rc != PN2_OK || b == 0 || s == 0) return rc;
+        return pn2x_bn_stats((long)b * s * k, c1, out, c1, sums, stream);
+    }
+    if (b < 0 || n < 1 || s < 0 || k < 1 || (xyz && wx_ld < 3)) return PN2_EINVAL;
+    if (b == 0 || s == 0) return PN2_OK;
+    if (!idx || !out || (!a1f && !xyz)) return PN2_ENULL;
+    if (xyz && (!cxyz || !wx)) return PN2_ENULL;
+    if ((a1f && (a1f_ld < c1 || a1f_ld % 4)) || (cadd && (cadd_ld < c1 || cadd_ld % 4))) return PN2_EINVAL;
+    if (((uintptr_t)a1f | (uintptr_t)cadd | (uintptr_t)out) % 16) return PN2_EINVAL;
+    const int rpp = kTT / Q, sk = s * k;
+    int rpb = (int)(((long)sk * b + 2047) / 2048);  // ~2048 workgroups on a large problem, at least 8 rows per thread
+    if (rpb < 8 * rpp) rpb = 8 * rpp;
+    rpb = (rpb + rpp - 1) / rpp * rpp;
+    hipLaunchKernelGGL(sa_layer1_stats_kernel, dim3((unsigned)((sk + rpb - 1) / rpb), b), dim3(kTT), 0, (hipStream_t)stream, n, s, k, Q, a1f,
+                       a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, rpb, sums);
     return check_launch();
 }
 

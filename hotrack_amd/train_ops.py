@@ -28,6 +28,10 @@ _lib.pn2x_three_interpolate_pm_grad.argtypes = [_ci, _ci, _ci, _ci, _vp, _ci, _v
 _lib.pn2x_sa_layer1.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_sa_layer1_ld.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp]
 _lib.pn2x_sa_layer1_ld.restype = _ci
+_lib.pn2x_sa_layer1_stats.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]
+_lib.pn2x_sa_layer1_stats.restype = _ci
+_lib.pn2x_bn_sums_doubles.argtypes = [_ci]
+_lib.pn2x_bn_sums_doubles.restype = _ci
 _lib.pn2x_rows_outer3.argtypes = [_cl, _ci, _vp, _ci, _vp, _vp, _vp, _cl, _vp]
 _lib.pn2x_rows_outer3.restype = _ci
 _lib.pn2x_rows_outer3_scratch_floats.argtypes = [_cl, _ci]
@@ -251,28 +255,35 @@ class _SaLayer1(torch.autograd.Function):
         idxs, wxs, invs = rest[:n_scales], rest[n_scales:2 * n_scales], rest[2 * n_scales:]
         B, N, _ = xyz.shape
         S = cxyz.shape[1]
-        outs, rels = [], []
+        outs, rels, sums = [], [], []
         col = 0
         st = _native._stream(xyz)
+        ws = aux.get("ws") if aux is not None else None  # the consumer stacks' workspace: BatchNorm statistics taken on the way
         for idx, wx in zip(idxs, wxs):
             K, C1 = idx.shape[2], wx.shape[0]
             out = torch.empty((B, S * K, C1), dtype=_f32, device=xyz.device)
             rel = torch.empty((B, S * K, 3), dtype=_f32, device=xyz.device)
             if wx.dim() != 2 or wx.shape[1] != 3 or wx.stride(1) != 1 or wx.dtype != _f32:
                 wx = wx.contiguous().float()
-            with torch.cuda.device(xyz.device):  # the (C1, 3) block is read in place (a column block of the layer's weight)
-                _native._check(_lib.pn2x_sa_layer1_ld(
-                    B, N, S, K, C1, None if a1f is None else a1f.data_ptr() + 4 * col, 0 if a1f is None else a1f.stride(1),
+            sm = ws.take(_lib.pn2x_bn_sums_doubles(C1)) if ws is not None else None
+            args = (B, N, S, K, C1, None if a1f is None else a1f.data_ptr() + 4 * col, 0 if a1f is None else a1f.stride(1),
                     xyz.data_ptr(), cxyz.data_ptr(), wx.data_ptr(), wx.stride(0) if C1 > 1 else 3,
                     None if cadd is None else cadd.data_ptr() + 4 * col,
                     0 if cadd is None else cadd.stride(1), _native._ptr(idx, "idx", torch.int32, B * S * K), out.data_ptr(),
-                    rel.data_ptr(), st), "sa_layer1")
+                    rel.data_ptr())
+            with torch.cuda.device(xyz.device):  # the (C1, 3) block is read in place (a column block of the layer's weight)
+                if sm is not None:
+                    _native._check(_lib.pn2x_sa_layer1_stats(*args, sm.data_ptr(), st), "sa_layer1_stats")
+                else:
+                    _native._check(_lib.pn2x_sa_layer1_ld(*args, st), "sa_layer1")
             outs.append(out)
             rels.append(rel)
+            sums.append(sm)
             col += C1
         ctx.aux = aux
         if aux is not None:
             aux["rel"], aux["dwx"] = list(rels), {}
+            aux["sums"] = {i: sm for i, sm in enumerate(sums) if sm is not None}  # layer-1 statistics for mlp_stack(aux=(aux, i))
         ctx.save_for_backward(*idxs, *rels, *invs)
         ctx.meta = (n_scales, None if a1f is None else tuple(a1f.shape), None if cadd is None else tuple(cadd.shape), S)
         return tuple(outs)
@@ -313,13 +324,16 @@ class _SaLayer1(torch.autograd.Function):
         return (d_a1f, d_cadd, None, None, None, None, *([None] * n), *d_wx, *([None] * len(invs)))
 
 
-def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs, invs=None, aux=None):
+def sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs, invs=None, aux=None, ws=None):
     """Layer-1 pre-activations of every scale of one SA module: list of (B, S*K_i, C1_i).
     a1f (B,N,sum C1) per-point feature terms [scale 0 | scale 1 ...] or None; cadd (B,S,sum C1) per-centroid terms or None;
     xyz (B,N,3), cxyz (B,S,3) (no gradient); idxs[i] (B,S,K_i) int32; wxs[i] (C1_i, 3).
     invs[i] = inverse_index(idxs[i].view(B, -1), N), computed by a caller that feeds the same neighbour lists to several modules
     (the backward inverts them itself otherwise).  aux: an empty dict shared with train_stack.mlp_stack(aux=(aux, i)) -- see
-    _SaLayer1.forward."""
+    _SaLayer1.forward.  ws (with aux): the Workspace of the stacks that will consume the outputs -- the kernel then also accumulates
+    each output's BatchNorm statistics into a slice of it (aux["sums"][i]) and the stack skips its own statistics pass."""
+    if aux is not None and ws is not None:
+        aux["ws"] = ws
     extra = [t for inv in invs for t in inv] if invs else []
     return list(_SaLayer1.apply(a1f, cadd, xyz, cxyz, len(idxs), aux, *idxs, *wxs, *extra))
 

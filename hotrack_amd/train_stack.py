@@ -226,8 +226,15 @@ class _Fwd:
         ws_f = [ws.take(_lib.pn2x_bn_sums_doubles(tensors[4 * i + 1].shape[0])) for i in range(L)]
         ws_b = [ws.take(_lib.pn2x_bn_sums_doubles(tensors[4 * i + 1].shape[0])) for i in range(L)]
         ys, saved = [y1], []
+        # the producer of y1 may have taken its statistics already (train_ops.sa_layer1(ws=...)): a slice of THIS workspace generation
+        pre = aux[0].get("sums", {}).pop(aux[1], None) if aux is not None else None
+        if pre is not None and pre.numel() == ws_f[0].numel() and pre.device == ws_f[0].device:
+            ws_f[0] = pre
+        else:
+            pre = None
         with torch.cuda.device(dev):
-            _native._check(_lib.pn2x_bn_stats(R, C1, py, ldy, ws_f[0].data_ptr(), st), "bn_stats")
+            if pre is None:
+                _native._check(_lib.pn2x_bn_stats(R, C1, py, ldy, ws_f[0].data_ptr(), st), "bn_stats")
             for i in range(1, L):
                 w, gamma_p, beta_p, bias_p = tensors[4 * i], tensors[4 * (i - 1) + 1], tensors[4 * (i - 1) + 2], tensors[4 * (i - 1) + 3]
                 bias_p = bias_p if bias_p.numel() else None

@@ -322,6 +322,12 @@ int pn2x_sa_layer1(int b, int n, int s, int k, int c1, const float *a1f, int a1f
 int pn2x_sa_layer1_ld(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
                       const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
                       void *stream);
+/* the same, also accumulating the BatchNorm statistics of `out` into sums (pn2x_bn_sums_doubles(c1) doubles, zeroed by the caller,
+ * as pn2x_bn_stats would): the layer that follows is a train-mode BatchNorm (pointnet_utils.py:399-401), and its separate
+ * statistics pass over the (b s k, c1) tensor -- one launch per scale and step -- is saved */
+int pn2x_sa_layer1_stats(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
+                         const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
+                         double *sums, void *stream);
 /*
  * Transpose of pn2x_gather_rows (group_points_grad on point-major rows, reference group_points_gpu.cu:8-25):
  *   din[b, idx[b,j], :] += dout[b, j, :]      dout (b, m, ldo), idx (b, m) int32, din (b, n, ldi) accumulated into.

@@ -17,6 +17,8 @@ The module path (pointnet_utils.py in this directory) remains the general fallba
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -145,7 +147,8 @@ class FastTrain:
             wc = w1[0][2] if len(w1) == 1 else torch.cat([w[2] for w in w1], dim=0)
             cadd = F.linear(center2d, wc).view(B, S, -1)
         aux = {} if self.use_fused_stacks else None  # relative coordinates -> the stacks, d(W_xyz) <- the stacks (train_ops.sa_layer1)
-        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1], invs=invs, aux=aux)
+        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1], invs=invs, aux=aux,
+                        ws=self.ws if os.environ.get("HOTRACK_SA1_STATS", "1") != "0" else None)
         outs = []
         pair = self._pair_stacks(mod, y1s, idxs, aux) if len(y1s) == 2 else None
         if pair is not None:  # both neighbourhood sizes layer by layer, equal-shaped fused launches grouped (train_stack.mlp_stack_pair)

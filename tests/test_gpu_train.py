@@ -239,6 +239,34 @@ def test_fast_train_path_equals_module_path():
             torch.testing.assert_close(bb[k], ba[k], rtol=1e-4, atol=3e-5, msg=lambda m: f"{k}: {m}")
 
 
+@pytest.mark.parametrize("C1,K", [(32, 32), (64, 32), (128, 16), (128, 64), (12, 7)])
+def test_sa_layer1_statistics_in_the_same_launch(C1, K):
+    """sa_layer1(ws=...): same outputs bit for bit, and the BatchNorm statistics it leaves in the workspace slice are what
+    pn2x_bn_stats computes from the output (fp64 accumulators of fp32 partial sums: equal to round-off); mlp_stack then takes
+    them instead of running its own pass (C1 = 12: channel quads that do not divide the workgroup -> the two-launch form inside)."""
+    import ctypes
+    from hotrack_amd import train_ops as T
+    B, N, S = 5, 700, 37
+    g = torch.Generator(device="cuda").manual_seed(C1 + K)
+    xyz, cxyz = torch.rand(B, N, 3, device="cuda", generator=g), torch.rand(B, S, 3, device="cuda", generator=g)
+    a1f, cadd = torch.randn(B, N, C1, device="cuda", generator=g), torch.randn(B, S, C1, device="cuda", generator=g)
+    idx = torch.randint(0, N, (B, S, K), device="cuda", generator=g, dtype=torch.int32)
+    wx = torch.randn(C1, 3, device="cuda", generator=g)
+    plain, = T.sa_layer1(a1f, cadd, xyz, cxyz, [idx], [wx])
+    ws, aux = T.Workspace("cuda"), {}
+    fused, = T.sa_layer1(a1f, cadd, xyz, cxyz, [idx], [wx], aux=aux, ws=ws)
+    assert torch.equal(plain, fused) and set(aux["sums"]) == {0}
+    ref = torch.zeros(T._lib.pn2x_bn_sums_doubles(C1), dtype=torch.float64, device="cuda")
+    T._native._check(T._lib.pn2x_bn_stats(B * S * K, C1, plain.data_ptr(), C1, ref.data_ptr(), T._native._stream(plain)), "bn_stats")
+    rep = ref.numel() // (2 * C1)
+    tot = lambda t: t.view(rep, 2, C1).sum(0)
+    y = plain.double().view(-1, C1)
+    exact = torch.stack([y.sum(0), (y * y).sum(0)])
+    scale = torch.stack([y.abs().sum(0), (y * y).sum(0)])  # fp32 partial sums of ~10 rows each, then fp64: ~1e-7 of the absolute sums
+    for got in (tot(aux["sums"][0]), tot(ref)):
+        assert float(((got - exact).abs() / scale).max()) < 2e-6, float(((got - exact).abs() / scale).max())
+
+
 def test_gather_rows_gradient_is_the_segment_sum():
     """train_ops.gather_rows == torch.index_select along the rows, forward (bit-exact) and backward (a repeated row receives the
     sum of its slots' gradients, an unused row exact zeros), incl. the static permutation of the rearrange modules."""
