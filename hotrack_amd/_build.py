@@ -94,12 +94,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if p.returncode:
             raise subprocess.CalledProcessError(p.returncode, cmd)
         # No kernel may use scratch (private) memory: a register array that hipcc leaves there costs 5-10x on a hot loop
-        #  and is invisible in the source.  PN2_ALLOW_SCRATCH=1 lets a tuning build through.
+        #  and is invisible in the source.  Register allocation belongs to the toolchain, though: a user's
+        # hipcc of another minor version that spills one register must still get a working library.  So: a WARNING that
+        # names the kernels by default; a build failure under PN2_STRICT_SCRATCH=1 (what __graft_entry__.build(), the
+        # tests and CI set -- the committed sources are held to zero scratch on the pinned toolchain).
         bad = scratch_kernels(p.stderr)
         if bad and os.environ.get("PN2_ALLOW_SCRATCH", "0") != "1":
-            if os.path.exists(obj):
-                os.remove(obj)
-            raise RuntimeError("%s: kernels with scratch memory (bytes/lane): %s" % (os.path.basename(src), bad))
+            msg = "%s: kernels with scratch memory (bytes/lane): %s" % (os.path.basename(src), bad)
+            if os.environ.get("PN2_STRICT_SCRATCH", "0") == "1":
+                if os.path.exists(obj):
+                    os.remove(obj)
+                raise RuntimeError(msg)
+            print("hotrack_amd build WARNING: " + msg + " -- expect these kernels to run several times slower than on the "
+                  "toolchain the sources were tuned with (ROCm 7.2 hipcc); PN2_STRICT_SCRATCH=1 turns this into an error",
+                  file=sys.stderr)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

@@ -209,8 +209,13 @@ int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const fl
 // Small batches only (the tracking loop): there the two launches are two links of a dependent chain of ~4 us launches; with
 // many clouds in flight the query workgroups do better without the check's 21 KB of static LDS (headline, same box: 88.5 k
 // frames/s with, 88.8 k without).
+// LDS: the tie check's static 21.5 KB (fps_tie_body: picks, check keys, chunk totals) ride on top of the query's dynamic cloud
+// tile (12 B per point, up to kBqTile points): held to 64 KB per workgroup in total -- the limit a launch gets without opting
+// in to more -- i.e. clouds of at most 3584 points take this path (larger clouds use the two separate launches).
+constexpr long kBallTieMaxN = (64 * 1024 - 22 * 1024) / 12 / 64 * 64;  // 3584
 bool ball_tie_supported(long b, long n, long m, long m2) {
-    return b >= 1 && m >= 1 && b * n <= 16384 && b * m < 2L * kBqWaves * 2048 && m2 >= 1 && m2 <= m && m2 <= kTieMaxM;
+    return b >= 1 && m >= 1 && n <= kBallTieMaxN && b * n <= 16384 && b * m < 2L * kBqWaves * 2048 && m2 >= 1 && m2 <= m &&
+           m2 <= kTieMaxM;
 }
 
 int ball_tie_dispatch(int b, int n, int m, float radius, int nsample, const float *xyz, int *idx, const int *picks, float *new_xyz_out,

@@ -232,7 +232,7 @@ class _Fwd:
             ws_f[0] = pre
         else:
             pre = None
-        with torch.cuda.device(dev):
+        with _guarded_by_drive(dev):
             if pre is None:
                 _native._check(_lib.pn2x_bn_stats(R, C1, py, ldy, ws_f[0].data_ptr(), st), "bn_stats")
             for i in range(1, L):
@@ -325,7 +325,7 @@ class _Bwd:
             _pending_params.update(t.data_ptr() for t in dparams)
         gam = lambda i: tensors[4 * i + 1]
         bet = lambda i: tensors[4 * i + 2]
-        with torch.cuda.device(dev):
+        with _guarded_by_drive(dev):
             yl, svl = ys[L - 1], saved[L - 1]
             Cl = yl.shape[1]
             g, gmode = dout, (2 if K else 1)
@@ -470,39 +470,63 @@ def _issue_pair(a, b):
         return int(nparts[0]), int(nparts[1])
 
 
-def _drive(gens):
-    """Run the stack generators in lockstep; returns their return values."""
+class _guarded_by_drive:
+    """What the stack generators wrap their launches in: nothing.  A generator that yields from inside `torch.cuda.device(dev)`
+    enters and leaves that guard out of LIFO order when two of them run in lockstep (the one that finishes first restores the
+    previous device under the other's feet: its remaining direct launches would go to the wrong device when the model is not on
+    the current one).  _drive() holds ONE guard around the whole lockstep loop instead; this context only checks that."""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def __enter__(self):
+        if self.dev.type == "cuda" and torch.cuda.current_device() != (self.dev.index if self.dev.index is not None else torch.cuda.current_device()):
+            raise RuntimeError("train_stack: a stack generator must be advanced by _drive() (device guard)")
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _drive(gens, dev):
+    """Run the stack generators in lockstep under ONE device guard; returns their return values.  Whatever happens, no
+    generator is left suspended (a generator that outlives an exception of its sibling would run its cleanup at GC time)."""
     n = len(gens)
     results, answer, alive = [None] * n, [None] * n, list(range(n))
-    while alive:
-        reqs = {}
-        for i in list(alive):
-            try:
-                reqs[i] = gens[i].send(answer[i])
-            except StopIteration as stop:
-                results[i] = stop.value
-                alive.remove(i)
-            answer[i] = None
-        if len(reqs) == 2 and _pairable(*reqs.values()):
-            (i, a), (j, b) = reqs.items()
-            answer[i], answer[j] = _issue_pair(a, b)
-        else:
-            for i, r in reqs.items():
-                answer[i] = _issue(r)
+    try:
+        with torch.cuda.device(dev):
+            while alive:
+                reqs = {}
+                for i in list(alive):
+                    try:
+                        reqs[i] = gens[i].send(answer[i])
+                    except StopIteration as stop:
+                        results[i] = stop.value
+                        alive.remove(i)
+                    answer[i] = None
+                if len(reqs) == 2 and _pairable(*reqs.values()):
+                    (i, a), (j, b) = reqs.items()
+                    answer[i], answer[j] = _issue_pair(a, b)
+                else:
+                    for i, r in reqs.items():
+                        answer[i] = _issue(r)
+    finally:
+        for g in gens:
+            g.close()
     return results
 
 
 class _Stack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y1, K, ws, metas, aux, *tensors):
-        (out, saved, info), = _drive([_Fwd.gen(y1, K, ws, metas, aux, tensors)])
+        (out, saved, info), = _drive([_Fwd.gen(y1, K, ws, metas, aux, tensors)], y1.device)
         ctx.save_for_backward(*saved)
         ctx.info = info
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (dy1, grads), = _drive([_Bwd.gen(ctx.info, ctx.saved_tensors, dout)])
+        (dy1, grads), = _drive([_Bwd.gen(ctx.info, ctx.saved_tensors, dout)], dout.device)
         return (dy1, None, None, None, None, *grads)
 
 
@@ -511,7 +535,7 @@ class _StackPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y1a, y1b, Ka, Kb, ws, metas_a, metas_b, aux_a, aux_b, n_a, *tensors):
-        ra, rb = _drive([_Fwd.gen(y1a, Ka, ws, metas_a, aux_a, tensors[:n_a]), _Fwd.gen(y1b, Kb, ws, metas_b, aux_b, tensors[n_a:])])
+        ra, rb = _drive([_Fwd.gen(y1a, Ka, ws, metas_a, aux_a, tensors[:n_a]), _Fwd.gen(y1b, Kb, ws, metas_b, aux_b, tensors[n_a:])], y1a.device)
         ctx.save_for_backward(*ra[1], *rb[1])
         ctx.split, ctx.infos = len(ra[1]), (ra[2], rb[2])
         return ra[0], rb[0]
@@ -519,7 +543,7 @@ class _StackPair(torch.autograd.Function):
     @staticmethod
     def backward(ctx, da, db):
         t = ctx.saved_tensors
-        ra, rb = _drive([_Bwd.gen(ctx.infos[0], t[:ctx.split], da), _Bwd.gen(ctx.infos[1], t[ctx.split:], db)])
+        ra, rb = _drive([_Bwd.gen(ctx.infos[0], t[:ctx.split], da), _Bwd.gen(ctx.infos[1], t[ctx.split:], db)], da.device)
         return (ra[0], rb[0], None, None, None, None, None, None, None, None, *ra[1], *rb[1])
 
 

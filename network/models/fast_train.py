@@ -264,6 +264,7 @@ class FastTrain:
         l1_out = self._fp(bh.fp2, l1_xyz, l2_xyz, l1_feat, l2_out, nn3=geo["fp2"]).view(B, S1, -1)
         # fp1 (skip = xyz) and the backbone's conv1 / bn1 as one stack [131 -> 128 -> 128 -> C]
         src2 = self._fp(bh.fp1, xyz, l1_xyz, xyz, l1_out, extra=(bh.conv1, bh.bn1), nn3=geo["fp1"])    # (B*N, C)
+        src2 = net.cut_after_backbone(src2)  # (a fresh leaf when the trainer runs the backward in two segments: hand_network.py)
         C = src2.shape[1]
 
         # ---- q1 -> r1 -> q2 -> r2 around the J keypoints; one kNN search for both neighbourhood sizes ------------------
@@ -321,8 +322,20 @@ class FastTail:
                 import torch.distributed as dist
                 rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
                 start = ((int(torch.initial_seed()) * 0x9E3779B97F4A7C15) ^ ((rank + 1) * 0xD1B54A32D192ED03)) & ((1 << 62) - 1)
+            self._start = start
             self.seed = torch.full((1,), start, dtype=torch.int64, device=dev)
         return self.seed
+
+    def rewind_dropout_counter(self, snapshot=None):
+        """Put the device counter back (in place: captured graphs hold its address): to `snapshot` (a clone taken earlier), or to
+        the value it was created with when no snapshot exists (the counter was created after the caller's snapshot point).  The
+        trainer's capture warm-up runs forwards whose effects must not be seen by the step that follows."""
+        if self.seed is None:
+            return
+        if snapshot is not None:
+            self.seed.copy_(snapshot)
+        else:
+            self.seed.fill_(int(self._start))
 
     def dropout_state(self) -> int:
         """The counter's current value (a host read: checkpoint time only); None before the first forward."""

@@ -96,6 +96,13 @@ class HandTrackNet(nn.Module):
         self.use_fast_tail = True  # training on the GPU: the 21-token tail with fused element-wise runs (fast_train.FastTail)
         self._ftail = None
         self._ftrain = None
+        # Segmented backward (network/trainer.py, dp = flat): when set, a TRAINING forward detaches the backbone's output
+        # features (the only tensor that joins the backbone to everything after it) and leaves (backbone output, detached leaf)
+        # in `backward_cut`; the caller then runs loss.backward() -- which stops at the leaf: gradients of q1 / r1 / q2 / r2 /
+        # tail are complete -- and later backbone_output.backward(leaf.grad).  Same gradients as one pass; the exchange of the
+        # first segment's gradients can travel while the backbone's backward runs.
+        self.cut_backbone_grad = False
+        self.backward_cut = None
         self.bhand = PointNet2Msg_fast(cfg, C)
         self.r1 = rearrange_module(channel=C)
         self.r2 = rearrange_module(channel=C)
@@ -125,6 +132,19 @@ class HandTrackNet(nn.Module):
     def _fast_train_frame_ok(self, hand_points, palm_template, kp_num, use_ft) -> bool:
         return bool(self.training and use_ft and self.handframe == "kp" and self.elide_dead_attention and hand_points.is_cuda
                     and kp_num == 21 and palm_template.shape[-2] == 6 and pointnet_utils.hip_backend_active())
+
+    def cut_after_backbone(self, feat):
+        """The backbone's output features, detached into a fresh leaf when a segmented backward was asked for (see __init__)."""
+        self.backward_cut = None
+        if self.cut_backbone_grad and self.training and torch.is_grad_enabled() and feat.requires_grad:
+            leaf = feat.detach().requires_grad_(True)
+            self.backward_cut = (feat, leaf)
+            return leaf
+        return feat
+
+    def segment_upstream_parameters(self):
+        """Parameters whose gradients are complete only after the SECOND segment of a cut backward (the backbone's)."""
+        return list(self.bhand.parameters())
 
     def precompute_geometry(self, input, flag_dict):
         """The part of a TRAINING step on the GPU that depends on the batch only, not on the parameters: the hand frame (Kabsch of
@@ -232,7 +252,7 @@ class HandTrackNet(nn.Module):
             src2 = None if elide else src2_pm.transpose(1, 2)
         else:
             xyz2, xyz1 = xyz2.contiguous(), xyz1.contiguous()
-            src2 = self.bhand(xyz2)  # (B,C,N)
+            src2 = self.cut_after_backbone(self.bhand(xyz2))  # (B,C,N)
             f11, group_idx = self.q1(xyz2, src2, xyz1, None, return_group_idx=True)
             f12 = self.r1(f11, True)
             f13 = self.q2(xyz2, src2, xyz1, f12, pre_group_idx=group_idx)

@@ -133,7 +133,17 @@ class Trainer(nn.Module):
         # captured HIP graphs under data parallelism (graph: forward+backward | eager: RCCL all-reduce of 16.7 MB | graph:
         # Adam); parameters that never receive a gradient keep grad=None on every rank, exactly as with "ddp".
         self.dp_mode = cfg.get("dp", "flat" if getattr(self, "graph_step", False) else "ddp") if self.world > 1 else None
-        self._flat = self._flat_grads = self._opt_graph = None
+        if (self.world == 1 and dist.is_available() and dist.is_initialized() and self.optimizer is not None
+                and str(cfg.get("dp_force", os.environ.get("HOTRACK_DP_FORCE", ""))) == "flat"):
+            self.dp_mode = "flat"  # a one-rank process group: the exchange path end to end on one GPU (bench_train.py --dp-selftest)
+        # "flat", backward in SEGMENTS (default 2: everything after the backbone | the backbone): the first segment's gradients
+        # (14.5 of the 16.7 MB) are exchanged while the second segment's backward runs; only the last segment's exchange is
+        # exposed.  bwd_segments: 1 restores the single exchange after the whole backward.  dp_overlap: False keeps the segments
+        # but issues every exchange in stream order (A/B measurements).
+        self.bwd_segments = int(cfg.get("bwd_segments", os.environ.get("HOTRACK_BWD_SEGMENTS", "2")))
+        self.dp_overlap = bool(cfg.get("dp_overlap", os.environ.get("HOTRACK_DP_OVERLAP", "1") == "1"))
+        self._segs, self._active_segs = {}, []
+        self._opt_graph = self._graph_rest = self._comm_stream = self._seg_done = None
         if self.world > 1 and self.optimizer is not None:
             if self.dp_mode == "ddp":
                 if torch.cuda.is_available():  # DDP's bucket hooks read .grad inside the pass: no deferred weight-gradient sums
@@ -270,19 +280,43 @@ class Trainer(nn.Module):
         return self._step_impl(data, zero)
 
     def _step_impl(self, data, zero=True):
-        loss_dict = self._forward_backward(data, zero)
-        if self.dp_mode == "flat":
-            self._allreduce_flat()
-            self._scatter_flat()
+        if self.dp_mode != "flat":
+            loss_dict = self._forward_backward(data, zero)
+            self.optimizer.step()
+            return loss_dict
+        # "flat", eager: segment 0's exchange is in flight (async) while segment 1's backward is issued
+        loss_dict, cut = self._fb_head(data, zero)
+        self._pack_segment(0, cut is not None)
+        works = [self._exchange(0, async_op=cut is not None and self.dp_overlap)]
+        if cut is not None:
+            self._fb_rest(cut)
+            self._pack_segment(1, True)
+            works.append(self._exchange(1))
+        self._finish_exchange(works)
+        self._scatter_flat()
         self.optimizer.step()
         return loss_dict
 
     def _forward_backward(self, data, zero=True, geo=None):
+        """Forward, loss and the whole backward (both segments when the model was cut), no gradient exchange."""
+        loss_dict, cut = self._fb_head(data, zero, geo)
+        if cut is not None:
+            self._fb_rest(cut)
+        return loss_dict
+
+    def _fb_head(self, data, zero=True, geo=None):
+        """Forward + loss + the backward down to the backbone cut (the whole backward when the model is not cut: one segment,
+        "ddp", single process).  Returns (loss dict, cut | None); cut = (backbone output, its detached leaf) for _fb_rest."""
         if zero:
             self.optimizer.zero_grad()
         flags = self.init_flag_dict()
         if geo is not None:  # this batch's precomputed geometry (static buffers of the captured step)
             data = dict(data, _geometry=geo)
+        net = self._bare_model()
+        can_cut = hasattr(net, "cut_backbone_grad")
+        seg = can_cut and self.dp_mode == "flat" and self.bwd_segments > 1
+        if can_cut:
+            net.cut_backbone_grad, net.backward_cut = seg, None
         if self.ddp is not None:
             loss_dict = self.ddp(data, flags)  # forward + compute_loss inside the DDP-wrapped module
         else:
@@ -290,31 +324,86 @@ class Trainer(nn.Module):
             loss_dict, _ = self.model.compute_loss(data, ret, flags)
         loss_dict = self.summarize_losses(loss_dict)
         loss_dict["total_loss"].backward()  # "ddp": bucketed all-reduce overlapped with backward
-        return loss_dict
+        cut = None
+        if seg:
+            cut, net.backward_cut = net.backward_cut, None
+        return loss_dict, cut
 
-    # ---- "flat" data parallelism: one all-reduce of all gradients -----------------------------------------------------
-    def _allreduce_flat(self):
-        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-        if not grads:
-            return  # nothing received a gradient on this rank (and, by the layout check below, on no rank)
+    @staticmethod
+    def _fb_rest(cut):
+        """Second segment: the backbone's backward from the gradient that segment 1 left at the cut."""
+        out, leaf = cut
+        g, leaf.grad = leaf.grad, None
+        if g is not None:
+            out.backward(g)
+
+    # ---- "flat" data parallelism: one all-reduce per backward segment, over flat gradient buffers ---------------------------
+    def _segment_params(self, s, cut_exists):
+        """Parameters whose gradients are complete once segment s has run (in parameter order: the same on every rank)."""
+        params = [p for p in self.model.parameters() if p.grad is not None]
+        if not cut_exists:
+            return params
+        up = {id(p) for p in self._bare_model().segment_upstream_parameters()}
+        if s == 0 and any(id(p) in up for p in params):
+            raise RuntimeError("dp=flat: a parameter upstream of the backward cut received a gradient in the first segment "
+                               "(the model's cut does not separate its parameters); use bwd_segments=1")
+        return [p for p in params if (id(p) in up) == (s == 1)]
+
+    def _pack_segment(self, s, cut_exists, in_capture=False):
+        """Segment s's gradients -> its flat buffer (one concatenation).  in_capture: the buffer is allocated by the
+        concatenation itself (from the capturing graph's pool) and re-filled by every replay."""
+        params = self._segment_params(s, cut_exists)
+        grads = [p.grad for p in params]
         n = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
-            self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
-            self._check_flat_layout(n, len(grads))
-        self._flat_grads = grads
-        torch.cat([g.reshape(-1) for g in grads], out=self._flat)
-        if dist.get_backend() == "nccl":
-            dist.all_reduce(self._flat, op=dist.ReduceOp.AVG)  # RCCL over xGMI: one 16.7 MB ring / tree all-reduce
-        else:
-            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
-            self._flat.div_(self.world)
+        if s == 0:
+            self._active_segs = []
+        self._active_segs.append(s)
+        seg = self._segs.get(s)
+        dev = grads[0].device if grads else torch.device(self.device)
+        if in_capture or seg is None or seg["flat"].numel() != n or seg["flat"].device != dev or seg["count"] != len(grads):
+            flat = (torch.cat([g.reshape(-1) for g in grads]) if (in_capture and grads) else
+                    torch.empty(n, dtype=grads[0].dtype if grads else torch.float32, device=dev))
+            seg = self._segs[s] = {"flat": flat, "count": len(grads), "checked": False}
+            if in_capture:
+                seg["grads"] = grads
+                return
+        seg["grads"] = grads
+        if grads:
+            torch.cat([g.reshape(-1) for g in grads], out=seg["flat"])
 
-    def _check_flat_layout(self, numel, count):
+    def _exchange(self, s, async_op=False):
+        """All-reduce (mean) of segment s's flat buffer; returns the work handle (async_op) or None.  Never inside a capture."""
+        seg = self._segs[s]
+        flat = seg["flat"]
+        if not seg["checked"]:
+            self._check_flat_layout(flat, seg["count"])
+            seg["checked"] = True
+        if flat.numel() == 0:
+            return None  # nothing received a gradient in this segment on this rank (and, by the layout check, on no rank)
+        if dist.get_backend() == "nccl":
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=async_op)  # RCCL over xGMI: ring / tree all-reduce
+        w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        seg["divide"] = True
+        return w
+
+    def _finish_exchange(self, works):
+        """Order the step's stream behind the exchanges (the current stream waits for the collective's stream: the direction
+        that costs nothing on this runtime); backends without a mean reduce divide here."""
+        for w in works:
+            if w is not None:
+                w.wait()
+        for s in self._active_segs:
+            seg = self._segs[s]
+            if seg.pop("divide", False):
+                seg["flat"].div_(self.world)
+
+    def _check_flat_layout(self, flat, count):
         """The flat exchange assumes every rank holds the same set of non-None gradients (same code path, same shapes: a
-        DistributedSampler with drop_last).  Checked whenever the layout is (re)built -- on every rank at the same step if the
-        assumption holds; a mismatch raises on all ranks instead of silently misaligning gradients."""
+        DistributedSampler with drop_last).  Checked whenever a segment's layout is (re)built -- on every rank at the same step
+        if the assumption holds; a mismatch raises on all ranks instead of silently misaligning gradients."""
+        numel = flat.numel()
         t = torch.tensor([numel, -numel, count, -count], dtype=torch.int64,
-                         device=self._flat.device if dist.get_backend() == "nccl" else "cpu")
+                         device=flat.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         mx_n, mn_n, mx_c, mn_c = int(t[0]), -int(t[1]), int(t[2]), -int(t[3])
         if mx_n != mn_n or mx_c != mn_c:
@@ -331,13 +420,25 @@ class Trainer(nn.Module):
         return bool(int(t[0]))
 
     def _scatter_flat(self):
-        if not self._flat_grads:
-            return
-        views, off = [], 0
-        for g in self._flat_grads:
-            views.append(self._flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
-        torch._foreach_copy_(self._flat_grads, views)
+        """The exchanged flat buffers of this step's segments back into the parameters' .grad tensors (one multi-tensor copy)."""
+        dst, views = [], []
+        for s in self._active_segs:
+            seg, off = self._segs[s], 0
+            for g in seg["grads"]:
+                views.append(seg["flat"][off:off + g.numel()].view_as(g))
+                dst.append(g)
+                off += g.numel()
+        if dst:
+            torch._foreach_copy_(dst, views)
+
+    @property
+    def _flat(self):
+        """(compatibility: benches read the exchanged bytes) every segment's flat buffer, in segment order."""
+        return [self._segs[s]["flat"] for s in sorted(self._segs)] or None
+
+    def _allreduce_flat(self):
+        """All segments' exchanges back to back on the current stream (what a step costs in exchange alone: bench legs)."""
+        self._finish_exchange([self._exchange(s) for s in self._active_segs])
 
     def update(self, data, next_data=None):
         """One training step on `data`.  next_data: the batch the NEXT call will be given (the same object), if the loop knows
@@ -357,7 +458,7 @@ class Trainer(nn.Module):
                     torch.cuda.synchronize()
                 if not self._agree(err is None):
                     self.log_string(f"graph_step disabled ({err or 'capture failed on another rank'})")
-                    self.graph_step, self._graph, self._opt_graph = False, None, None
+                    self.graph_step, self._graph, self._opt_graph, self._graph_rest = False, None, None, None
             if self.graph_step:
                 loss_dict = dict(self._graphed_step(data, sig, next_data))
         if loss_dict is None:
@@ -430,8 +531,28 @@ class Trainer(nn.Module):
             self._geometry_for(data, next_data)
         self._copy_leaves(self._static, data)
         self._graph.replay()
-        if self._opt_graph is not None:  # data parallel: forward+backward graph | eager all-reduce | optimiser graph
-            self._allreduce_flat()
+        if self._opt_graph is not None:
+            # data parallel: [forward + backward segment 0 + pack] | [backward segment 1 + pack] | exchanges | [scatter + Adam].
+            # Segment 0's exchange runs on the collective's own stream beside graph 2.  The step's stream never records an
+            # event that another stream waits for (that stalls it by 50-200 us on this runtime: profiles/r04_two_graph_overlap.txt):
+            # the HOST waits for graph 1 (an event nobody waits for on the device) and then issues the collective from an idle
+            # stream; the step's stream only ever waits FOR the collective (free).
+            works = []
+            if self._graph_rest is not None:
+                cur = torch.cuda.current_stream()
+                if self.dp_overlap:
+                    self._seg_done.record(cur)
+                self._graph_rest.replay()
+                if self.dp_overlap:
+                    self._seg_done.synchronize()
+                    with torch.cuda.stream(self._comm_stream):
+                        works.append(self._exchange(0, async_op=True))
+                else:
+                    works.append(self._exchange(0))
+                works.append(self._exchange(1, async_op=self.dp_overlap))
+            else:
+                works.append(self._exchange(0))
+            self._finish_exchange(works)
             self._opt_graph.replay()
         return self._static_loss
 
@@ -457,20 +578,29 @@ class Trainer(nn.Module):
         # with and the optimizer state tensors the graph will update already exist (creating them inside the capture
         # would replay their zero-fill every step).
         model_snap = {k: v.clone() for k, v in self.model.state_dict().items()}
+        tail = getattr(self._bare_model(), "_ftail", None)
+        seed_snap = tail.seed.clone() if tail and tail.seed is not None else None  # the fused tail's device dropout counter
         opt_snap = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.optimizer.state.items()}
         flat = self.dp_mode == "flat"
         err = None
         # HOTRACK_KEEP_GRAPH=1: keep the hipGraph_t next to its executable (bench legs count its kernel nodes)
         keep = {"keep_graph": True} if os.environ.get("HOTRACK_KEEP_GRAPH", "0") == "1" else {}
         graph = torch.cuda.CUDAGraph(**keep)
-        self._opt_graph = None
+        self._opt_graph = self._graph_rest = None
+        self._segs, self._active_segs = {}, []  # flat buffers of an earlier capture belong to its pool
+        rest = None
         from hotrack_amd import gemm_tuning
         try:
             # The warm-up steps are LOCAL (no gradient exchange: their effect is undone below anyway).  A rank that raises here
             # has therefore issued exactly as many collectives as its peers -- none -- when the ranks agree below (ADVICE r3:
             # with the all-reduce inside the warm-up a failing rank met its peers' all-reduce with the agreement's).
             if self.prefetch_geometry and hasattr(self._bare_model(), "precompute_geometry"):
-                self._capture_geometry(clone(data))  # (inside the try: under dp=flat every failure is agreed on below)
+                try:
+                    self._capture_geometry(clone(data))
+                except Exception as exc:  # (TypeError of _tree_flatten included) no prefetch: the step runs its geometry in line
+                    torch.cuda.synchronize()
+                    self._geo_graph = self._static_geo = self._geo_ready_for = None
+                    self.log_string(f"geometry prefetch disabled for this batch shape ({exc})")
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             try:
@@ -487,12 +617,25 @@ class Trainer(nn.Module):
                         for k, v in st.items():
                             if torch.is_tensor(v):
                                 v.copy_(opt_snap[p][k]) if p in opt_snap else v.zero_()
+                    # the warm-up forwards advanced the fused tail's dropout counter: a captured / resumed run must draw the
+                    # masks an uninterrupted eager run draws; a counter created BY the warm-up goes back to its start value
+                    tail = getattr(self._bare_model(), "_ftail", None)
+                    if tail:
+                        tail.rewind_dropout_counter(seed_snap)
                 self.optimizer.zero_grad(set_to_none=True)
             with gemm_tuning.scope():
                 with torch.cuda.graph(graph):
-                    self._static_loss = self._forward_backward(self._static, zero=False, geo=self._static_geo)
-                    if not flat:
+                    self._static_loss, cut = self._fb_head(self._static, zero=False, geo=self._static_geo)
+                    if flat:
+                        self._pack_segment(0, cut is not None, in_capture=True)
+                    else:
                         self.optimizer.step()
+                if cut is not None:  # (flat only) the backbone's backward as its own graph: segment 0 travels beside it
+                    rest = torch.cuda.CUDAGraph(**keep)
+                    with torch.cuda.graph(rest, pool=graph.pool()):
+                        self._fb_rest(cut)
+                        self._pack_segment(1, True, in_capture=True)
+                del cut
         except RuntimeError as exc:
             err = exc
             torch.cuda.synchronize()
@@ -501,12 +644,14 @@ class Trainer(nn.Module):
             if not self._agree(err is None):
                 raise RuntimeError(f"graph capture failed ({err or 'on another rank'})")
             with gemm_tuning.scope():
-                self._allreduce_flat()  # eager (collectives stay outside the graphs); also fixes the flat buffer / gradient list
+                self._allreduce_flat()  # eager (collectives stay outside the graphs); also the collective layout checks
                 opt_graph = torch.cuda.CUDAGraph(**keep)
                 with torch.cuda.graph(opt_graph, pool=graph.pool()):
                     self._scatter_flat()
                     self.optimizer.step()
-            self._opt_graph = opt_graph
+            self._opt_graph, self._graph_rest = opt_graph, rest
+            if rest is not None and self._comm_stream is None:
+                self._comm_stream, self._seg_done = torch.cuda.Stream(), torch.cuda.Event()
         elif err is not None:
             raise err
         self._graph, self._graph_sig = graph, sig
@@ -527,7 +672,8 @@ class Trainer(nn.Module):
         if geo is None:
             return
         leaves, spec = _tree_flatten(geo)
-        assert all(t.dtype in (torch.float32, torch.int32) for t in leaves), "geometry leaves are 4-byte tensors"
+        if not all(t.dtype in (torch.float32, torch.int32) for t in leaves):
+            raise RuntimeError("geometry prefetch: geometry leaves must be 4-byte tensors")
         dev = leaves[0].device
         graph = torch.cuda.CUDAGraph(**({"keep_graph": True} if os.environ.get("HOTRACK_KEEP_GRAPH", "0") == "1" else {}))
         with torch.cuda.graph(graph, stream=side):
@@ -535,7 +681,8 @@ class Trainer(nn.Module):
         # the captured outputs live at fixed addresses of the graph's pool: flat int32 views of them, interleaved with zero pads
         # so that every leaf starts 16-byte aligned in the pack (the kernels of the dense step load rows as float4 / int4)
         outs = [t.contiguous().view(-1).view(torch.int32) for t in _tree_flatten(geo)[0]]
-        assert all(o.data_ptr() == t.data_ptr() for o, t in zip(outs, _tree_flatten(geo)[0])), "geometry outputs are contiguous"
+        if not all(o.data_ptr() == t.data_ptr() for o, t in zip(outs, _tree_flatten(geo)[0])):
+            raise RuntimeError("geometry prefetch: geometry outputs must be contiguous")
         srcs, offs, total = [], [], 0
         for o in outs:
             offs.append(total)

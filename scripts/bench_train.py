@@ -13,7 +13,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce=True):
+def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce=True, cfg_extra=None):
     """configs[2] per GPU on an already initialised process group (or a single process): returns the result dict (every
     rank; times are max over ranks).  Used by main() below and by bench.py's `train` leg when WORLD_SIZE > 1."""
     os.environ.setdefault("HOTRACK_DATA_ROOT", "/tmp/hotrack_bench_data")
@@ -24,7 +24,8 @@ def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce
     args = add_args(argparse.ArgumentParser()).parse_args(["--config", "handtracknet_train_SimGrasp.yml"])
     args.num_points, args.batch_size = 1024, batch
     cfg = get_config(args, save=False)
-    cfg["graph_step"] = graph  # data parallel: forward+backward graph | eager flat all-reduce | Adam graph
+    cfg["graph_step"] = graph  # data parallel: forward+backward graphs (two segments) | flat all-reduces | Adam graph
+    cfg.update(cfg_extra or {})
     torch.manual_seed(0)
     tr = Trainer(cfg)
     tr.step_epoch()
@@ -62,7 +63,8 @@ def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce
     launches = None
     if getattr(tr, "_graph", None) is not None:
         from hotrack_amd.graph_utils import kernel_nodes
-        parts = [kernel_nodes(g) for g in (tr._graph, tr._opt_graph, getattr(tr, "_geo_graph", None)) if g is not None]
+        parts = [kernel_nodes(g) for g in (tr._graph, getattr(tr, "_graph_rest", None), tr._opt_graph, getattr(tr, "_geo_graph", None))
+                 if g is not None]
         launches = sum(parts) if parts and all(p is not None for p in parts) else None
     res = {"metric": "HandTrackNet training frames/sec (N=1024)", "value": round(batch * world * steps / dt, 1),
            "launches": launches, "tflops": round(flops / (dt / steps) / 1e12, 2),
@@ -71,18 +73,29 @@ def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce
            "scaling": "weak", "graph_step": bool(getattr(tr, "graph_step", False)), "dp_mode": tr.dp_mode,
            "geometry_prefetch": getattr(tr, "_geo_graph", None) is not None,
            "loss": float(loss["total_loss"]), "dtype": "f32", "data": "synthetic"}
-    if world > 1:
+    if tr.dp_mode is not None:
         res["backend"] = dist.get_backend()  # "nccl" = RCCL on ROCm
         res["world_size_seen_by_backend"] = dist.get_world_size()
+        res["bwd_segments"] = 2 if getattr(tr, "_graph_rest", None) is not None else 1
+        res["dp_overlap"] = bool(tr.dp_overlap) and res["bwd_segments"] > 1
         if measure_allreduce and tr.dp_mode == "flat" and tr._flat is not None:
-            # the gradient exchange alone: the same flat buffer the step all-reduces, K times back to back
+            # the gradient exchange alone: the same flat buffers the step all-reduces (one per backward segment), K times back to
+            # back; the LAST segment's is the one a step cannot hide (the others travel beside the next segment's backward)
             sync()
             t0 = time.perf_counter()
             for _ in range(20):
                 tr._allreduce_flat()
             sync()
             res["allreduce_us"] = round(reduce_max(time.perf_counter() - t0) / 20 * 1e6, 1)
-            res["bytes"] = int(tr._flat.numel() * tr._flat.element_size())
+            res["segment_bytes"] = [int(f.numel() * f.element_size()) for f in tr._flat]
+            res["bytes"] = int(sum(res["segment_bytes"]))
+            last = sorted(tr._segs)[-1]
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                tr._finish_exchange([tr._exchange(last)])
+            sync()
+            res["exposed_allreduce_us"] = round(reduce_max(time.perf_counter() - t0) / 20 * 1e6, 1)
             # ring all-reduce moves 2 (N-1)/N of the buffer per rank
             res["allreduce_busbw_GBs"] = round(2 * (world - 1) / world * res["bytes"] / (res["allreduce_us"] * 1e-6) / 1e9, 2)
     return res
@@ -94,18 +107,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--graph", action="store_true", help="whole-step HIP graph (single GPU)")
+    ap.add_argument("--dp-selftest", action="store_true",
+                    help="ONE rank with a one-rank process group and dp=flat: the segmented backward + exchange path end to end "
+                         "on one GPU (what it costs beside the single-graph step; the all-reduce is RCCL's one-rank path)")
+    ap.add_argument("--segments", type=int, default=None, help="dp=flat: backward segments (default 2)")
+    ap.add_argument("--no-overlap", action="store_true", help="dp=flat: exchanges in stream order (A/B)")
     a = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local % torch.cuda.device_count())
     if os.environ.get("PN2_BENCH_FAIL_TRAIN_LEG", "") == str(rank):  # harness self-test: this rank's training leg dies
         raise RuntimeError("injected failure of the training leg on rank %d (PN2_BENCH_FAIL_TRAIN_LEG)" % rank)
-    if world > 1:
+    extra = {}
+    if a.segments is not None:
+        extra["bwd_segments"] = a.segments
+    if a.no_overlap:
+        extra["dp_overlap"] = False
+    if world > 1 or a.dp_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("PN2_DIST_BACKEND", "nccl"))  # gloo: several ranks on one GPU (self-test)
-    res = run_training_leg(a.steps, a.warmup, a.batch, a.graph, rank, world)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(os.environ.get("PN2_DIST_BACKEND", "nccl"), rank=rank, world_size=world)  # gloo: several ranks on one GPU (self-test)
+        if world == 1:
+            extra["dp_force"] = "flat"
+    res = run_training_leg(a.steps, a.warmup, a.batch, a.graph, rank, world, cfg_extra=extra)
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

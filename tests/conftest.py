@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("PN2_STRICT_SCRATCH", "1")  # tests / CI: a kernel with scratch memory fails the build (users get a warning)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -310,7 +310,9 @@ def test_ball_query_tie_check_colaunch_equals_separate_launches(monkeypatch):
     assert ext.BALL_TIE_COLAUNCH
     cases = [(1, 1024, 256, 128, 0.1, 32, "hand"), (16, 1024, 256, 128, 0.1, 32, "hand"), (3, 1000, 256, 128, 0.2, 16, "uniform"),
              (2, 1024, 256, 128, 0.15, 32, "lattice"), (2, 512, 128, 64, 0.3, 8, "dup"), (2, 343, 100, 100, 0.5, 64, "lattice"),
-             (6, 2560, 512, 128, 0.1, 32, "uniform"), (1, 21, 8, 4, 1.0, 4, "uniform"), (64, 1024, 256, 128, 0.1, 32, "hand")]
+             (6, 2560, 512, 128, 0.1, 32, "uniform"), (1, 21, 8, 4, 1.0, 4, "uniform"),
+             (1, 3584, 512, 128, 0.1, 32, "uniform"),   # the largest cloud of the co-launch: 42 KB tile + 21.5 KB static LDS <= 64 KB
+             (64, 1024, 256, 128, 0.1, 32, "hand"), (1, 4096, 512, 128, 0.1, 32, "uniform")]  # many clouds / a larger cloud: two launches
     seen = []
     for seed, (B, N, m1, m2, r, K, kind) in enumerate(cases):
         d = torch.from_numpy(cloud(9000 + seed, B, N, kind)).cuda()
@@ -322,7 +324,7 @@ def test_ball_query_tie_check_colaunch_equals_separate_launches(monkeypatch):
             assert torch.equal(x, y), (seed, kind)
         assert torch.equal(a[3], ops.ball_query(r, K, d, a[1])) and torch.equal(a[2], ops.furthest_point_sample(a[1], m2))
         seen.append(bool(ext._lib.pn2x_ball_query_picks_ties_supported(B, N, m1, m2)))
-    assert seen == [True] * 8 + [False]   # many clouds: two launches
+    assert seen == [True] * 9 + [False] * 2
     real = ext._lib.pn2x_ball_query_picks_ties
     assert real(1, 1024, 256, 0.1, 32, None, None, None, None, None, 0, 128, None, None, None) == -2   # NULL pointers
     assert real(1, 1024, 256, 0.1, 32, None, None, None, None, None, 0, 300, None, None, None) == -1   # m2 > m
