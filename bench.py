@@ -308,6 +308,8 @@ def main():
             torch.cuda.synchronize()
             eager_ms = (time.perf_counter() - t0) / 5 * 1e3
             from hotrack_amd import ext
+            import hotrack_amd
+            hotrack_amd.streams_in_flight(ninf)  # warns once when the hardware-queue setting would serialise the streams
             gstreams = [torch.cuda.Stream() for _ in range(ninf)]
             slots = [_flatten(pool[0][0], dev) for _ in range(ninf)]  # static inputs of each stream's graph
             graphs = []

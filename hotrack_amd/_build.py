@@ -65,8 +65,20 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(p) for p in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build_variant(name: str, extra_flags, verbose: bool = False) -> str:
+    """A tuning / profiling variant of the library: every source compiled with `extra_flags` on top of the product flags into
+    its own object directory, linked as libpn2_hip.<name>.so next to the product library (never loaded unless PN2_LIB_PATH
+    points at it: scripts/probes)."""
+    return build(force=False, verbose=verbose, _variant=(name, list(extra_flags)))
+
+
+def build(force: bool = False, verbose: bool = False, _variant=None) -> str:
     """Compile every .hip under csrc/ and link libpn2_hip.so.  Returns its path."""
+    LIB_PATH, OBJ_DIR, vflags = globals()["LIB_PATH"], globals()["OBJ_DIR"], []
+    if _variant is not None:
+        LIB_PATH = os.path.join(_HERE, "libpn2_hip.%s.so" % _variant[0])
+        OBJ_DIR = os.path.join(CSRC, "build", "variant_" + _variant[0])
+        vflags = _variant[1]
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _deps_mtime():
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -82,7 +94,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr)):
             return obj
         cmd = [hipcc, *HIPCC_FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []),
-               *os.environ.get("PN2_EXTRA_HIPCC_FLAGS", "").split(), "-Rpass-analysis=kernel-resource-usage",
+               *os.environ.get("PN2_EXTRA_HIPCC_FLAGS", "").split(), *vflags, "-Rpass-analysis=kernel-resource-usage",
                "-c", src, "-o", obj]  # env: tuning sweeps
         if verbose:
             print(" ".join(cmd))

@@ -64,9 +64,11 @@ struct BwdArgs {
 #ifdef PN2_TGB_PROFILE
 #define TGB_T(var) const long long var = clock64()
 #define TGB_ADD(slot, t1, t0) do { if (lane == 0) pacc[slot] += (t1) - (t0); } while (0)
+#define TGB_ADD2(slot, t1, t0) do { if (lane == 0) pacc2[slot] += (t1) - (t0); } while (0)
 #else
 #define TGB_T(var)
 #define TGB_ADD(slot, t1, t0)
+#define TGB_ADD2(slot, t1, t0)
 #endif
 
 template <int NB, int KB, int GMODE = 0>
@@ -146,7 +148,8 @@ __device__ __forceinline__ void tg_bwd_body(const BwdArgs &a, const int wg, cons
         }
     };
     long tile = wg;
-    if (tile < T) prefetch(tile);  // the first tile's operands travel while the constants (and W_i) are set up
+    // (the first tile's operands are requested after the constants' loads, further down: loads return in order, and the fp64
+    // sums of the constants would otherwise wait for every HBM row queued in front of them -- round 5, see tg_bwd2_body)
 
     // W_i (where it is LDS-resident) is requested before the constants are derived and stored after them: one memory round trip
     constexpr int WQ = Kd * N / 4, WCNT = P::WLDS ? (WQ + kT - 1) / kT : 1;
@@ -176,6 +179,7 @@ __device__ __forceinline__ void tg_bwd_body(const BwdArgs &a, const int wg, cons
         }
         if (wg == 0)
             for (int e = tid; e < Kd * N; e += kT) a.dW[e] = 0.f;
+        if (tile < T) prefetch(tile);
         if constexpr (P::WLDS) {
 #pragma unroll
             for (int i = 0; i < WCNT; ++i) {
@@ -433,12 +437,423 @@ tg_bwd_pair_kernel(BwdArgs a0, BwdArgs a1, int n0) {
     else tg_bwd_body<NB, KB, GMODE>(a1, (int)blockIdx.x - n0, (int)gridDim.x - n0);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same layer backward with the data gradient's B operand (W_i) in REGISTERS (C_{i-1} in {64, 128}).
+//
+// Per-wave cycle counts of the kernel above (profiles/r04_tgb_phase_cycles_per_wave.json) show where its time goes on the
+// 128-channel layers: the data-gradient phase runs at 66 % of the matrix rate (W_i streams from L2 one batch of 16 instructions
+// ahead; a deeper buffer does not fit: a wave's 32 x 32 output block needs C_i / 2 = 96 registers of W_i for the 32x32x2
+// instruction), and the first wave of a SIMD then waits 17 k cycles at the barrier for the second.  A first attempt this round
+// gave the waves two ROLES (four hold W_i and own the data gradient, four own the weight gradient, both concurrently): the
+// data-gradient waves then ran at the full matrix rate, but a wave that issues VALU / LDS / store instructions beside a
+// co-resident wave streaming fp32 MFMAs gets about one issue slot per matrix instruction -- their accumulator-direct epilogue
+// took 20 k cycles per tile -- and the sum was no faster (profiles/r05_misc_measurements.md).  What is kept from it: the
+// register-resident W_i.  With v_mfma_f32_16x16x4_f32 a wave's output block is 16 columns wide, so its slice of W_i is
+// C_i / 4 = 32 .. 48 registers (8 waves x 16 columns = the 128 columns of the tile; 64 columns: 4 slices x 2 row halves), the
+// A fragments are 16-byte LDS reads (one per four instructions, k-permuted like sa_fused.hip's), and every wave still takes
+// part in both matrix phases, the staging tile and the float4 epilogue exactly as above.
+template <int NB, int KB>
+struct Plan2 {
+    static constexpr int N = 32 * NB, Kd = 32 * KB;
+    static constexpr int LDY = Kd + 4;           // float4 rows; 16 lanes x 4 k-groups of a fragment read cover every bank 4 times
+    static constexpr int LDX = N + 4;
+    static constexpr int CS = N / 16;            // 16-column slices of the data-gradient tile (8 | 4)
+    static constexpr int RH = 8 / CS;            // row groups (1 | 2): wave = (row group, column slice)
+    static constexpr int RT = 4 / RH;            // 16-row tiles per wave (4 | 2)
+    static constexpr int NQ = Kd / 16;           // k groups: one 16-byte A read and four matrix instructions per row tile each
+    static constexpr int WBLK = NB * KB;
+    static constexpr int KS_W = WBLK >= 8 ? 1 : 8 / WBLK;
+    static constexpr int WB = WBLK >= 8 ? WBLK / 8 : 1;
+    static constexpr int QN = N / 4, RG = kT / QN;
+    static constexpr int lds_floats = 7 * Kd + 4 * N + BM * LDY + 2 * BM * LDX;
+    static_assert(NB == 2 || NB == 4, "C_{i-1} in {64, 128}");
+    static_assert(WBLK < 8 || WBLK % 8 == 0, "weight-gradient blocks must split evenly over 8 waves");
+    static_assert(2 * RG * N <= BM * LDX, "the final column-sum staging reuses the data-gradient staging");
+};
+
+template <int NB, int KB, int GMODE>
+__device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, const int nwg) {
+    using P = Plan2<NB, KB>;
+    constexpr int N = P::N, Kd = P::Kd, LDY = P::LDY, LDX = P::LDX;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *cA = lds;                        // [7][Kd]
+    float *cP = cA + 7 * Kd;                // [4][N]
+    float *dYs = cP + 4 * N;                // [BM][LDY]
+    float *Xs = dYs + BM * LDY;             // [BM][LDX]  xhat_{i-1}
+    float *Gs = Xs + BM * LDX;              // [BM][LDX]  data gradient of the tile, for the float4 epilogue
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5, li = lane & 15, g4 = lane >> 4;
+#ifdef PN2_TGB_PROFILE
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long pacc2[4] = {0, 0, 0, 0};  // prologue: loads issued | constants | W_i staged | barrier
+#endif
+    TGB_T(t_start);
+
+    const long T = (a.R + BM - 1) / BM;
+    const int arow = 8 * wave + (lane >> 3), aq = lane & 7;
+    const int cq = tid % P::QN, rg = tid / P::QN;
+    constexpr bool kLateG = GMODE == 2;  // dout / arg are L2 hits (one row serves Kmax rows of the tile): fetched by the commit
+    // (routed source: dout / arg arrive in two halves -- half of their 2 x C_i / 32 registers live at a time)
+    constexpr int GH = kLateG && KB >= 4 ? KB / 2 : KB;
+    float4 pg[GH], py[KB], ph[NB];
+    int4 par[GMODE == 2 ? GH : 1];
+    auto fetch_g = [&](long tile, int i0) {
+        long row = tile * BM + arow;
+        row = row < a.R ? row : a.R - 1;
+        const long grow = GMODE == 2 ? (a.kshift >= 0 ? ((int)row >> a.kshift) : ((int)row / a.Kmax)) : row;
+#pragma unroll
+        for (int i = 0; i < GH; ++i) {
+            pg[i] = *reinterpret_cast<const float4 *>(a.G + grow * a.ldg + 4 * (8 * (i0 + i) + aq));
+            if constexpr (GMODE == 2) par[i] = *reinterpret_cast<const int4 *>(a.arg + grow * a.ldarg + 4 * (8 * (i0 + i) + aq));
+        }
+    };
+    auto prefetch = [&](long tile) {  // G_i (dense sources) and Y_i: requested right behind the commit's barrier
+        long row = tile * BM + arow;
+        row = row < a.R ? row : a.R - 1;
+        if constexpr (!kLateG) fetch_g(tile, 0);
+#pragma unroll
+        for (int i = 0; i < KB; ++i) py[i] = *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + 4 * (8 * i + aq));
+    };
+    auto prefetch_p = [&](long tile) {  // Y_{i-1}: requested between the two matrix phases (not live during the first)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            long r = tile * BM + rg + P::RG * i;
+            r = r < a.R ? r : a.R - 1;
+            ph[i] = *reinterpret_cast<const float4 *>(a.Yp + r * a.ldyp + 4 * cq);
+        }
+    };
+    // data gradient: this wave's 16 columns and 16-row tiles rt0 .. rt0 + RT - 1
+    const int dcs = wave % P::CS, rt0 = (wave / P::CS) * P::RT;
+    // W_i, this wave's slice, as the B operand of instruction (q, j): lane (li, g4) holds W_i[16 q + 4 g4 + j][16 dcs + li] -- requested
+    // first (one memory round trip with the first tile's operands and the constants), used after the first commit
+    // It reaches the registers through LDS: 16-byte coalesced loads of the whole matrix by the whole workgroup (the region of
+    // the tiles is free before the first commit), then every lane picks its C_i / 4 values.  (Fetched directly -- 4-byte
+    // loads, 64-byte segments, the same addresses in the same order on every CU at the same moment -- the prologue of these
+    // kernels took 16 k cycles instead of 7 k: profiles/r05_misc_measurements.md.)  Workgroups start at rotated offsets.
+    float wreg[4 * P::NQ];
+    constexpr int WQ = Kd * N / 4, WCNT = WQ / kT, LDW = N + 4;  // staging rows of N + 4 floats: the four k slots of a fragment hit disjoint banks
+    static_assert(WQ % kT == 0 && Kd * LDW <= BM * LDY + 2 * BM * LDX, "W_i staging fits the tile region");
+    f32x4 wst[WCNT];
+    const int wrot = (int)(((unsigned)wg * 1103u) % (unsigned)WQ);
+#pragma unroll
+    for (int i = 0; i < WCNT; ++i) {
+        int e = tid + i * kT + wrot;
+        e = e >= WQ ? e - WQ : e;
+        const int kd = e / (N / 4), q = e % (N / 4);
+#ifdef TGB2_PROBE_NO_W   /* timing probe: what W_i costs the prologue (results are wrong) */
+        wst[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
+#else
+        wst[i] = *reinterpret_cast<const f32x4 *>(a.W + (size_t)kd * a.ldw + 4 * q);
+#endif
+    }
+    long tile = wg;
+    // The first tile's operands are requested AFTER the constants' own loads below, not before them: loads return in order, so
+    // with 82 KB of HBM rows per workgroup queued in front, the fp64 sums the constants are derived from (and with them the
+    // whole staging chain: constants -> barrier -> W_i to registers -> barrier) waited for the slowest load of the launch.
+    // Measured on the 128 -> 192 keypoint-query layer: prologue 17.6 k -> 9.3 k cycles, the kernel 115.6 k -> 106.7 k, and the
+    // first commit does not wait any longer for it (profiles/r05_misc_measurements.md; TGB2_PROBE_EARLY_TILE: the old order).
+#ifdef TGB2_PROBE_EARLY_TILE
+    if (tile < T) {
+        prefetch(tile);
+        prefetch_p(tile);
+    }
+#endif
+    TGB_T(t_p1);
+    {
+        const float inv_r = (float)(1.0 / (double)a.R);
+        for (int c = tid; c < Kd; c += kT) {
+            double sa = 0.0, sb = 0.0;
+            for (int r = 0; r < kBnRep; ++r) {
+                sa += a.sums_bwd[(size_t)r * 2 * a.sums_ld + c];
+                sb += a.sums_bwd[(size_t)r * 2 * a.sums_ld + a.sums_ld + c];
+            }
+            const float is = a.invstd[c];
+            cA[c] = a.mean[c]; cA[Kd + c] = is; cA[2 * Kd + c] = a.gamma[c] * is;
+            cA[3 * Kd + c] = (float)sa * inv_r; cA[4 * Kd + c] = (float)sb * inv_r;
+            if constexpr (GMODE != 0) { cA[5 * Kd + c] = a.gamma[c]; cA[6 * Kd + c] = a.beta[c]; }
+        }
+        for (int c = tid; c < N; c += kT) {
+            cP[c] = a.mean_p[c]; cP[N + c] = a.invstd_p[c]; cP[2 * N + c] = a.gamma_p[c]; cP[3 * N + c] = a.beta_p[c];
+        }
+        if (wg == 0)
+            for (int e = tid; e < Kd * N; e += kT) a.dW[e] = 0.f;
+    }
+#ifndef TGB2_PROBE_EARLY_TILE
+    if (tile < T) {
+        prefetch(tile);
+        prefetch_p(tile);
+    }
+#endif
+    TGB_T(t_p2);
+    TGB_ADD2(0, t_p1, t_start); TGB_ADD2(1, t_p2, t_p1);
+    {
+#pragma unroll
+        for (int i = 0; i < WCNT; ++i) {
+            int e = tid + i * kT + wrot;
+            e = e >= WQ ? e - WQ : e;
+            const int kd = e / (N / 4), q = e % (N / 4);
+            *reinterpret_cast<f32x4 *>(dYs + kd * LDW + 4 * q) = wst[i];
+        }
+    }
+    TGB_T(t_p3);
+    __syncthreads();
+    TGB_T(t_p4);
+    TGB_ADD2(2, t_p3, t_p2); TGB_ADD2(3, t_p4, t_p3);
+    {
+        const float *wp = dYs + (4 * g4) * LDW + dcs * 16 + li;
+#pragma unroll
+        for (int q = 0; q < P::NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wreg[4 * q + j] = wp[(16 * q + j) * LDW];
+    }
+    __syncthreads();  // the staging region becomes the tiles
+
+    auto commit = [&](long tile) {
+        const bool v = tile * BM + arow < a.R;
+        if constexpr (kLateG) fetch_g(tile, 0);
+        int kk = 0;
+        if constexpr (GMODE == 2) {
+            const long row = tile * BM + arow;
+            const int rr = (int)(row < a.R ? row : a.R - 1);
+            kk = a.kshift >= 0 ? (rr & (a.Kmax - 1)) : (rr % a.Kmax);
+        }
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            if constexpr (kLateG && GH < KB) {
+                if (i == GH) fetch_g(tile, GH);
+            }
+            const int gi = i % GH;
+            const int c = 4 * (8 * i + aq);
+            const float4 mean = *reinterpret_cast<const float4 *>(cA + c), is = *reinterpret_cast<const float4 *>(cA + Kd + c);
+            const float4 sc = *reinterpret_cast<const float4 *>(cA + 2 * Kd + c), m1 = *reinterpret_cast<const float4 *>(cA + 3 * Kd + c);
+            const float4 m2 = *reinterpret_cast<const float4 *>(cA + 4 * Kd + c);
+            // same expressions as train_gemm.hip's dy_value
+            const float x0 = (py[i].x - mean.x) * is.x, x1 = (py[i].y - mean.y) * is.y;
+            const float x2 = (py[i].z - mean.z) * is.z, x3 = (py[i].w - mean.w) * is.w;
+            float g0 = pg[gi].x, g1 = pg[gi].y, g2 = pg[gi].z, g3 = pg[gi].w;
+            if constexpr (GMODE == 2) {
+                const float4 ga = *reinterpret_cast<const float4 *>(cA + 5 * Kd + c), be = *reinterpret_cast<const float4 *>(cA + 6 * Kd + c);
+                g0 = (par[gi].x == kk && x0 * ga.x + be.x > 0.f) ? g0 : 0.f;  // routed to the arg-max row, [relu(BN(y)) > 0]
+                g1 = (par[gi].y == kk && x1 * ga.y + be.y > 0.f) ? g1 : 0.f;
+                g2 = (par[gi].z == kk && x2 * ga.z + be.z > 0.f) ? g2 : 0.f;
+                g3 = (par[gi].w == kk && x3 * ga.w + be.w > 0.f) ? g3 : 0.f;
+            }
+            if constexpr (GMODE == 1) {
+                const float4 ga = *reinterpret_cast<const float4 *>(cA + 5 * Kd + c), be = *reinterpret_cast<const float4 *>(cA + 6 * Kd + c);
+                g0 = (x0 * ga.x + be.x > 0.f) ? g0 : 0.f;  // [relu(BN(y)) > 0], torch's evaluation order
+                g1 = (x1 * ga.y + be.y > 0.f) ? g1 : 0.f;
+                g2 = (x2 * ga.z + be.z > 0.f) ? g2 : 0.f;
+                g3 = (x3 * ga.w + be.w > 0.f) ? g3 : 0.f;
+            }
+            float4 d;
+            d.x = v ? sc.x * (g0 - m1.x - x0 * m2.x) : 0.f;
+            d.y = v ? sc.y * (g1 - m1.y - x1 * m2.y) : 0.f;
+            d.z = v ? sc.z * (g2 - m1.z - x2 * m2.z) : 0.f;
+            d.w = v ? sc.w * (g3 - m1.w - x3 * m2.w) : 0.f;
+            *reinterpret_cast<float4 *>(dYs + arow * LDY + c) = d;
+        }
+        const float4 pm = *reinterpret_cast<const float4 *>(cP + 4 * cq), pis = *reinterpret_cast<const float4 *>(cP + N + 4 * cq);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r = rg + P::RG * i;
+            const bool vr = tile * BM + r < a.R;
+            float4 x;
+            x.x = vr ? (ph[i].x - pm.x) * pis.x : 0.f;
+            x.y = vr ? (ph[i].y - pm.y) * pis.y : 0.f;
+            x.z = vr ? (ph[i].z - pm.z) * pis.z : 0.f;
+            x.w = vr ? (ph[i].w - pm.w) * pis.w : 0.f;
+            *reinterpret_cast<float4 *>(Xs + r * LDX + 4 * cq) = x;
+        }
+    };
+
+    // weight gradient: this wave's blocks (sharing the column block nbw) and its slice of the tile's rows -- as above
+    const int wb0 = P::WBLK >= 8 ? wave * P::WB : wave % P::WBLK;
+    const int ksw = P::WBLK >= 8 ? 0 : wave / P::WBLK;
+    const int nbw = wb0 / KB, kb0 = wb0 % KB;
+    constexpr int steps_w = (BM / 2) / P::KS_W;
+    const float wga = cP[2 * N + nbw * 32 + l31], wbe = cP[3 * N + nbw * 32 + l31];
+    f32x16 accw[P::WB];
+#pragma unroll
+    for (int j = 0; j < P::WB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cqs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    TGB_T(t_pro);
+    TGB_ADD(0, t_pro, t_start);
+    while (tile < T) {
+        TGB_T(t0);
+        commit(tile);
+        TGB_T(t1);
+        __syncthreads();
+        TGB_T(t2);
+        const long ntile = tile + nwg;
+        if (ntile < T) prefetch(ntile);  // nothing else of this tile reads global memory before the epilogue
+        {
+            // data gradient: acc[t] (16 x 16: row 4 g4 + r, column li) of row tile rt0 + t; instruction (q, j) multiplies
+            // dY[.][16 q + 4 g4 + j] by W_i[16 q + 4 g4 + j][.]: every k once, in the order the fragments are laid out
+            f32x4 acc[P::RT];
+#pragma unroll
+            for (int t = 0; t < P::RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float *ap = dYs + (rt0 * 16 + li) * LDY + 4 * g4;
+            // (the 128 -> 192 kernel has no registers left for fragments a whole k group ahead: its reads are issued where the
+            // compiler places them, the SIMD's other wave covers their latency)
+            constexpr bool kAhead = !(NB == 4 && KB == 6);
+            float4 an[kAhead ? P::RT : 1];
+            if constexpr (kAhead) {
+#pragma unroll
+                for (int t = 0; t < P::RT; ++t) an[t] = *reinterpret_cast<const float4 *>(ap + t * 16 * LDY);
+            }
+#pragma unroll
+            for (int q = 0; q < P::NQ; ++q) {
+                float4 av[P::RT];
+#pragma unroll
+                for (int t = 0; t < P::RT; ++t) {
+                    if constexpr (kAhead) av[t] = an[t];
+                    else av[t] = *reinterpret_cast<const float4 *>(ap + t * 16 * LDY + 16 * q);
+                }
+                if (kAhead && q + 1 < P::NQ) {  // the next k group's fragments travel behind this group's instructions
+#pragma unroll
+                    for (int t = 0; t < P::RT; ++t) an[t] = *reinterpret_cast<const float4 *>(ap + t * 16 * LDY + 16 * (q + 1));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < P::RT; ++t) {
+                        const float x = j == 0 ? av[t].x : j == 1 ? av[t].y : j == 2 ? av[t].z : av[t].w;
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, wreg[4 * q + j], acc[t], 0, 0, 0);
+                    }
+            }
+            float *gs = Gs + ((rt0 * 16 + 4 * g4) * LDX + dcs * 16 + li);
+#pragma unroll
+            for (int t = 0; t < P::RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gs[(t * 16 + r) * LDX] = acc[t][r];
+        }
+        TGB_T(t3);
+        if (ntile < T) prefetch_p(ntile);
+        {
+            const float *xp = Xs + (kh + 2 * ksw * steps_w) * LDX + nbw * 32 + l31;
+            const float *ap = dYs + (kh + 2 * ksw * steps_w) * LDY + kb0 * 32 + l31;
+#pragma unroll 4
+            for (int s = 0; s < steps_w; ++s) {
+                const float bv = relu_nan(xp[2 * s * LDX] * wga + wbe);
+#pragma unroll
+                for (int j = 0; j < P::WB; ++j) {
+                    const float av = ap[2 * s * LDY + 32 * j];
+                    accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);
+                }
+            }
+        }
+        TGB_T(t4);
+        __syncthreads();
+        TGB_T(t5);
+        {
+            const bool full = tile * BM + BM <= a.R;
+            const float4 pga = *reinterpret_cast<const float4 *>(cP + 2 * N + 4 * cq), pbe = *reinterpret_cast<const float4 *>(cP + 3 * N + 4 * cq);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int r = rg + P::RG * i;
+                float4 g = *reinterpret_cast<const float4 *>(Gs + r * LDX + 4 * cq);
+                const long row = tile * BM + r;
+                if (a.Gadd && (full || row < a.R)) {
+                    const float4 t = *reinterpret_cast<const float4 *>(a.Gadd + row * a.ldga + 4 * cq);
+                    g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                }
+                if (a.raw_out) {  // (workgroup-uniform) a column slice of a wider layer: the next slice finishes these rows
+                    if (full || row < a.R) *reinterpret_cast<float4 *>(a.Gp + row * a.ldgp + 4 * cq) = g;
+                    continue;
+                }
+                const float4 x = *reinterpret_cast<const float4 *>(Xs + r * LDX + 4 * cq);
+                g.x = (x.x * pga.x + pbe.x > 0.f) ? g.x : 0.f;  // [relu(BN(y)) > 0], torch's evaluation order
+                g.y = (x.y * pga.y + pbe.y > 0.f) ? g.y : 0.f;
+                g.z = (x.z * pga.z + pbe.z > 0.f) ? g.z : 0.f;
+                g.w = (x.w * pga.w + pbe.w > 0.f) ? g.w : 0.f;
+                cs[0] += g.x; cs[1] += g.y; cs[2] += g.z; cs[3] += g.w;   // rows beyond R: dY == 0 -> g == 0, xhat == 0
+                cqs[0] += g.x * x.x; cqs[1] += g.y * x.y; cqs[2] += g.z * x.z; cqs[3] += g.w * x.w;
+                if (full || row < a.R) *reinterpret_cast<float4 *>(a.Gp + row * a.ldgp + 4 * cq) = g;
+            }
+        }
+        // no barrier here: the next commit overwrites dYs / Xs at the elements this thread itself read in the epilogue (same
+        // (row, quad) mapping), other readers passed the barrier above; Gs is rewritten only after the next commit's barrier
+        TGB_T(t6);
+        TGB_ADD(1, t1, t0); TGB_ADD(2, t2, t1); TGB_ADD(3, t3, t2); TGB_ADD(4, t4, t3); TGB_ADD(5, t5, t4); TGB_ADD(6, t6, t5);
+        tile = ntile;
+    }
+    TGB_T(t_loop);
+
+    {  // weight-gradient partial tile of this workgroup (and row slice)
+        float *out = a.partial + ((size_t)wg * P::KS_W + ksw) * (size_t)(Kd * N);
+#pragma unroll
+        for (int j = 0; j < P::WB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kd = (kb0 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[(size_t)kd * N + nbw * 32 + l31] = accw[j][r];
+            }
+    }
+    if (a.raw_out) return;  // (workgroup-uniform)
+    __syncthreads();
+    float *redS = Gs, *redQ = Gs + P::RG * N;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        redS[rg * N + 4 * cq + e] = cs[e];
+        redQ[rg * N + 4 * cq + e] = cqs[e];
+    }
+    __syncthreads();
+    if (tid < N) {
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < P::RG; ++r) {
+            s += (double)redS[r * N + tid];
+            q += (double)redQ[r * N + tid];
+        }
+        double *dst = a.sums_bwd_p + (size_t)(wg % kBnRep) * 2 * N;
+        unsafeAtomicAdd(dst + tid, s);
+        unsafeAtomicAdd(dst + N + tid, q);
+    }
+#ifdef PN2_TGB_PROFILE
+    if (lane == 0 && a.prof) {
+        pacc[7] = clock64() - t_loop;
+        for (int k = 0; k < 8; ++k) a.prof[((size_t)wg * 8 + wave) * 8 + k] = pacc[k];
+        for (int k = 0; k < 4; ++k) a.prof[(size_t)1024 * 64 + ((size_t)wg * 8 + wave) * 4 + k] = pacc2[k];
+    }
+#endif
+}
+
+template <int NB, int KB, int GMODE>
+__global__ void __launch_bounds__(kT, 2) tg_bwd2_kernel(BwdArgs a) {
+    tg_bwd2_body<NB, KB, GMODE>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int NB, int KB, int GMODE>
+__global__ void __launch_bounds__(kT, 2) tg_bwd2_pair_kernel(BwdArgs a0, BwdArgs a1, int n0) {
+    if ((int)blockIdx.x < n0) tg_bwd2_body<NB, KB, GMODE>(a0, (int)blockIdx.x, n0);
+    else tg_bwd2_body<NB, KB, GMODE>(a1, (int)blockIdx.x - n0, (int)gridDim.x - n0);
+}
+
+// the (C_{i-1} / 32, C_i / 32) pairs the two-role kernel is instantiated for
+#define PN2_TGB2_SHAPES(X) X(2, 2) X(2, 4) X(4, 4) X(4, 6)
+static bool g_tgb2 = [] {
+    const char *e = getenv("HOTRACK_TGB2");   // 0: the round-4 kernel for every shape (A/B measurements, tests of both)
+    return !(e && e[0] == '0');
+}();
+static bool v2_shape(int nb, int kb) {
+    if (!g_tgb2) return false;
+#define X(NB_, KB_) if (nb == NB_ && kb == KB_) return true;
+    PN2_TGB2_SHAPES(X)
+#undef X
+    return false;
+}
+template <int NB, int KB>
+static size_t lds2_of() { return (size_t)Plan2<NB, KB>::lds_floats * sizeof(float); }
+
 struct Shape {
     int nb, kb, ks_w;
     size_t lds;
+    bool v2;   // the register-resident-W kernel of round 5 (one workgroup per CU)
 };
 template <int NB, int KB>
-static Shape shape_of() { return Shape{NB, KB, Plan<NB, KB>::KS_W, (size_t)Plan<NB, KB>::lds_floats * sizeof(float)}; }
+static Shape shape_of() { return Shape{NB, KB, Plan<NB, KB>::KS_W, (size_t)Plan<NB, KB>::lds_floats * sizeof(float), false}; }
 
 static int kshift_of(int k) {
     if (k < 1 || (k & (k - 1))) return -1;
@@ -453,6 +868,11 @@ static int kshift_of(int k) {
 static bool find_shape(int c_in, int c_out, Shape &s) {
     if (c_in % 32 || c_out % 32) return false;
     const int nb = c_in / 32, kb = c_out / 32;
+    if (v2_shape(nb, kb)) {
+#define X(NB_, KB_) if (nb == NB_ && kb == KB_) { s = Shape{NB_, KB_, Plan2<NB_, KB_>::KS_W, lds2_of<NB_, KB_>(), true}; return true; }
+        PN2_TGB2_SHAPES(X)
+#undef X
+    }
 #define X(NB_, KB_) if (nb == NB_ && kb == KB_) { s = shape_of<NB_, KB_>(); return true; }
     PN2_TGB_SHAPES(X)
 #undef X
@@ -462,7 +882,7 @@ static bool find_shape(int c_in, int c_out, Shape &s) {
 static int grid_of(long rows, const Shape &s) {
     const long tiles = (rows + BM - 1) / BM;
     // persistent workgroups: one per CU where the LDS footprint admits only one, two otherwise
-    const long cap = (long)num_compute_units() * (s.lds * 2 <= 160 * 1024 ? 2 : 1);
+    const long cap = (long)num_compute_units() * (!s.v2 && s.lds * 2 <= 160 * 1024 ? 2 : 1);
     return (int)(tiles < cap ? tiles : cap);
 }
 
@@ -553,6 +973,26 @@ extern "C" int pn2x_tg_bwd_slice(PN2_TGB_PARAMS(), void *stream) {
                                       (int)s.lds);                                                                    \
         hipLaunchKernelGGL((tg_bwd_kernel<NB_, KB_, GM_>), dim3(grid), dim3(kT), s.lds, st, a);                       \
     } while (0)
+#define PN2_TGB2_LAUNCH(NB_, KB_, GM_)                                                                                 \
+    do {                                                                                                              \
+        static PerDeviceOnce once;                                                                                    \
+        if (once.first_use())                                                                                         \
+            (void)hipFuncSetAttribute((const void *)tg_bwd2_kernel<NB_, KB_, GM_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)s.lds);                                                                    \
+        hipLaunchKernelGGL((tg_bwd2_kernel<NB_, KB_, GM_>), dim3(grid), dim3(kT), s.lds, st, a);                      \
+    } while (0)
+    if (s.v2) {
+#define X(NB_, KB_)                                                                                                   \
+    if (nb == NB_ && kb == KB_) {                                                                                     \
+        if (gmode == 0) PN2_TGB2_LAUNCH(NB_, KB_, 0);                                                                 \
+        else if (gmode == 1) PN2_TGB2_LAUNCH(NB_, KB_, 1);                                                            \
+        else PN2_TGB2_LAUNCH(NB_, KB_, 2);                                                                            \
+    }
+        PN2_TGB2_SHAPES(X)
+#undef X
+        return check_launch();
+    }
+#undef PN2_TGB2_LAUNCH
 #define X(NB_, KB_)                                                                                                   \
     if (nb == NB_ && kb == KB_) {                                                                                     \
         if (gmode == 0) PN2_TGB_LAUNCH(NB_, KB_, 0);                                                                  \
@@ -582,8 +1022,13 @@ extern "C" int pn2x_tg_bwd_slice_pair(PN2_TGB_PARAMS(0), PN2_TGB_PARAMS(1), int 
     if (rc != PN2_OK) return rc;
     if (n0 != n1 || k0 != k1 || gmode0 != gmode1) return PN2_EINVAL;
     if (!pn2x_tg_bwd_pair_supported(k0, n0)) return PN2_ERANGE;
+    if (s0.v2 && k0 == 128 && n0 == 192 && gmode0 != 2) {
+        // (the pair form of the 128 -> 192 register-resident-W kernel with a dense source needs three registers more than a
+        // wave has: that combination -- not one of this network's -- keeps the round-4 kernel; same partial-tile layout)
+        s0 = s1 = shape_of<4, 6>();
+    }
     const long t0 = (rows0 + BM - 1) / BM, t1 = (rows1 + BM - 1) / BM;
-    long cap = (long)num_compute_units() * (s0.lds * 2 <= 160 * 1024 ? 2 : 1);
+    long cap = (long)num_compute_units() * (!s0.v2 && s0.lds * 2 <= 160 * 1024 ? 2 : 1);
     if (cap < 2) cap = 2;
     long rounds = (t0 + t1 + cap - 1) / cap, wg0, wg1;
     for (;; ++rounds) {  // the same number of rounds for both shares
@@ -610,6 +1055,27 @@ extern "C" int pn2x_tg_bwd_slice_pair(PN2_TGB_PARAMS(0), PN2_TGB_PARAMS(1), int 
         else if (gmode == 1) PN2_TGB_LAUNCH(NB_, KB_, 1);                                                             \
         else PN2_TGB_LAUNCH(NB_, KB_, 2);                                                                             \
     }
+#define PN2_TGB2_LAUNCH(NB_, KB_, GM_)                                                                                 \
+    do {                                                                                                              \
+        static PerDeviceOnce once;                                                                                    \
+        if (once.first_use())                                                                                         \
+            (void)hipFuncSetAttribute((const void *)tg_bwd2_pair_kernel<NB_, KB_, GM_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)s0.lds);                                                                   \
+        hipLaunchKernelGGL((tg_bwd2_pair_kernel<NB_, KB_, GM_>), dim3((unsigned)(wg0 + wg1)), dim3(kT), s0.lds, st, a0, a1, (int)wg0); \
+    } while (0)
+#define Y(NB_, KB_)                                                                                                   \
+    if (nb == NB_ && kb == KB_) {                                                                                     \
+        if (gmode == 0) PN2_TGB2_LAUNCH(NB_, KB_, 0);                                                                 \
+        else if (gmode == 1) PN2_TGB2_LAUNCH(NB_, KB_, 1);                                                            \
+        else PN2_TGB2_LAUNCH(NB_, KB_, 2);                                                                            \
+    }
+    if (s0.v2) {
+        if (nb == 4 && kb == 4) { Y(4, 4) }
+        else PN2_TGB2_LAUNCH(4, 6, 2);
+        return check_launch();
+    }
+#undef Y
+#undef PN2_TGB2_LAUNCH
     X(4, 4) X(4, 6)
 #undef X
 #undef PN2_TGB_LAUNCH

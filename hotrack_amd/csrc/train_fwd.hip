@@ -79,7 +79,8 @@ __device__ __forceinline__ void tgf_body(const FwdArgs &a, const int wg, const i
         }
     };
     long tile = wg;
-    if (tile < tiles) prefetch(tile);  // the first tile's operands travel while the constants and W_i are set up
+    // (the first tile's operands are requested after the constants' loads, below: loads return in order, and the fp64 sums the
+    // constants are derived from would otherwise wait for every HBM row queued in front of them -- round 5, train_bwd.hip)
     // W_i's slice: requested now, stored to LDS after the constants (one memory round trip for both instead of two in a row)
     constexpr int WCNT = NW * (K / 4) / T;
     static_assert(NW * (K / 4) % T == 0, "W_i slice splits evenly over the workgroup");
@@ -112,6 +113,7 @@ __device__ __forceinline__ void tgf_body(const FwdArgs &a, const int wg, const i
         }
     }
     if (first && tid == 0 && a.nbt) *a.nbt += 1;
+    if (tile < tiles) prefetch(tile);
 #pragma unroll
     for (int i = 0; i < WCNT; ++i) {
         const int e = tid + i * T, n = e / (K / 4), q = e % (K / 4);

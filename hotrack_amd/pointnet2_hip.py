@@ -22,7 +22,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpn2_hip.so")
+# PN2_LIB_PATH: a tuning / profiling VARIANT of the library built by hotrack_amd._build.build_variant (probes only; the product
+# and the tests load the in-tree build)
+LIB_PATH = os.environ.get("PN2_LIB_PATH") or os.path.join(_HERE, "libpn2_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -540,13 +540,18 @@ class Trainer(nn.Module):
             works = []
             if self._graph_rest is not None:
                 cur = torch.cuda.current_stream()
-                if self.dp_overlap:
+                probe = os.environ.get("HOTRACK_DP_PROBE", "")  # timing probes only (profiles/r05_misc_measurements.md)
+                if self.dp_overlap and probe != "norecord":
                     self._seg_done.record(cur)
                 self._graph_rest.replay()
                 if self.dp_overlap:
-                    self._seg_done.synchronize()
-                    with torch.cuda.stream(self._comm_stream):
+                    if probe != "norecord":
+                        self._seg_done.synchronize()
+                    if probe == "mainstream":
                         works.append(self._exchange(0, async_op=True))
+                    else:
+                        with torch.cuda.stream(self._comm_stream):
+                            works.append(self._exchange(0, async_op=True))
                 else:
                     works.append(self._exchange(0))
                 works.append(self._exchange(1, async_op=self.dp_overlap))

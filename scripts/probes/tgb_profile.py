@@ -25,7 +25,7 @@ def main():
         raise SystemExit("library built without -DPN2_TGB_PROFILE")
     lib.pn2x_tg_bwd_set_profile.argtypes = [ctypes.c_void_p]
     lib.pn2x_tg_bwd_set_profile.restype = None
-    prof = torch.zeros(1024 * 8 * 8, dtype=torch.int64, device="cuda")
+    prof = torch.zeros(1024 * 8 * 8 + 1024 * 8 * 4, dtype=torch.int64, device="cuda")  # + the prologue sub-phases of the round-5 kernel
     lib.pn2x_tg_bwd_set_profile(prof.data_ptr())
     names = ["prologue", "commit", "barrier1", "dgrad", "wgrad", "barrier2", "epilogue", "tail"]
     out = {}
@@ -42,10 +42,12 @@ def main():
             ws_gen = torch.autograd.grad(o, y, torch.ones_like(o), retain_graph=True)
         torch.cuda.synchronize()
         grid = int(lib.pn2x_tg_bwd_partials(R, cout, cin))
-        pw = prof.view(-1, 8, 8)[:min(grid, 1024)].double()   # [workgroup][wave][phase]
+        pw = prof[:1024 * 64].view(-1, 8, 8)[:min(grid, 1024)].double()   # [workgroup][wave][phase]
         pw = pw[pw[:, 0].sum(dim=1) > 0]
         p = pw[:, 0]
-        out[name] = {"workgroups": int(p.shape[0]), "tiles": (R + 63) // 64,
+        p2 = prof[1024 * 64:].view(-1, 8, 4)[:min(grid, 1024)].double()
+        pro = {n: [round(float(p2[:, w, i].mean())) for w in (0, 3, 7)] for i, n in enumerate(("loads_issued", "constants", "w_staged", "barrier"))}
+        out[name] = {"prologue_parts_waves_0_3_7": pro, "workgroups": int(p.shape[0]), "tiles": (R + 63) // 64,
                      **{n: round(float(p[:, i].mean())) for i, n in enumerate(names)}, "total": round(float(p.sum(dim=1).mean())),
                      "per_wave": {n: [round(float(pw[:, w, i].mean())) for w in range(8)] for i, n in enumerate(names) if n in ("barrier1", "dgrad", "wgrad", "barrier2", "commit", "epilogue")}}
     print(json.dumps(out, indent=1))

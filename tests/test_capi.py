@@ -141,3 +141,19 @@ def test_build_refuses_kernels_with_scratch_memory(tmp_path):
                         str(tmp_path / "scr.o")], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-500:]
     assert list(_build.scratch_kernels(p.stderr).values())[0] >= 256
+
+
+def test_streams_in_flight_warns_once_about_hardware_queues(monkeypatch):
+    """VERDICT r4 item 7: several captured forwards in flight need GPU_MAX_HW_QUEUES >= streams + 1 before the runtime starts;
+    hotrack_amd.streams_in_flight says so once instead of silently running the streams behind each other."""
+    import warnings
+    import hotrack_amd
+    monkeypatch.setattr(hotrack_amd, "_hw_queue_warned", False)
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert hotrack_amd.streams_in_flight(1) is True and not w
+        assert hotrack_amd.streams_in_flight(4) is False and len(w) == 1 and "GPU_MAX_HW_QUEUES=8" in str(w[0].message)
+        assert hotrack_amd.streams_in_flight(4) is False and len(w) == 1   # once
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert hotrack_amd.streams_in_flight(4) is True
