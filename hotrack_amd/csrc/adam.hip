@@ -14,7 +14,7 @@ namespace pn2 {
 namespace adam {
 
 constexpr int kMaxT = 64;      // tensors per launch (kernel-argument budget)
-constexpr int kChunk = 8192;   // elements per workgroup
+constexpr int kChunk = 2048;   // elements per workgroup (round 5: 8192 gave 115 - 384 workgroups per launch on 256 CUs -- ragged rounds)
 constexpr int kT = 256;
 
 struct Pack {

@@ -495,6 +495,7 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
     constexpr bool kLateG = GMODE == 2;  // dout / arg are L2 hits (one row serves Kmax rows of the tile): fetched by the commit
     // (routed source: dout / arg arrive in two halves -- half of their 2 x C_i / 32 registers live at a time)
     constexpr int GH = kLateG && KB >= 4 ? KB / 2 : KB;
+    constexpr bool kEarlyG = kLateG && !(NB == 4 && KB == 6);  // (the 128 -> 192 kernel has no registers to carry it across the epilogue)
     float4 pg[GH], py[KB], ph[NB];
     int4 par[GMODE == 2 ? GH : 1];
     auto fetch_g = [&](long tile, int i0) {
@@ -556,6 +557,7 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
     if (tile < T) {
         prefetch(tile);
         prefetch_p(tile);
+        if constexpr (kEarlyG) fetch_g(tile, 0);
     }
 #endif
     TGB_T(t_p1);
@@ -582,6 +584,7 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
     if (tile < T) {
         prefetch(tile);
         prefetch_p(tile);
+        if constexpr (kEarlyG) fetch_g(tile, 0);
     }
 #endif
     TGB_T(t_p2);
@@ -610,7 +613,9 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
 
     auto commit = [&](long tile) {
         const bool v = tile * BM + arow < a.R;
-        if constexpr (kLateG) fetch_g(tile, 0);
+        // (routed source: the first half of dout / arg was requested behind the previous tile's weight-gradient phase -- the
+        // registers are free there -- and the second half follows once the first is consumed)
+        if constexpr (kLateG && !kEarlyG) fetch_g(tile, 0);
         int kk = 0;
         if constexpr (GMODE == 2) {
             const long row = tile * BM + arow;
@@ -746,6 +751,9 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
             }
         }
         TGB_T(t4);
+        if constexpr (kEarlyG) {
+            if (ntile < T) fetch_g(ntile, 0);
+        }
         __syncthreads();
         TGB_T(t5);
         {
@@ -837,6 +845,16 @@ static bool g_tgb2 = [] {
     const char *e = getenv("HOTRACK_TGB2");   // 0: the round-4 kernel for every shape (A/B measurements, tests of both)
     return !(e && e[0] == '0');
 }();
+}  // namespace tgb
+}  // namespace pn2
+// 1: the register-resident-W kernel where it is instantiated (default), 0: the round-4 kernel everywhere.  Process-wide; the
+// partial-tile counts pn2x_tg_bwd_partials reports follow it, so switch between whole backward passes only (tests, A/B benches).
+extern "C" int pn2x_tg_bwd_set_variant(int v2) {
+    pn2::tgb::g_tgb2 = v2 != 0;
+    return PN2_OK;
+}
+namespace pn2 {
+namespace tgb {
 static bool v2_shape(int nb, int kb) {
     if (!g_tgb2) return false;
 #define X(NB_, KB_) if (nb == NB_ && kb == KB_) return true;

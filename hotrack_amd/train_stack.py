@@ -88,6 +88,14 @@ def _bwd_slices(c_in: int, c_out: int):
 _lib.pn2x_bn_bwd_reduce_routed.argtypes = [_cl, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_bn_bwd_reduce_routed.restype = _ci
 _lib.pn2x_tg_bwd.restype = _ci
+_lib.pn2x_tg_bwd_set_variant.argtypes = [_ci]
+_lib.pn2x_tg_bwd_set_variant.restype = _ci
+
+
+def set_bwd_kernel_variant(v2: bool) -> None:
+    """True (default): the layer backward with W_i register-resident (round 5) where it is instantiated; False: the round-4 kernel
+    for every shape.  Process-wide; switch between whole backward passes only (tests, A/B benches)."""
+    _native._check(_lib.pn2x_tg_bwd_set_variant(1 if v2 else 0), "tg_bwd_set_variant")
 FUSED_BWD = _os.environ.get("HOTRACK_STACK_FUSED_BWD", "1") != "0"  # data + weight gradient of a layer in one kernel (train_bwd.hip)
 ROUTE_ON_LOAD = _os.environ.get("HOTRACK_STACK_ROUTE_ON_LOAD", "1") != "0"  # max-pooled top: sums from the arg-max rows, routed on load
 _lib.pn2x_bn_bwd_reduce.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp]

@@ -582,6 +582,11 @@ int pn2x_tg_fwd2_pair(long rows0, int k, int n, const float *x0, int ldx0, const
                       float *running_var1, long long *nbt1, float *save_mean1, float *save_invstd1, double *sums_out1, void *stream);
 int pn2x_tg_bwd_supported(int c_in, int c_out);
 int pn2x_tg_bwd_partials(long rows, int c_out, int c_in);
+/* Round 5: for c_in in {64, 128} the kernel keeps W_i in registers as the B operand of v_mfma_f32_16x16x4_f32 (16-column slices
+ * per wave; csrc/train_bwd.hip, tg_bwd2).  pn2x_tg_bwd_set_variant(0) selects the round-4 kernel (W_i streamed from L2 / LDS) for
+ * every shape, 1 (default, or HOTRACK_TGB2) the new one where instantiated.  Process-wide: switch between whole backward passes
+ * only (tests, A/B benches) -- the number of partial tiles a launch writes depends on it. */
+int pn2x_tg_bwd_set_variant(int v2);
 int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, int ldg, const int *arg, int kmax, const float *yi, int ldyi,
                 const float *mean_i, const float *invstd_i, const float *gamma_i, const float *beta_i, const double *sums_bwd_i,
                 const float *w, int ldw, const float *yp,

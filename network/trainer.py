@@ -569,10 +569,10 @@ class Trainer(nn.Module):
 
         self._graph, self._static = None, clone(data)
         pts = data.get("hand_points") if isinstance(data, dict) else None
-        if (torch.is_tensor(pts) and pts.dim() == 3 and pts.shape[0] * pts.shape[1] not in (32 * 1024, 64 * 1024)
+        if (torch.is_tensor(pts) and pts.dim() == 3 and pts.shape[0] * pts.shape[1] not in tuple(b * 1024 for b in (16, 24, 32, 48, 64))
                 and os.environ.get("HOTRACK_TUNE_GEMMS", "0") != "1" and not getattr(Trainer, "_tune_hint_given", False)):
             Trainer._tune_hint_given = True  # once per process
-            self.log_string("the shipped GEMM solution table covers per-GPU batches of 32 / 64 x 1024 points; for this batch (%d x %d) "
+            self.log_string("the shipped GEMM solution table covers per-GPU batches of 16 / 24 / 32 / 48 / 64 x 1024 points; for this batch (%d x %d) "
                             "HOTRACK_TUNE_GEMMS=1 tunes the library GEMMs during this warm-up (~15 s; measured 2.68 -> 2.34 ms/step at "
                             "batch 16, 4.58 -> 3.91 at 48) and HOTRACK_GEMM_CACHE=<file> keeps the result" % (pts.shape[0], pts.shape[1]))
         if self._geo_ready_for is not None:  # a prefetch of the previous capture's graph may still be running: its graph, its

@@ -543,6 +543,53 @@ def test_mlp_stack_one_kernel_layer_backward_equals_two_kernel_backward(R, width
             torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("R,widths,K", [
+    (16 * 4403, [64, 64, 128], 16),       # C_{i-1} = 64: four 16-column slices x two row halves; routed top, ragged last tile
+    (64 * 150 + 64, [128, 128, 192], 64),  # C_{i-1} = 128: eight slices, C_i = 192 (48 registers of W_i per lane)
+    (5000, [128, 128, 384], 0),           # dense top, two column slices of 192 chained through the partial data gradient
+    (128 * 40, [128, 128, 512], 128),     # routed top over four column slices of 128
+    (3000, [64, 64, 64], 0),
+    (21 * 16 * 7, [128, 128, 192], 16),   # one tile per workgroup and fewer tiles than compute units
+])
+def test_layer_backward_with_register_resident_w_equals_round4_kernel(R, widths, K):
+    """Round 5: tg_bwd2 (W_i register-resident, 16x16x4 data-gradient tiles; csrc/train_bwd.hip) against the round-4 kernel on the
+    same forward: the same dY / mask / sums expressions, another summation order inside the data gradient only."""
+    from hotrack_amd import train_stack
+    from hotrack_amd.train_ops import Workspace
+    g = torch.Generator(device="cuda").manual_seed(R + 1)
+    convs = [torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])]
+    bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in widths]
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.copy_(1 + 0.3 * torch.randn(bn.weight.shape, device="cuda", generator=g))
+            bn.bias.copy_(0.2 * torch.randn(bn.bias.shape, device="cuda", generator=g))
+    params = [p for m in convs + bns for p in m.parameters()]
+    y1 = torch.randn(R, widths[0], device="cuda", generator=g) * 1.3 + 0.2
+    go = torch.randn(R // K if K else R, widths[-1], device="cuda", generator=g)
+    ws = Workspace("cuda")
+
+    def run(v2):
+        train_stack.set_bwd_kernel_variant(v2)
+        try:
+            for p in params:
+                p.grad = None
+            ws.reset()
+            y = y1.clone().requires_grad_(True)
+            layers = [train_stack.Layer(None, bns[0])] + [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(convs, bns[1:])]
+            train_stack.mlp_stack(y, layers, ws, max_over=K).backward(go)
+            torch.cuda.synchronize()
+            return [y.grad.clone()] + [None if p.grad is None else p.grad.clone() for p in params]
+        finally:
+            train_stack.set_bwd_kernel_variant(True)
+
+    new, old = run(True), run(False)
+    for a, b in zip(new, old):
+        assert (a is None) == (b is None)
+        if a is not None:
+            scale = max(1.0, float(b.abs().max()))
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * scale)
+
+
 def test_mlp_stack_deferred_weight_gradient_sums():
     """The weight-gradient reductions of all stacks run as ONE launch at the end of the autograd pass (train_stack._defer):
     same gradients as the immediate reductions; more layers in a pass than one kernel-argument pack holds; a second pass
