@@ -1,0 +1,172 @@
+"""Plain linear layers of the training path with the WEIGHT GRADIENT deferred to the end of the autograd pass.
+
+    linear(x, weight, bias=None)                     torch.nn.functional.linear for 2-D x and a weight PARAMETER
+                                                     (C_out, C_in[, 1[, 1]]); same values forward
+    per_point_first_layer(x, groups, D)              the per-point halves x . W_f^T of the first layers of set-abstraction
+                                                     modules whose weights are [feature | xyz | centre] column blocks
+                                                     (reference pointnet_utils.py:389-403, :566-581), plus the xyz / centre
+                                                     blocks as differentiable views
+
+Nothing reads a weight gradient before the optimiser step, and `grad_out^T . x` reduces 672 ... 32768 rows into a small
+matrix -- as separate library GEMMs these were 15 latency-bound launches of a training step.  The backward here computes the
+input gradient at once (it is on the critical path) and only RECORDS (grad_out, x, where dW goes); ONE grouped launch at the
+end of the pass (train_stack's end-of-pass callback, csrc/train_wgrad.hip: pn2x_wgrad_multi) computes every recorded product,
+writing straight into the tensor autograd adopted as `.grad` (for a first-layer weight: into its feature column block).
+
+Deferring is only sound where autograd ADOPTS the returned tensor and nothing reads it inside the pass (train_stack._may_defer:
+leaf parameter without gradient, without hooks, met once in the pass; off under DistributedDataParallel).  Otherwise the
+product is a library GEMM inside the pass, as before.  GPU tensors only (no CPU path).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import pointnet2_hip as _native
+from . import train_stack as _ts
+
+_f32 = torch.float32
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """t as a 2-D operand the grouped kernel takes: unit column stride, row stride >= columns."""
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1] or t.dtype != _f32:
+        t = t.contiguous().float()
+    return t
+
+
+def _defer_ok(params) -> bool:
+    ok = _ts._may_defer(params)
+    if ok:
+        if _ts._enter_task():
+            torch.autograd.Variable._execution_engine.queue_callback(_ts._flush_reductions)
+        _ts._pending_params.update(p.data_ptr() for p in params)
+    return ok
+
+
+def _record(g, x, dw_owner, dw_ptr, lddw, n, k):
+    _ts._pending.append(_ts.WgradItem(g, x, dw_owner, dw_ptr, lddw, n, k, _native._stream(g)))
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w2 = weight.view(weight.shape[0], -1)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.mm(x, w2.t()) if bias is None else torch.addmm(bias, x, w2.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        w2 = weight.view(weight.shape[0], -1)
+        dx = torch.mm(g, w2) if ctx.needs_input_grad[0] else None
+        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if g.is_cuda and _defer_ok([weight]):
+                gg, xx = _rows(g), _rows(x)
+                dw = torch.empty(w2.shape, dtype=_f32, device=g.device)
+                _record(gg, xx, dw, dw.data_ptr(), w2.shape[1], w2.shape[0], w2.shape[1])
+                dw = dw.view(weight.shape)  # a fresh view: autograd adopts it (no clone); the late product lands in its storage
+            else:
+                dw = torch.mm(g.t(), x).view(weight.shape)
+        return dx, dw, db
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
+    """x (R, C_in) . weight^T (+ bias): `weight` the PARAMETER itself, (C_out, C_in) or a 1x1 convolution's (C_out, C_in, 1[, 1])."""
+    return _Linear.apply(x, weight, bias)
+
+
+class _PerPoint(torch.autograd.Function):
+    """x (R, D); ws = the first-layer weights (C_s, D + 3 [+ Dc][, 1, 1]) of all scales of `len(sizes)` modules (sizes[m] scales
+    each).  Returns per module a1f_m = x . cat_s(w_s[:, :D])^T, then per weight its xyz block (C_s, 3), then per weight its centre
+    block (C_s, Dc) (only for weights that have one)."""
+
+    @staticmethod
+    def forward(ctx, x, D, sizes, *ws):
+        w2 = [w.view(w.shape[0], -1) for w in ws]
+        outs, wfs, i = [], [], 0
+        for n in sizes:
+            blocks = [w[:, :D] for w in w2[i:i + n]]
+            wf = blocks[0] if n == 1 else torch.cat(blocks, dim=0)
+            outs.append(torch.mm(x, wf.t()))
+            wfs.append(wf)  # (kept for the input gradient: no second concatenation in the backward)
+            i += n
+        outs += [w[:, D:D + 3] for w in w2]
+        centre = [w.shape[1] > D + 3 for w in w2]
+        outs += [w[:, D + 3:] for w, c in zip(w2, centre) if c]
+        ctx.save_for_backward(x, *ws, *wfs)
+        ctx.D, ctx.sizes, ctx.centre = D, tuple(sizes), centre
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        D, sizes, centre = ctx.D, ctx.sizes, ctx.centre
+        x, *rest = ctx.saved_tensors
+        ws, wfs = rest[:len(rest) - len(sizes)], rest[len(rest) - len(sizes):]
+        w2 = [w.view(w.shape[0], -1) for w in ws]
+        nm, nw = len(sizes), len(ws)
+        ga = grads[:nm]
+        gx = grads[nm:nm + nw]
+        gc_it = iter(grads[nm + nw:])
+        gc = [next(gc_it) if c else None for c in centre]
+        dev = x.device
+        # input gradient: sum over modules of g_m . W_f,m (the first product creates it, the others accumulate: no add pass)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            for m in range(nm):
+                if ga[m] is not None:
+                    if dx is None:
+                        dx = torch.mm(ga[m], wfs[m])
+                    else:
+                        dx.addmm_(ga[m], wfs[m])
+        live = [w for j, w in enumerate(ws) if ctx.needs_input_grad[3 + j]]
+        defer = bool(live) and x.is_cuda and _defer_ok(live)
+        xx = _rows(x) if defer else x
+        dws, i = [], 0
+        for m, n in enumerate(sizes):
+            g_m = ga[m]
+            if g_m is not None and defer:
+                g_m = _rows(g_m)
+            c0 = 0
+            for j in range(i, i + n):
+                w = w2[j]
+                C = w.shape[0]
+                if not ctx.needs_input_grad[3 + j]:
+                    dws.append(None)
+                    c0 += C
+                    continue
+                zx = gx[j] if gx[j] is not None else torch.zeros((C, 3), dtype=_f32, device=dev)
+                tail = [zx] + ([gc[j] if gc[j] is not None else torch.zeros((C, w.shape[1] - D - 3), dtype=_f32, device=dev)] if centre[j] else [])
+                if g_m is None:
+                    full = torch.cat([torch.zeros((C, D), dtype=_f32, device=dev)] + tail, dim=1)
+                elif defer:
+                    # [feature block: written at the end of the pass | xyz | centre] -- one concatenation; the placeholder's
+                    # (uninitialised) values are overwritten by the grouped launch
+                    full = torch.cat([torch.empty((C, D), dtype=_f32, device=dev)] + tail, dim=1)
+                    _record(g_m[:, c0:c0 + C], xx, full, full.data_ptr(), full.shape[1], C, D)
+                else:
+                    full = torch.cat([torch.mm(g_m[:, c0:c0 + C].t(), x)] + tail, dim=1)
+                dws.append(full.view(ws[j].shape))
+                c0 += C
+            i += n
+        return (dx, None, None, *dws)
+
+
+def per_point_first_layer(x: torch.Tensor, groups, D: int):
+    """groups: per module the list of its scales' first-layer weight PARAMETERS (C_s, D + 3 [+ Dc][, 1, 1]).
+    -> (a1f per module (R, sum_s C_s), [per module [per scale (xyz block, centre block | None)]])."""
+    sizes = tuple(len(g) for g in groups)
+    ws = [w for g in groups for w in g]
+    outs = _PerPoint.apply(x, int(D), sizes, *ws)
+    nm, nw = len(sizes), len(ws)
+    a1f = list(outs[:nm])
+    wx = list(outs[nm:nm + nw])
+    rest = iter(outs[nm + nw:])
+    wc = [next(rest) if w.view(w.shape[0], -1).shape[1] > D + 3 else None for w in ws]
+    blocks, i = [], 0
+    for n in sizes:
+        blocks.append([(wx[j], wc[j]) for j in range(i, i + n)])
+        i += n
+    return a1f, blocks

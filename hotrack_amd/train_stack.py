@@ -174,7 +174,55 @@ def _pending_now(item):
     _reduce_items([item])
 
 
+_lib.pn2x_wgrad_multi_max.restype = _ci
+_lib.pn2x_wgrad_multi_scratch_floats.argtypes = [_ci, ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_ci)]
+_lib.pn2x_wgrad_multi_scratch_floats.restype = _cl
+_lib.pn2x_wgrad_multi.argtypes = [_ci, ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_vp), ctypes.POINTER(_ci), ctypes.POINTER(_ci),
+                                  ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_vp), ctypes.POINTER(_ci), _vp, _cl, _vp]
+_lib.pn2x_wgrad_multi.restype = _ci
+
+
+class WgradItem:
+    """dw (N x K, row stride lddw, written in place) = g^T (R x N) . x (R x K): the weight gradient of a plain linear layer,
+    recorded by hotrack_amd.linear_dw during the autograd pass and computed with all the others by ONE grouped launch at its
+    end (csrc/train_wgrad.hip).  Holds g, x and the tensor dw points into until then."""
+    __slots__ = ("g", "x", "dw", "dw_ptr", "lddw", "n", "k", "stream")
+
+    def __init__(self, g, x, dw, dw_ptr, lddw, n, k, stream):
+        self.g, self.x, self.dw, self.dw_ptr, self.lddw, self.n, self.k, self.stream = g, x, dw, dw_ptr, lddw, n, k, stream
+
+
+def wgrad_multi(items):
+    """Run the recorded weight-gradient products (list of WgradItem) now."""
+    if not items:
+        return
+    st = items[0].stream
+    if any(it.stream != st for it in items):
+        raise RuntimeError("train_stack: deferred weight gradients recorded on different streams")
+    cap = int(_lib.pn2x_wgrad_multi_max())
+    dev = items[0].g.device
+    with torch.cuda.device(dev):
+        for i0 in range(0, len(items), cap):
+            chunk = items[i0:i0 + cap]
+            n = len(chunk)
+            g, x, dw = (_vp * n)(), (_vp * n)(), (_vp * n)()
+            ldg, ldx, rows, nn, kk, lddw = (_ci * n)(), (_ci * n)(), (_ci * n)(), (_ci * n)(), (_ci * n)(), (_ci * n)()
+            for j, it in enumerate(chunk):
+                g[j], x[j], dw[j] = it.g.data_ptr(), it.x.data_ptr(), it.dw_ptr
+                ldg[j], ldx[j], rows[j], nn[j], kk[j], lddw[j] = it.g.stride(0), it.x.stride(0), it.g.shape[0], it.n, it.k, it.lddw
+            nf = int(_lib.pn2x_wgrad_multi_scratch_floats(n, rows, nn, kk))
+            if nf < 0:
+                raise RuntimeError("train_stack: pn2x_wgrad_multi_scratch_floats rejected the problem list")
+            scratch = torch.empty(max(nf, 4), dtype=_f32, device=dev)
+            _native._check(_lib.pn2x_wgrad_multi(n, g, ldg, x, ldx, rows, nn, kk, dw, lddw, scratch.data_ptr(), scratch.numel(), st),
+                           "wgrad_multi")
+
+
 def _reduce_items(items):
+    wg = [it for it in items if isinstance(it, WgradItem)]
+    if wg:
+        wgrad_multi(wg)
+        items = [it for it in items if not isinstance(it, WgradItem)]
     if not items:
         return
     n = len(items)

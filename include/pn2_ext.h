@@ -593,6 +593,20 @@ int pn2x_tg_bwd(long rows, int n, int k, int gmode, const float *g, int ldg, con
                 int ldyp, const float *mean_p, const float *invstd_p, const float *gamma_p, const float *beta_p, float *gp, int ldgp,
                 double *sums_bwd_p, float *partial, long partial_floats, float *dw, void *stream);
 
+/* The weight gradients of `count` plain linear layers in one grouped launch (csrc/train_wgrad.hip):
+ *   dw[p] (n[p] x k[p], row stride lddw[p]) = g[p]^T (rows[p] x n[p], row stride ldg[p]) . x[p] (rows[p] x k[p], row stride ldx[p])
+ * -- what autograd computes as `grad_out.t() @ input` per torch.nn.functional.linear call (layer 1 of every stack over the
+ * un-grouped points, the rearrange linears, the 21-token tail: reference pointnet_utils.py:399-403,460-462,504-506,577-581,
+ * blocks.py:226-239, transformer.py:72-82).  Host arrays of `count` <= pn2x_wgrad_multi_max() entries; any n / k / strides
+ * (16-byte loads where an operand allows them); dw[p] is overwritten (a column block of a wider weight when lddw[p] > k[p]).
+ * Work is cut into (128 x 128 tile, row split) units of equal length over all problems; split problems go through `scratch`
+ * (>= pn2x_wgrad_multi_scratch_floats floats, 16-byte aligned) and are summed in a fixed order by a second launch:
+ * deterministic, no atomics.  PN2_ESCRATCH when the scratch is too small. */
+int pn2x_wgrad_multi_max(void);
+long pn2x_wgrad_multi_scratch_floats(int count, const int *rows, const int *n, const int *k);
+int pn2x_wgrad_multi(int count, const float *const *g, const int *ldg, const float *const *x, const int *ldx, const int *rows,
+                     const int *n, const int *k, float *const *dw, const int *lddw, float *scratch, long scratch_floats, void *stream);
+
 /* y (m x n, row stride ldy) = act(x (m x k) . w^T (w: n x k) + bias (n | NULL)), relu != 0: ReLU -- a dense layer over FEW rows
  * (the B = 1 tracking loop: 21 ... 1024 rows; csrc/linear_small.hip): one workgroup per 32 x 32 output block, its four waves
  * splitting the reduction.  Same result as the BLAS library up to summation order. */

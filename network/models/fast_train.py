@@ -83,6 +83,7 @@ class FastTrain:
         self.ws = None
         import os
         self.use_fused_stacks = os.environ.get("HOTRACK_FUSED_STACKS", "1") != "0"  # 0: round-2 path (library GEMMs + streaming BN)
+        self.defer_wgrad = os.environ.get("HOTRACK_DEFER_WGRAD", "1") != "0"  # 0: every weight gradient a library GEMM inside the pass
 
     @staticmethod
     def supported(net) -> bool:
@@ -107,15 +108,31 @@ class FastTrain:
             from hotrack_amd import train_stack
             widths = [c.weight.shape[0] for c in convs]
             if train_stack.stack_supported(widths[0], widths[1:]):
-                y1 = x2d if first_done else F.linear(x2d, _w2d(convs[0]))
+                y1 = x2d if first_done else self._linear(x2d, convs[0])
                 layers = [train_stack.Layer(None, bns[0], convs[0].bias)]
                 layers += [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(convs[1:], bns[1:])]
                 return train_stack.mlp_stack(y1, layers, self.ws, max_over, aux=aux if first_done else None)
         last = len(convs) - 1
         for i, (conv, bn) in enumerate(zip(convs, bns)):
-            y = x2d if (first_done and i == 0) else F.linear(x2d, _w2d(conv))
+            y = x2d if (first_done and i == 0) else self._linear(x2d, conv)
             x2d = bn_relu_max(y, max_over, bn, self.ws, conv.bias) if (max_over and i == last) else bn_relu(y, bn, self.ws, conv.bias)
         return x2d
+
+    def _linear(self, x2d, conv, bias=None):
+        """x2d . W^T (+ bias) for a Linear / 1x1 convolution module's weight; the weight gradient is computed by the grouped
+        end-of-pass launch (hotrack_amd.linear_dw) unless HOTRACK_DEFER_WGRAD=0."""
+        if self.defer_wgrad:
+            from hotrack_amd.linear_dw import linear
+            return linear(x2d, conv.weight, bias)
+        return F.linear(x2d, _w2d(conv), bias)
+
+    def _per_point(self, feat2d, mods, D):
+        """Per module (first-layer blocks [(None, xyz block, centre block | None) per scale], feat2d . W_f^T): the per-point halves of
+        the first layers of `mods`, which all read the same rows (one Function: one input gradient, deferred weight gradients)."""
+        from hotrack_amd.linear_dw import per_point_first_layer
+        groups = [[convs[0].weight for convs in m.conv_blocks] for m in mods]
+        a1f, blocks = per_point_first_layer(feat2d, groups, D)
+        return [([(None, wx, wc) for wx, wc in b], a) for b, a in zip(blocks, a1f)]
 
     @staticmethod
     def _first_layer_blocks(mod, D, has_center):
@@ -138,6 +155,9 @@ class FastTrain:
         a1f = cadd = None
         if pre is not None:
             w1, a1f2d = pre
+            a1f = a1f2d.view(B, N, -1)
+        elif D and self.defer_wgrad:
+            (w1, a1f2d), = self._per_point(feat2d, [mod], D)
             a1f = a1f2d.view(B, N, -1)
         else:
             w1, wf = self._first_layer_blocks(mod, D, center2d is not None)
@@ -270,9 +290,12 @@ class FastTrain:
         # ---- q1 -> r1 -> q2 -> r2 around the J keypoints; one kNN search for both neighbourhood sizes ------------------
         idxs, invs = geo["knn"], geo["knn_inv"]
         # the per-point halves of both modules' first layers read src2: one Function, one input gradient (_Linear2Shared)
-        w1_q1, wf_q1 = self._first_layer_blocks(net.q1, C, False)
-        w1_q2, wf_q2 = self._first_layer_blocks(net.q2, C, True)
-        a1f_q1, a1f_q2 = _Linear2Shared.apply(src2, wf_q1, wf_q2)
+        if self.defer_wgrad:
+            (w1_q1, a1f_q1), (w1_q2, a1f_q2) = self._per_point(src2, [net.q1, net.q2], C)
+        else:
+            w1_q1, wf_q1 = self._first_layer_blocks(net.q1, C, False)
+            w1_q2, wf_q2 = self._first_layer_blocks(net.q2, C, True)
+            a1f_q1, a1f_q2 = _Linear2Shared.apply(src2, wf_q1, wf_q2)
         # both modules gather through the same neighbour lists: inverted once (geometry) for the two backward scatters
         f11 = self._sa_scales(net.q1, xyz, kp, src2, idxs, pre=(w1_q1, a1f_q1), invs=invs)             # (B,J,C)
         f12 = self._rearrange(net.r1, f11)                                                                 # (B*J, C)
@@ -295,6 +318,9 @@ class FastTrain:
             g = gather_rows(tok, cache[0], cache[1])  # (B, J*re, C); backward: one segment-sum launch
         else:
             g = tok.index_select(1, cache[0][0].long())
+        if os.environ.get("HOTRACK_DEFER_WGRAD", "1") != "0":
+            from hotrack_amd.linear_dw import linear
+            return linear(g.view(B * J, mod.re * C), mod.linear.weight, mod.linear.bias)
         return F.linear(g.view(B * J, mod.re * C), mod.linear.weight.squeeze(-1), mod.linear.bias)
 
 
@@ -375,12 +401,16 @@ class FastTail:
         seed_used = torch.empty(1, dtype=torch.int64, device=dev)
         grads = T.TailGrads(dev, 14 * C + 2 * H + Hf + 3 * Hf + 3)
         pd = lambda m: float(m.p) if m.training else 0.0
+        if os.environ.get("HOTRACK_DEFER_WGRAD", "1") != "0":
+            from hotrack_amd.linear_dw import linear as lin
+        else:
+            lin = lambda x, w: F.linear(x, w.view(w.shape[0], -1))
         h = T.ln(rows, s11.norm1, c11.norm1, grads, seed_dev=self.seed, seed_out=seed_used)
-        d = T.relu_dropout(F.linear(h, c11.linear1.weight), c11.linear1.bias, pd(c11.dropout2), 1, seed_used, grads)
-        h2 = T.ln(h, c11.norm2, c3.norm1, grads, y=F.linear(d, c11.linear2.weight), bias=c11.linear2.bias, p=pd(c11.dropout3), site=2, seed_in=seed_used)
-        d2 = T.relu_dropout(F.linear(h2, c3.linear1.weight), c3.linear1.bias, pd(c3.dropout2), 3, seed_used, grads)
-        h3 = T.ln(h2, c3.norm2, None, grads, y=F.linear(d2, c3.linear2.weight), bias=c3.linear2.bias, p=pd(c3.dropout3), site=4, seed_in=seed_used)
-        hf = T.relu_dropout(F.linear(h3, net.final_mlp[0].weight.squeeze(-1)), net.final_mlp[0].bias, 0.0, 0, None, grads)
+        d = T.relu_dropout(lin(h, c11.linear1.weight), c11.linear1.bias, pd(c11.dropout2), 1, seed_used, grads)
+        h2 = T.ln(h, c11.norm2, c3.norm1, grads, y=lin(d, c11.linear2.weight), bias=c11.linear2.bias, p=pd(c11.dropout3), site=2, seed_in=seed_used)
+        d2 = T.relu_dropout(lin(h2, c3.linear1.weight), c3.linear1.bias, pd(c3.dropout2), 3, seed_used, grads)
+        h3 = T.ln(h2, c3.norm2, None, grads, y=lin(d2, c3.linear2.weight), bias=c3.linear2.bias, p=pd(c3.dropout3), site=4, seed_in=seed_used)
+        hf = T.relu_dropout(lin(h3, net.final_mlp[0].weight), net.final_mlp[0].bias, 0.0, 0, None, grads)
         # last Conv1d + residual on the initial keypoints + de-canonicalisation: one launch per direction
         return T.pose_head(hf, net.final_mlp[2].weight.squeeze(-1), net.final_mlp[2].bias, xyz1, canon_pose["rotation"],
                            canon_pose["translation"], canon_pose["scale"], grads)
