@@ -16,6 +16,7 @@
 //   scatter_add_rows      dIn[b, idx[b,j], :] += dOut[b, j, :]                   (group_points_grad on rows)
 //   interp_pm_bwd         dPts[b, idx[b,j,t], :] += w[b,j,t] * dOut[b, j, :]      (three_interpolate_grad on rows)
 // All HBM-bound: 16-byte accesses along the contiguous channel axis, one pass over each operand.
+#include <cstdlib>
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
@@ -448,10 +449,7 @@ bn_relu_bwd_apply_rel_kernel(long rows, int C, const float *__restrict__ dH, int
         }
         const long r0 = (long)blockIdx.x * rows_per_block;
         const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-        for (long r = r0 + rr; r < r1; r += rpp) {
-            const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
-            const float4 g = *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q);
-            const float e0 = rel[r * 3 + 0], e1 = rel[r * 3 + 1], e2 = rel[r * 3 + 2];
+        auto one_row = [&](long r, float4 y, float4 g, float e0, float e1, float e2) {
             const float yy[4] = {y.x, y.y, y.z, y.w};
             float gg[4] = {g.x, g.y, g.z, g.w}, o[4];
 #pragma unroll
@@ -462,7 +460,28 @@ bn_relu_bwd_apply_rel_kernel(long rows, int C, const float *__restrict__ dH, int
                 a[i][0] += o[i] * e0; a[i][1] += o[i] * e1; a[i][2] += o[i] * e2;
             }
             *reinterpret_cast<float4 *>(dY + r * ldo + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        };
+        // four rows per round, their ten loads in flight together (same values, same order of the d(W_xyz) additions)
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        long r = r0 + rr;
+        for (; r + 3L * rpp < r1; r += 4L * rpp) {
+            v4 y[4], g[4];
+            float e[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long ru = r + (long)u * rpp;
+                y[u] = *reinterpret_cast<const v4 *>(Y + ru * ldy + 4 * q);
+                g[u] = *reinterpret_cast<const v4 *>(dH + ru * ldd + 4 * q);
+                e[u][0] = rel[ru * 3 + 0]; e[u][1] = rel[ru * 3 + 1]; e[u][2] = rel[ru * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                one_row(r + (long)u * rpp, make_float4(y[u].x, y[u].y, y[u].z, y[u].w), make_float4(g[u].x, g[u].y, g[u].z, g[u].w),
+                        e[u][0], e[u][1], e[u][2]);
         }
+        for (; r < r1; r += rpp)
+            one_row(r, *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q), *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q),
+                    rel[r * 3 + 0], rel[r * 3 + 1], rel[r * 3 + 2]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -575,15 +594,11 @@ sa_layer1_stats_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f
             for (int c = 0; c < 3; ++c) w[i][c] = wx[(size_t)(4 * q + i) * wx_ld + c];
     }
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sq = sm;
-    for (int r = r0 + rr; r < r1; r += rpp) {
-        const int s = r / K;
-        const int j = idx[(size_t)b * sk + r];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a1f) acc = *reinterpret_cast<const float4 *>(a1f + ((size_t)b * n + j) * a1f_ld + 4 * q);
+    // one row: the expressions of sa_layer1_kernel (same floats); sums taken in row order
+    auto finish = [&](int r, float4 acc, float px, float py, float pz, float cx, float cy, float cz, float4 cv) {
         if (xyz) {
-            const float *p = xyz + ((size_t)b * n + j) * 3, *c = cxyz + ((size_t)b * S + s) * 3;
-            const float rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
-            acc.x += w[0][0] * rx + w[0][1] * ry + w[0][2] * rz;  // the expressions of sa_layer1_kernel: same floats
+            const float rx = px - cx, ry = py - cy, rz = pz - cz;
+            acc.x += w[0][0] * rx + w[0][1] * ry + w[0][2] * rz;
             acc.y += w[1][0] * rx + w[1][1] * ry + w[1][2] * rz;
             acc.z += w[2][0] * rx + w[2][1] * ry + w[2][2] * rz;
             acc.w += w[3][0] * rx + w[3][1] * ry + w[3][2] * rz;
@@ -592,13 +607,54 @@ sa_layer1_stats_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f
                 o[0] = rx; o[1] = ry; o[2] = rz;
             }
         }
-        if (cadd) {
-            const float4 v = *reinterpret_cast<const float4 *>(cadd + ((size_t)b * S + s) * cadd_ld + 4 * q);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
+        if (cadd) { acc.x += cv.x; acc.y += cv.y; acc.z += cv.z; acc.w += cv.w; }
         *reinterpret_cast<float4 *>(out + ((size_t)b * sk + r) * (4 * Q) + 4 * q) = acc;
         sm.x += acc.x; sm.y += acc.y; sm.z += acc.z; sm.w += acc.w;
         sq.x += acc.x * acc.x; sq.y += acc.y * acc.y; sq.z += acc.z * acc.z; sq.w += acc.w * acc.w;
+    };
+    int r = r0 + rr;
+    // four rows per round: their neighbour indices first, then every gather of the round in flight together (a row is two
+    // dependent memory round trips -- index, then the rows it names -- and one row at a time made this kernel a latency chain:
+    // 1.4 TB/s on sa1's 262144 x 32 output).  (Native vector types: an array of float4 STRUCTS stays in scratch memory.)
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    for (; r + 3 * rpp < r1; r += 4 * rpp) {
+        int j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = idx[(size_t)b * sk + r + u * rpp];
+        v4 acc[4], cv[4];
+        float px[4], py[4], pz[4], cx[4], cy[4], cz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[u] = a1f ? *reinterpret_cast<const v4 *>(a1f + ((size_t)b * n + j[u]) * a1f_ld + 4 * q) : v4{0.f, 0.f, 0.f, 0.f};
+            px[u] = py[u] = pz[u] = cx[u] = cy[u] = cz[u] = 0.f;
+            cv[u] = v4{0.f, 0.f, 0.f, 0.f};
+            const int s = (r + u * rpp) / K;
+            if (xyz) {
+                const float *p = xyz + ((size_t)b * n + j[u]) * 3, *c = cxyz + ((size_t)b * S + s) * 3;
+                px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+                cx[u] = c[0]; cy[u] = c[1]; cz[u] = c[2];
+            }
+            if (cadd) cv[u] = *reinterpret_cast<const v4 *>(cadd + ((size_t)b * S + s) * cadd_ld + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            finish(r + u * rpp, make_float4(acc[u].x, acc[u].y, acc[u].z, acc[u].w), px[u], py[u], pz[u], cx[u], cy[u], cz[u],
+                   make_float4(cv[u].x, cv[u].y, cv[u].z, cv[u].w));
+    }
+    for (; r < r1; r += rpp) {
+        const int s = r / K;
+        const int j = idx[(size_t)b * sk + r];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a1f) acc = *reinterpret_cast<const float4 *>(a1f + ((size_t)b * n + j) * a1f_ld + 4 * q);
+        float px = 0.f, py = 0.f, pz = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+        if (xyz) {
+            const float *p = xyz + ((size_t)b * n + j) * 3, *c = cxyz + ((size_t)b * S + s) * 3;
+            px = p[0]; py = p[1]; pz = p[2];
+            cx = c[0]; cy = c[1]; cz = c[2];
+        }
+        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cadd) cv = *reinterpret_cast<const float4 *>(cadd + ((size_t)b * S + s) * cadd_ld + 4 * q);
+        finish(r, acc, px, py, pz, cx, cy, cz, cv);
     }
     block_reduce_to_sums(sm, sq, Q, rpp, 4 * Q, sums);
 }
@@ -697,6 +753,48 @@ inverse_index_kernel(int n_dst, int L, const int *__restrict__ idx_all, int *__r
     for (int e = threadIdx.x; e < L; e += kTT) order[atomicAdd(&cnt[key(e)], 1)] = e;
 }
 
+// acc += sum over p = p0, p0 + step, ... < p1 of [w] . row(order[p]), in that order.  Four list entries per round: their source
+// indices first, then the four row segments (and weights) in flight together -- an entry is two dependent memory round trips, and
+// one entry at a time made the long segments (ball-query padding) latency chains.  Same additions in the same order.
+template <int T>
+__device__ __forceinline__ void segment_rows_sum(float4 &acc, int p0, int p1, int step, const int *__restrict__ order,
+                                                 const float *__restrict__ src, int ldo, const float *__restrict__ weight) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    int p = p0;
+    for (; p + 3 * step < p1; p += 4 * step) {
+        int e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = order[p + u * step];
+        v4 v[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = T == 1 ? e[u] : e[u] / T;
+            v[u] = *reinterpret_cast<const v4 *>(src + (size_t)j * ldo);
+            w[u] = T == 1 ? 1.f : weight[e[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (T == 1) {
+                acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+            } else {
+                acc.x += w[u] * v[u].x; acc.y += w[u] * v[u].y; acc.z += w[u] * v[u].z; acc.w += w[u] * v[u].w;
+            }
+        }
+    }
+    for (; p < p1; p += step) {
+        const int e = order[p];
+        const int j = T == 1 ? e : e / T;
+        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)j * ldo);
+        if constexpr (T == 1) {
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        } else {
+            const float w = weight[e];
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+    }
+}
+
 template <int T>  // index entries per source row: 1 = plain row scatter, 3 = three-NN interpolation (weighted)
 __global__ void __launch_bounds__(kTT)
 rows_segment_sum_kernel(int n_dst, int m_src, int Q, const float *__restrict__ dOut, int ldo, const int *__restrict__ offsets_all,
@@ -711,17 +809,7 @@ rows_segment_sum_kernel(int n_dst, int m_src, int Q, const float *__restrict__ d
     const float *__restrict__ src = dOut + (size_t)b * m_src * ldo + 4 * q;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int p1 = offsets[i + 1];
-    for (int p = offsets[i]; p < p1; ++p) {
-        const int e = order[p];
-        const int j = T == 1 ? e : e / T;
-        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)j * ldo);
-        if constexpr (T == 1) {
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        } else {
-            const float w = weight_all[(size_t)b * m_src * T + e];
-            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
-        }
-    }
+    segment_rows_sum<T>(acc, offsets[i], p1, 1, order, src, ldo, weight_all + (size_t)b * m_src * T);
     float4 *dst = reinterpret_cast<float4 *>(dIn + ((size_t)b * n_dst + i) * ldi + 4 * q);
     if (accumulate) {
         const float4 d = *dst;
@@ -749,17 +837,7 @@ rows_segment_sum_split_kernel(int n_dst, int m_src, int Q, int EL, const float *
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n_dst) {
         const int p1 = offsets[i + 1];
-        for (int p = offsets[i] + el; p < p1; p += EL) {
-            const int e = order[p];
-            const int j = T == 1 ? e : e / T;
-            const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)j * ldo);
-            if constexpr (T == 1) {
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            } else {
-                const float w = weight_all[(size_t)b * m_src * T + e];
-                acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
-            }
-        }
+        segment_rows_sum<T>(acc, offsets[i] + el, p1, EL, order, src, ldo, weight_all + (size_t)b * m_src * T);
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -1162,7 +1240,8 @@ extern "C" int pn2x_sa_layer1_stats(int b, int n, int s, int k, int c1, const fl
     if ((a1f && (a1f_ld < c1 || a1f_ld % 4)) || (cadd && (cadd_ld < c1 || cadd_ld % 4))) return PN2_EINVAL;
     if (((uintptr_t)a1f | (uintptr_t)cadd | (uintptr_t)out) % 16) return PN2_EINVAL;
     const int rpp = kTT / Q, sk = s * k;
-    int rpb = (int)(((long)sk * b + 2047) / 2048);  // ~2048 workgroups on a large problem, at least 8 rows per thread
+    static const int target_wgs = [] { const char *e = getenv("PN2_SA1_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+    int rpb = (int)(((long)sk * b + target_wgs - 1) / target_wgs);  // ~2048 workgroups on a large problem, at least 8 rows per thread
     if (rpb < 8 * rpp) rpb = 8 * rpp;
     rpb = (rpb + rpp - 1) / rpp * rpp;
     hipLaunchKernelGGL(sa_layer1_stats_kernel, dim3((unsigned)((sk + rpb - 1) / rpb), b), dim3(kTT), 0, (hipStream_t)stream, n, s, k, Q, a1f,

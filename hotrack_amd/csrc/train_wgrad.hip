@@ -27,8 +27,14 @@
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
+#ifndef WGM_DMA
+#define WGM_DMA 1   // 1: chunks go from memory straight into LDS (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass)
+#endif
 #ifndef WGM_NBUF
-#define WGM_NBUF 1  // LDS chunk buffers: 1 = two barriers per chunk, three workgroups per CU; 2 = one barrier, two workgroups
+#define WGM_NBUF (WGM_DMA ? 2 : 1)  // LDS chunk buffers: 1 = two barriers per chunk; 2 = one barrier per chunk, 64 KB per workgroup
+#endif
+#if WGM_DMA && WGM_NBUF != 2
+#error "WGM_DMA needs two LDS chunk buffers"
 #endif
 
 namespace pn2 {
@@ -46,7 +52,7 @@ constexpr int TN = 128, TK = 128;  // output tile: rows (channels of G) x column
 #define WGM_RC 32
 #endif
 constexpr int RC = WGM_RC;         // rows per reduction chunk
-constexpr int kMaxP = 20;          // problems per launch (kernel-argument table)
+constexpr int kMaxP = 40;          // problems per launch (kernel-argument table: 72 bytes each)
 constexpr int NBUF = WGM_NBUF;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -111,6 +117,7 @@ __device__ __forceinline__ void segment(const Prob &p, float *__restrict__ parti
         vg[i] = n0 + 4 * q < p.N ? 4u * ((unsigned)(rr0 + 8 * i) * p.ldg + 4 * q) : 0x7ffffff0u;
         vx[i] = k0 + 4 * q < p.K ? 4u * ((unsigned)(rr0 + 8 * i) * p.ldx + 4 * q) : 0x7ffffff0u;
     }
+#if !WGM_DMA
     f32x4 pg[LI], px[LI];
     auto prefetch = [&](int ci) {
 #ifdef WGM_PROBE_NOLOAD  // timing probe (wrong results): no global loads, no LDS writes
@@ -138,6 +145,7 @@ __device__ __forceinline__ void segment(const Prob &p, float *__restrict__ parti
 #pragma unroll
         for (int i = 0; i < LI; ++i) *reinterpret_cast<f32x4 *>(Xd + (rr0 + 8 * i) * TK + 4 * q) = px[i];
     };
+#endif
     // wave (wn, wk) owns the 32 x 32 blocks {wn, wn + 2} x {wk, wk + 2} of the tile's 4 x 4 (its two operand fragments of a step are
     // 64 floats apart and consecutive steps 256: every LDS read of a chunk is one base register + an immediate, ds_read2st64_b32);
     // blocks that lie wholly outside the problem (edge tiles: K = 131 has a 3-column second tile) are skipped, wave-uniformly
@@ -185,6 +193,33 @@ __device__ __forceinline__ void segment(const Prob &p, float *__restrict__ parti
             }
         }
     };
+#if WGM_DMA
+    // the chunk lands in LDS in lane order: lane l of wave w fetches quad (l & 31) of row 2 w + (l >> 5) + 8 i, i.e. the wave's 64 quads
+    // are two consecutive 512-byte rows of the tile -- exactly base + 16 l, the only layout LDS-DMA can write.  Out-of-range lanes
+    // write zeros.  Chunk ci + 1 is requested right behind the barrier that publishes chunk ci and has a whole chunk of matrix
+    // instructions to arrive (hipcc waits vmcnt(0) in front of the next barrier).
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto issue = [&](int ci, float *Gd, float *Xd) {
+#ifdef WGM_PROBE_NOLOAD
+        return;
+#endif
+        const unsigned go = uniform((unsigned)ci) * gstep, xo = uniform((unsigned)ci) * xstep;
+        const rsrc_t rg = make_rsrc(gb + go, gbytes - go);
+        const rsrc_t rx = make_rsrc(xb + xo, xbytes - xo);
+#pragma unroll
+        for (int i = 0; i < LI; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr)(Gd + (2 * wave + 8 * i) * TN), 16, (int)vg[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < LI; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(Xd + (2 * wave + 8 * i) * TK), 16, (int)vx[i], 0, 0, 0);
+    };
+    issue(0, lds, lds + RC * TN);
+    for (int ci = 0; ci < nc; ++ci) {
+        float *cur = lds + (ci & 1) * (RC * (TN + TK)), *nxt = lds + ((ci + 1) & 1) * (RC * (TN + TK));
+        WGM_SYNC();  // chunk ci is in LDS for every wave; nobody reads the other buffer any more
+        if (ci + 1 < nc) issue(ci + 1, nxt, nxt + RC * TN);
+        mma(cur, cur + RC * TN);
+    }
+    WGM_SYNC();  // (the next segment's first chunk goes into buffer 0)
+#else
     if constexpr (NBUF == 1) {
         float *Gd = lds, *Xd = lds + RC * TN;
         prefetch(0);
@@ -207,6 +242,7 @@ __device__ __forceinline__ void segment(const Prob &p, float *__restrict__ parti
             WGM_SYNC();
         }
     }
+#endif
     // accumulator element r of block (i, j): row 32 wn + 64 i + (r & 3) + 8 (r >> 2) + 4 kh, column 32 wk + 64 j + l31
     if (c0 == 0 && c1 == p.chunks) {  // the whole row range: this IS the result
         // 4-byte buffer stores against [first element of the tile, last element of the problem]: rows beyond N fall outside the

@@ -47,12 +47,37 @@ def _record(g, x, dw_owner, dw_ptr, lddw, n, k):
     _ts._pending.append(_ts.WgradItem(g, x, dw_owner, dw_ptr, lddw, n, k, _native._stream(g)))
 
 
+_consts = {}
+
+
+def _ones(rows: int, dev) -> torch.Tensor:
+    """(rows, 1) of ones: `g^T . ones` = the column sums of g (a bias gradient) as one more problem of the grouped launch."""
+    key = ("ones", dev)
+    t = _consts.get(key)
+    if t is None or t.shape[0] < rows:
+        t = torch.ones((max(rows, 1024), 1), dtype=_f32, device=dev)
+        _consts[key] = t
+    return t[:rows]
+
+
+def _eye(n: int, dev) -> torch.Tensor:
+    """(n, n) identity: `eye^T . block` copies a small gradient block into its columns of a wider weight gradient at the end of
+    the pass (instead of a concatenation launch inside it)."""
+    key = ("eye", dev)
+    t = _consts.get(key)
+    if t is None or t.shape[0] < n:
+        t = torch.eye(max(n, 128), dtype=_f32, device=dev)
+        _consts[key] = t
+    return t[:n, :n]
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         w2 = weight.view(weight.shape[0], -1)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias = bias if (bias is not None and bias.requires_grad) else None  # (identity only: which parameter receives db)
         return torch.mm(x, w2.t()) if bias is None else torch.addmm(bias, x, w2.t())
 
     @staticmethod
@@ -60,16 +85,24 @@ class _Linear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         w2 = weight.view(weight.shape[0], -1)
         dx = torch.mm(g, w2) if ctx.needs_input_grad[0] else None
-        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        dw = None
-        if ctx.needs_input_grad[1]:
-            if g.is_cuda and _defer_ok([weight]):
-                gg, xx = _rows(g), _rows(x)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias is not None
+        dw = db = None
+        params = ([weight] if ctx.needs_input_grad[1] else []) + ([ctx.bias] if want_b else [])
+        if params and g.is_cuda and _defer_ok(params):
+            gg = _rows(g)
+            if ctx.needs_input_grad[1]:
                 dw = torch.empty(w2.shape, dtype=_f32, device=g.device)
-                _record(gg, xx, dw, dw.data_ptr(), w2.shape[1], w2.shape[0], w2.shape[1])
+                _record(gg, _rows(x), dw, dw.data_ptr(), w2.shape[1], w2.shape[0], w2.shape[1])
                 dw = dw.view(weight.shape)  # a fresh view: autograd adopts it (no clone); the late product lands in its storage
-            else:
+            if want_b:  # the column sums of g: one more (N x 1) problem of the grouped launch
+                db = torch.empty((w2.shape[0], 1), dtype=_f32, device=g.device)
+                _record(gg, _ones(g.shape[0], g.device), db, db.data_ptr(), 1, w2.shape[0], 1)
+                db = db.view(-1)
+        else:
+            if ctx.needs_input_grad[1]:
                 dw = torch.mm(g.t(), x).view(weight.shape)
+            if want_b:
+                db = g.sum(0)
         return dx, dw, db
 
 
@@ -142,10 +175,17 @@ class _PerPoint(torch.autograd.Function):
                 if g_m is None:
                     full = torch.cat([torch.zeros((C, D), dtype=_f32, device=dev)] + tail, dim=1)
                 elif defer:
-                    # [feature block: written at the end of the pass | xyz | centre] -- one concatenation; the placeholder's
-                    # (uninitialised) values are overwritten by the grouped launch
-                    full = torch.cat([torch.empty((C, D), dtype=_f32, device=dev)] + tail, dim=1)
-                    _record(g_m[:, c0:c0 + C], xx, full, full.data_ptr(), full.shape[1], C, D)
+                    # [feature block | xyz | centre], every block written at the end of the pass by the grouped launch: the feature
+                    # block as g^T x, the two small ones as eye^T . block (a copy as one more problem: no concatenation launch here)
+                    full = torch.empty((C, w.shape[1]), dtype=_f32, device=dev)
+                    ld = full.shape[1]
+                    _record(g_m[:, c0:c0 + C], xx, full, full.data_ptr(), ld, C, D)
+                    eye = _eye(C, dev)
+                    col = D
+                    for blk in tail:
+                        blk = _rows(blk)
+                        _record(eye, blk, full, full.data_ptr() + 4 * col, ld, C, blk.shape[1])
+                        col += blk.shape[1]
                 else:
                     full = torch.cat([torch.mm(g_m[:, c0:c0 + C].t(), x)] + tail, dim=1)
                 dws.append(full.view(ws[j].shape))

@@ -31,7 +31,7 @@ def main():
     from hotrack_amd.train_ops import sa_layer1
     lib = train_ops._lib
     out = {}
-    for name, B, N, S, K, C1, D in [("sa1", 32, 1024, 256, 32, 32, 0), ("sa2", 32, 256, 128, 32, 64, 64), ("q64", 32, 1024, 21, 64, 128, 384)]:
+    for name, B, N, S, K, C1, D in [("sa1", 32, 1024, 256, 32, 32, 0), ("sa2", 32, 256, 128, 32, 64, 64), ("q64", 32, 1024, 21, 64, 128, 384), ("q16", 32, 1024, 21, 16, 128, 384)]:
         xyz = torch.rand(B, N, 3, device="cuda")
         cxyz = torch.rand(B, S, 3, device="cuda")
         a1f = torch.randn(B, N, C1, device="cuda") if D else None
@@ -47,6 +47,13 @@ def main():
         def stats_after():
             lib.pn2x_bn_stats(R, C1, y.data_ptr(), C1, sums.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
+        from hotrack_amd.train_ops import Workspace
+        ws = Workspace("cuda")
+
+        def with_stats():
+            ws.used = 0
+            sa_layer1(a1f, None, xyz, cxyz, [idx], [wx], ws=ws, aux={})
+
         dy = torch.randn(R, C1, device="cuda")
         rel = torch.randn(R, 3, device="cuda")
         dwx = torch.empty(C1, 3, device="cuda")
@@ -61,7 +68,7 @@ def main():
 
         outer3()
         err = float((dwx - torch.mm(dy.t(), rel)).abs().max())
-        out[name] = {"rows": R, "c1": C1, "sa_layer1_us": round(timed(plain), 1), "bn_stats_us": round(timed(stats_after), 1),
+        out[name] = {"rows": R, "c1": C1, "sa_layer1_us": round(timed(plain), 1), "sa_layer1_stats_us": round(timed(with_stats), 1), "bn_stats_us": round(timed(stats_after), 1),
                      "rows_outer3_us": round(timed(outer3), 1),
                      "torch_mm_us": round(timed(mm), 1), "outer3_max_err": err}
     print(json.dumps(out))
