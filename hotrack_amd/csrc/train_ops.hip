@@ -208,18 +208,27 @@ bn_relu_max_kernel(long groups, int K, int C, const float *__restrict__ Y, int l
 // item scans rows ks, ks + S, ...; the partial (max, first arg-max) pairs meet in LDS.  Same result as the serial scan: the
 // maximum, its FIRST row among equals, and a NaN sticks (with the last NaN row, as the serial update leaves it).  The channel
 // constants are computed once per workgroup (the serial kernel derives them per thread from the fp64 sums).
-__global__ void __launch_bounds__(kTT)
-bn_relu_max_split_kernel(long groups, int K, int C, int S, const float *__restrict__ Y, int ldy, const double *__restrict__ sums,
-                         const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ conv_bias, float eps,
-                         float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
-                         float *__restrict__ save_mean, float *__restrict__ save_invstd, float *__restrict__ out, int *__restrict__ arg) {
+struct MaxSplitArgs {
+    long groups; int K, C, S; const float *Y; int ldy; const double *sums; const float *gamma, *beta, *conv_bias; float eps, momentum;
+    float *running_mean, *running_var; long long *nbt; float *save_mean, *save_invstd, *out; int *arg;
+};
+__device__ __forceinline__ void bn_relu_max_split_body(const MaxSplitArgs &A, unsigned bx) {
+    const long groups = A.groups;
+    const int K = A.K, C = A.C, S = A.S, ldy = A.ldy;
+    const float *__restrict__ Y = A.Y, *__restrict__ gamma = A.gamma, *__restrict__ beta = A.beta, *__restrict__ conv_bias = A.conv_bias;
+    const double *__restrict__ sums = A.sums;
+    const float eps = A.eps, momentum = A.momentum;
+    float *__restrict__ running_mean = A.running_mean, *__restrict__ running_var = A.running_var;
+    long long *__restrict__ nbt = A.nbt;
+    float *__restrict__ save_mean = A.save_mean, *__restrict__ save_invstd = A.save_invstd, *__restrict__ out = A.out;
+    int *__restrict__ arg = A.arg;
     __shared__ float cst[4][kTT];        // mean, invstd, gamma, beta of the channels this workgroup touches (<= 256: 64 quads)
     __shared__ float pm[kTT][4];
     __shared__ int pa[kTT][4];
     const int Q = C >> 2;
     const int ipb = kTT / S;             // items per workgroup
     const long rows = groups * K;
-    const long item0 = (long)blockIdx.x * ipb;
+    const long item0 = (long)bx * ipb;
     // channels of this workgroup: items item0 .. item0 + ipb - 1 -> quads (item % Q): ipb >= Q covers all C channels (C <= 256),
     // else the ipb consecutive quads starting at item0 % Q (wrapping)
     const int nq = ipb < Q ? ipb : Q;
@@ -237,7 +246,7 @@ bn_relu_max_split_kernel(long groups, int K, int C, int S, const float *__restri
         const float mean = (float)m, invstd = (float)(1.0 / sqrt(v + (double)eps));
         cst[0][t] = mean; cst[1][t] = invstd; cst[2][t] = gamma[c]; cst[3][t] = beta[c];
     }
-    if (blockIdx.x == 0) {  // the consumer finalises the producer's statistics: saved mean / invstd, running estimates
+    if (bx == 0) {  // the consumer finalises the producer's statistics: saved mean / invstd, running estimates
         for (int c = threadIdx.x; c < C; c += kTT) {
             double s1 = 0.0, s2 = 0.0;
             for (int r = 0; r < kRep; ++r) {
@@ -301,6 +310,13 @@ bn_relu_max_split_kernel(long groups, int K, int C, int S, const float *__restri
         *reinterpret_cast<float4 *>(out + grp * C + 4 * q) = make_float4(relu_nan(m[0]), relu_nan(m[1]), relu_nan(m[2]), relu_nan(m[3]));
         *reinterpret_cast<int4 *>(arg + grp * C + 4 * q) = make_int4(am[0], am[1], am[2], am[3]);
     }
+}
+__global__ void __launch_bounds__(kTT)
+bn_relu_max_split_kernel(MaxSplitArgs a) { bn_relu_max_split_body(a, blockIdx.x); }
+__global__ void __launch_bounds__(kTT)
+bn_relu_max_split_pair_kernel(MaxSplitArgs a, MaxSplitArgs b, unsigned na) {
+    if (blockIdx.x < na) bn_relu_max_split_body(a, blockIdx.x);
+    else bn_relu_max_split_body(b, blockIdx.x - na);
 }
 
 struct BnSaved {
@@ -413,12 +429,21 @@ bn_relu_bwd_apply_kernel(long rows, int C, const float *__restrict__ dH, int ldd
 // The same pass for the first layer of a set-abstraction scale, which ALSO forms the partial sums of d(W_xyz) = dY^T rel (rel
 // (rows x 3): the relative coordinates sa_layer1 saved): dY is in registers here anyway, and the separate pass over it
 // (rows_outer3_kernel) re-read 33 MB per scale.  partial: [gridDim.x][C][3], summed by rows_outer3_sum_kernel.
-__global__ void __launch_bounds__(kTT)
-bn_relu_bwd_apply_rel_kernel(long rows, int C, const float *__restrict__ dH, int ldd, const float *__restrict__ Y, int ldy,
-                             const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
-                             const float *__restrict__ beta, const double *__restrict__ sums, int rows_per_block, int relu,
-                             float *__restrict__ dY, int ldo, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                             float *__restrict__ dbias, const float *__restrict__ rel, float *__restrict__ partial) {
+struct ApplyRelArgs {
+    long rows; int C; const float *dH; int ldd; const float *Y; int ldy;
+    const float *mean, *invstd, *gamma, *beta; const double *sums; int rows_per_block, relu;
+    float *dY; int ldo; float *dgamma, *dbeta, *dbias; const float *rel; float *partial;
+};
+// (bx: this problem's workgroup index -- two problems of one module's two neighbourhood sizes share a launch, below)
+__device__ __forceinline__ void bn_relu_bwd_apply_rel_body(const ApplyRelArgs &A, unsigned bx) {
+    const long rows = A.rows;
+    const int C = A.C, ldd = A.ldd, ldy = A.ldy, rows_per_block = A.rows_per_block, relu = A.relu, ldo = A.ldo;
+    const float *__restrict__ dH = A.dH, *__restrict__ Y = A.Y, *__restrict__ mean = A.mean, *__restrict__ invstd = A.invstd;
+    const float *__restrict__ gamma = A.gamma, *__restrict__ beta = A.beta, *__restrict__ rel = A.rel;
+    const double *__restrict__ sums = A.sums;
+    float *__restrict__ dY = A.dY, *__restrict__ dgamma = A.dgamma, *__restrict__ dbeta = A.dbeta, *__restrict__ dbias = A.dbias;
+    float *__restrict__ partial = A.partial;
+
     __shared__ float red[12][kTT];
     const int Q = C >> 2, rpp = kTT / Q;
     const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
@@ -439,7 +464,7 @@ bn_relu_bwd_apply_rel_kernel(long rows, int C, const float *__restrict__ dH, int
             sgx[i] = (float)sb;
             scale[i] = k.g[i] * k.invstd[i];
         }
-        if (blockIdx.x == 0 && rr == 0) {
+        if (bx == 0 && rr == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 dgamma[4 * q + i] = sgx[i];
@@ -447,7 +472,7 @@ bn_relu_bwd_apply_rel_kernel(long rows, int C, const float *__restrict__ dH, int
                 if (dbias) dbias[4 * q + i] = 0.f;
             }
         }
-        const long r0 = (long)blockIdx.x * rows_per_block;
+        const long r0 = (long)bx * rows_per_block;
         const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
         auto one_row = [&](long r, float4 y, float4 g, float e0, float e1, float e2) {
             const float yy[4] = {y.x, y.y, y.z, y.w};
@@ -489,7 +514,7 @@ bn_relu_bwd_apply_rel_kernel(long rows, int C, const float *__restrict__ dH, int
         for (int t = 0; t < 3; ++t) red[i * 3 + t][threadIdx.x] = a[i][t];
     __syncthreads();
     if (rr == 0) {
-        float *o = partial + (size_t)blockIdx.x * 3 * C + 12 * q;  // out[c][t], c = 4 q + i
+        float *o = partial + (size_t)bx * 3 * C + 12 * q;  // out[c][t], c = 4 q + i
 #pragma unroll
         for (int kk = 0; kk < 12; ++kk) {
             float s = red[kk][q];
@@ -497,6 +522,15 @@ bn_relu_bwd_apply_rel_kernel(long rows, int C, const float *__restrict__ dH, int
             o[kk] = s;
         }
     }
+}
+
+__global__ void __launch_bounds__(kTT)
+bn_relu_bwd_apply_rel_kernel(ApplyRelArgs a) { bn_relu_bwd_apply_rel_body(a, blockIdx.x); }
+// two problems in one launch: workgroups [0, na) run a, the rest b
+__global__ void __launch_bounds__(kTT)
+bn_relu_bwd_apply_rel_pair_kernel(ApplyRelArgs a, ApplyRelArgs b, unsigned na) {
+    if (blockIdx.x < na) bn_relu_bwd_apply_rel_body(a, blockIdx.x);
+    else bn_relu_bwd_apply_rel_body(b, blockIdx.x - na);
 }
 
 // ---- transposes of the row gathers ------------------------------------------------------------------------------------
@@ -577,15 +611,22 @@ sa_layer1_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int 
 // The same with the BatchNorm statistics of the result taken on the way (pn2x_sa_layer1_stats): a workgroup owns rows_per_block
 // consecutive slots of one cloud, a thread a channel quad of every rpp-th of them, and the per-thread sums of y and y^2 go through
 // block_reduce_to_sums like pn2x_bn_stats' -- the separate pass over y1 (one launch per scale and step) disappears.
-__global__ void __launch_bounds__(kTT)
-sa_layer1_stats_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f, int a1f_ld, const float *__restrict__ xyz,
-                       const float *__restrict__ cxyz, const float *__restrict__ wx, int wx_ld, const float *__restrict__ cadd,
-                       int cadd_ld, const int *__restrict__ idx, float *__restrict__ out, float *__restrict__ rel_out,
-                       int rows_per_block, double *__restrict__ sums) {
-    const int b = blockIdx.y;
+struct SaLayer1Args {
+    int n, S, K, Q; const float *a1f; int a1f_ld; const float *xyz, *cxyz, *wx; int wx_ld; const float *cadd; int cadd_ld;
+    const int *idx; float *out, *rel_out; int rows_per_block; double *sums;
+};
+__device__ __forceinline__ void sa_layer1_stats_body(const SaLayer1Args &A, unsigned bx, unsigned by) {
+    const int n = A.n, S = A.S, K = A.K, Q = A.Q, a1f_ld = A.a1f_ld, wx_ld = A.wx_ld, cadd_ld = A.cadd_ld, rows_per_block = A.rows_per_block;
+    const float *__restrict__ a1f = A.a1f, *__restrict__ xyz = A.xyz, *__restrict__ cxyz = A.cxyz, *__restrict__ wx = A.wx;
+    const float *__restrict__ cadd = A.cadd;
+    const int *__restrict__ idx = A.idx;
+    float *__restrict__ out = A.out, *__restrict__ rel_out = A.rel_out;
+    double *__restrict__ sums = A.sums;
+
+    const int b = (int)by;
     const int sk = S * K, rpp = kTT / Q;  // kTT % Q == 0 (checked by the launcher)
     const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(sk, r0 + rows_per_block);
+    const int r0 = (int)bx * rows_per_block, r1 = min(sk, r0 + rows_per_block);
     float w[4][3] = {{0.f}};
     if (xyz) {
 #pragma unroll
@@ -657,6 +698,15 @@ sa_layer1_stats_kernel(int n, int S, int K, int Q, const float *__restrict__ a1f
         finish(r, acc, px, py, pz, cx, cy, cz, cv);
     }
     block_reduce_to_sums(sm, sq, Q, rpp, 4 * Q, sums);
+}
+
+__global__ void __launch_bounds__(kTT)
+sa_layer1_stats_kernel(SaLayer1Args a) { sa_layer1_stats_body(a, blockIdx.x, blockIdx.y); }
+// the two neighbourhood sizes of one module in one launch: workgroup columns [0, na) run a, the rest b (same clouds along y)
+__global__ void __launch_bounds__(kTT)
+sa_layer1_stats_pair_kernel(SaLayer1Args a, SaLayer1Args b, unsigned na) {
+    if (blockIdx.x < na) sa_layer1_stats_body(a, blockIdx.x, blockIdx.y);
+    else sa_layer1_stats_body(b, blockIdx.x - na, blockIdx.y);
 }
 
 // LDS-slab variant of the two row scatters: a workgroup owns (cloud, cc channels), accumulates every contribution to its
@@ -795,13 +845,17 @@ __device__ __forceinline__ void segment_rows_sum(float4 &acc, int p0, int p1, in
     }
 }
 
+struct SegSumArgs {
+    int n_dst, m_src, Q; const float *dOut; int ldo; const int *offsets_all, *order_all; const float *weight_all; float *dIn; int ldi, accumulate;
+};
 template <int T>  // index entries per source row: 1 = plain row scatter, 3 = three-NN interpolation (weighted)
-__global__ void __launch_bounds__(kTT)
-rows_segment_sum_kernel(int n_dst, int m_src, int Q, const float *__restrict__ dOut, int ldo, const int *__restrict__ offsets_all,
-                        const int *__restrict__ order_all, const float *__restrict__ weight_all, float *__restrict__ dIn, int ldi,
-                        int accumulate) {
-    const int b = blockIdx.y;
-    const long item = (long)blockIdx.x * kTT + threadIdx.x;
+__device__ __forceinline__ void rows_segment_sum_body(const SegSumArgs &A, unsigned bx, unsigned by) {
+    const int n_dst = A.n_dst, m_src = A.m_src, Q = A.Q, ldo = A.ldo, ldi = A.ldi, accumulate = A.accumulate;
+    const float *__restrict__ dOut = A.dOut, *__restrict__ weight_all = A.weight_all;
+    const int *__restrict__ offsets_all = A.offsets_all, *__restrict__ order_all = A.order_all;
+    float *__restrict__ dIn = A.dIn;
+    const int b = (int)by;
+    const long item = (long)bx * kTT + threadIdx.x;
     if (item >= (long)n_dst * Q) return;
     const int i = (int)(item / Q), q = (int)(item % Q);
     const int *__restrict__ offsets = offsets_all + (size_t)b * (n_dst + 1);
@@ -816,6 +870,15 @@ rows_segment_sum_kernel(int n_dst, int m_src, int Q, const float *__restrict__ d
         acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
     }
     *dst = acc;
+}
+template <int T>
+__global__ void __launch_bounds__(kTT)
+rows_segment_sum_kernel(SegSumArgs a) { rows_segment_sum_body<T>(a, blockIdx.x, blockIdx.y); }
+// two scatters of one module's two neighbourhood sizes (different column blocks of the same destination rows) in one launch
+__global__ void __launch_bounds__(kTT)
+rows_segment_sum_pair_kernel(SegSumArgs a, SegSumArgs b, unsigned na) {
+    if (blockIdx.x < na) rows_segment_sum_body<1>(a, blockIdx.x, blockIdx.y);
+    else rows_segment_sum_body<1>(b, blockIdx.x - na, blockIdx.y);
 }
 
 // The same sums with a destination's segment split over EL lanes (EL a power of two, Q * EL divides 256): ball-query padding
@@ -933,15 +996,21 @@ extern "C" int pn2x_bn_bwd_reduce_g(long rows, int c, const float *dh, int ldd, 
 namespace pn2 {
 // The BatchNorm-backward sums of a max-pooled top layer from the arg-max rows ALONE: the routed gradient is non-zero in one row
 // per (group, channel), so sum(g) and sum(g xhat) need groups x C gathered pre-activations, not the rows x C tensor.
-__global__ void __launch_bounds__(kTT)
-bn_bwd_reduce_routed_kernel(long groups, int K, int C, const float *__restrict__ dout, int ldd, const int *__restrict__ arg, int lda,
-                            const float *__restrict__ y, int ldy, const float *__restrict__ mean, const float *__restrict__ invstd,
-                            const float *__restrict__ gamma, const float *__restrict__ beta, long groups_per_block,
-                            double *__restrict__ sums) {
+struct RoutedArgs {
+    long groups; int K, C; const float *dout; int ldd; const int *arg; int lda; const float *y; int ldy;
+    const float *mean, *invstd, *gamma, *beta; long groups_per_block; double *sums;
+};
+__device__ __forceinline__ void bn_bwd_reduce_routed_body(const RoutedArgs &A, unsigned bx, unsigned by) {
+    const long groups = A.groups, groups_per_block = A.groups_per_block;
+    const int K = A.K, C = A.C, ldd = A.ldd, lda = A.lda, ldy = A.ldy;
+    const float *__restrict__ dout = A.dout, *__restrict__ y = A.y, *__restrict__ mean = A.mean, *__restrict__ invstd = A.invstd;
+    const float *__restrict__ gamma = A.gamma, *__restrict__ beta = A.beta;
+    const int *__restrict__ arg = A.arg;
+    double *__restrict__ sums = A.sums;
     __shared__ float red[2][4][64];
     const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
-    const long g0 = (long)blockIdx.x * groups_per_block;
+    const int c = (int)by * 64 + cl;
+    const long g0 = (long)bx * groups_per_block;
     const long g1 = (g0 + groups_per_block) < groups ? (g0 + groups_per_block) : groups;
     float s = 0.f, q = 0.f;
     if (c < C) {
@@ -960,10 +1029,18 @@ bn_bwd_reduce_routed_kernel(long groups, int K, int C, const float *__restrict__
     if (gl == 0 && c < C) {
         const double sd = (double)red[0][0][cl] + (double)red[0][1][cl] + (double)red[0][2][cl] + (double)red[0][3][cl];
         const double qd = (double)red[1][0][cl] + (double)red[1][1][cl] + (double)red[1][2][cl] + (double)red[1][3][cl];
-        double *dst = sums + (size_t)(blockIdx.x % kBnRep) * 2 * C;
+        double *dst = sums + (size_t)(bx % kBnRep) * 2 * C;
         unsafeAtomicAdd(dst + c, sd);
         unsafeAtomicAdd(dst + C + c, qd);
     }
+}
+__global__ void __launch_bounds__(kTT)
+bn_bwd_reduce_routed_kernel(RoutedArgs a) { bn_bwd_reduce_routed_body(a, blockIdx.x, blockIdx.y); }
+// two problems with the same channel count (the two neighbourhood sizes of a module) in one launch
+__global__ void __launch_bounds__(kTT)
+bn_bwd_reduce_routed_pair_kernel(RoutedArgs a, RoutedArgs b, unsigned na) {
+    if (blockIdx.x < na) bn_bwd_reduce_routed_body(a, blockIdx.x, blockIdx.y);
+    else bn_bwd_reduce_routed_body(b, blockIdx.x - na, blockIdx.y);
 }
 }  // namespace pn2
 
@@ -1011,12 +1088,11 @@ rows_outer3_kernel(long rows, int C, const float *__restrict__ dy, int ldy, cons
     }
 }
 
-__global__ void __launch_bounds__(kTT)
-rows_outer3_sum_kernel(int blocks, int n, const float *__restrict__ partial, float *__restrict__ out) {
+__device__ __forceinline__ void rows_outer3_sum_body(int blocks, int n, const float *__restrict__ partial, float *__restrict__ out, unsigned bx) {
     __shared__ float red[16][16];
     // one workgroup per 16 outputs: thread = (output, one of sixteen lanes over the partials), four loads in flight per lane
     const int el = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + el;
+    const int e = bx * 16 + el;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < n) {
         int p = pl;
@@ -1036,6 +1112,16 @@ rows_outer3_sum_kernel(int blocks, int n, const float *__restrict__ partial, flo
         for (int l = 0; l < 16; ++l) s += red[l][el];
         out[e] = s;
     }
+}
+__global__ void __launch_bounds__(kTT)
+rows_outer3_sum_kernel(int blocks, int n, const float *__restrict__ partial, float *__restrict__ out) {
+    rows_outer3_sum_body(blocks, n, partial, out, blockIdx.x);
+}
+__global__ void __launch_bounds__(kTT)
+rows_outer3_sum_pair_kernel(int blocks_a, int n_a, const float *__restrict__ partial_a, float *__restrict__ out_a, int blocks_b, int n_b,
+                            const float *__restrict__ partial_b, float *__restrict__ out_b, unsigned na) {
+    if (blockIdx.x < na) rows_outer3_sum_body(blocks_a, n_a, partial_a, out_a, blockIdx.x);
+    else rows_outer3_sum_body(blocks_b, n_b, partial_b, out_b, blockIdx.x - na);
 }
 }  // namespace pn2
 
@@ -1061,10 +1147,10 @@ extern "C" int pn2x_rows_outer3(long rows, int c, const float *dy, int ldy, cons
     return check_launch();
 }
 
-extern "C" int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, int lda, const float *y, int ldy,
-                                         const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums,
-                                         void *stream) {
-    using namespace pn2;
+namespace pn2 {
+static int routed_args(long groups, int k, int c, const float *dout, int ldd, const int *arg, int lda, const float *y, int ldy,
+                       const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums, RoutedArgs &a,
+                       unsigned &blocks_out) {
     if (groups < 1 || k < 1 || bad_c(c) || ldy < c || ldd < c || lda < c || groups * k > 0x7fffffffL) return PN2_EINVAL;
     if (!dout || !arg || !y || !mean || !invstd || !gamma || !beta || !sums) return PN2_ENULL;
     const int ny = (c + 63) / 64;
@@ -1073,8 +1159,41 @@ extern "C" int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float 
     gpb = (gpb + 3) / 4 * 4;
     if (gpb < 16) gpb = 16;
     blocks = (groups + gpb - 1) / gpb;
-    hipLaunchKernelGGL(bn_bwd_reduce_routed_kernel, dim3((unsigned)blocks, ny), dim3(kTT), 0, (hipStream_t)stream, groups, k, c, dout, ldd,
-                       arg, lda, y, ldy, mean, invstd, gamma, beta, gpb, sums);
+    blocks_out = (unsigned)blocks;
+    a = RoutedArgs{groups, k, c, dout, ldd, arg, lda, y, ldy, mean, invstd, gamma, beta, gpb, sums};
+    return PN2_OK;
+}
+}  // namespace pn2
+
+extern "C" int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, int lda, const float *y, int ldy,
+                                         const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums,
+                                         void *stream) {
+    using namespace pn2;
+    RoutedArgs a;
+    unsigned blocks = 0;
+    if (int rc = routed_args(groups, k, c, dout, ldd, arg, lda, y, ldy, mean, invstd, gamma, beta, sums, a, blocks)) return rc;
+    hipLaunchKernelGGL(bn_bwd_reduce_routed_kernel, dim3(blocks, (c + 63) / 64), dim3(kTT), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+// two problems of the same channel count in one launch (two calls when the counts differ); same results
+extern "C" int pn2x_bn_bwd_reduce_routed_pair(long groups_a, int k_a, int c_a, const float *dout_a, int ldd_a, const int *arg_a, int lda_a,
+                                              const float *y_a, int ldy_a, const float *mean_a, const float *invstd_a, const float *gamma_a,
+                                              const float *beta_a, double *sums_a, long groups_b, int k_b, int c_b, const float *dout_b,
+                                              int ldd_b, const int *arg_b, int lda_b, const float *y_b, int ldy_b, const float *mean_b,
+                                              const float *invstd_b, const float *gamma_b, const float *beta_b, double *sums_b, void *stream) {
+    using namespace pn2;
+    RoutedArgs a, b;
+    unsigned na = 0, nb = 0;
+    if (int rc = routed_args(groups_a, k_a, c_a, dout_a, ldd_a, arg_a, lda_a, y_a, ldy_a, mean_a, invstd_a, gamma_a, beta_a, sums_a, a, na)) return rc;
+    if (int rc = routed_args(groups_b, k_b, c_b, dout_b, ldd_b, arg_b, lda_b, y_b, ldy_b, mean_b, invstd_b, gamma_b, beta_b, sums_b, b, nb)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if ((c_a + 63) / 64 != (c_b + 63) / 64) {
+        hipLaunchKernelGGL(bn_bwd_reduce_routed_kernel, dim3(na, (c_a + 63) / 64), dim3(kTT), 0, st, a);
+        hipLaunchKernelGGL(bn_bwd_reduce_routed_kernel, dim3(nb, (c_b + 63) / 64), dim3(kTT), 0, st, b);
+        return check_launch();
+    }
+    hipLaunchKernelGGL(bn_bwd_reduce_routed_pair_kernel, dim3(na + nb, (c_a + 63) / 64), dim3(kTT), 0, st, a, b, na);
     return check_launch();
 }
 
@@ -1099,21 +1218,59 @@ extern "C" long pn2x_bn_bwd_apply_rel_scratch_floats(long rows, int c) {
     return ((rows + rpb - 1) / rpb) * 3L * c;
 }
 
+namespace pn2 {
+static int apply_rel_args(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean, const float *invstd,
+                          const float *gamma, const float *beta, int relu, const double *sums, float *dy, int ldo, float *dgamma,
+                          float *dbeta, float *dbias, const float *rel, float *scratch, long scratch_floats, float *dwx, ApplyRelArgs &a,
+                          long &blocks) {
+    if (rows < 1 || bad_c(c) || c > 256 || ldy < c || ldy % 4 || ldg < c || ldg % 4 || ldo < c || ldo % 4) return PN2_EINVAL;
+    if (!g || !y || !mean || !invstd || !gamma || !beta || !sums || !dy || !dgamma || !dbeta || !rel || !scratch || !dwx) return PN2_ENULL;
+    if (((uintptr_t)y | (uintptr_t)g | (uintptr_t)dy) % 16) return PN2_EINVAL;
+    const int rpb = rows_per_block_for(rows, c);
+    blocks = (rows + rpb - 1) / rpb;
+    if (scratch_floats < blocks * 3L * c) return PN2_ESCRATCH;
+    a = ApplyRelArgs{rows, c, g, ldg, y, ldy, mean, invstd, gamma, beta, sums, rpb, relu, dy, ldo, dgamma, dbeta, dbias, rel, scratch};
+    return PN2_OK;
+}
+}  // namespace pn2
+
 extern "C" int pn2x_bn_bwd_apply_rel(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean,
                                      const float *invstd, const float *gamma, const float *beta, int relu, const double *sums, float *dy,
                                      int ldo, float *dgamma, float *dbeta, float *dbias, const float *rel, float *scratch,
                                      long scratch_floats, float *dwx, void *stream) {
     using namespace pn2;
-    if (rows < 1 || bad_c(c) || c > 256 || ldy < c || ldy % 4 || ldg < c || ldg % 4 || ldo < c || ldo % 4) return PN2_EINVAL;
-    if (!g || !y || !mean || !invstd || !gamma || !beta || !sums || !dy || !dgamma || !dbeta || !rel || !scratch || !dwx) return PN2_ENULL;
-    if (((uintptr_t)y | (uintptr_t)g | (uintptr_t)dy) % 16) return PN2_EINVAL;
-    const int rpb = rows_per_block_for(rows, c);
-    const long blocks = (rows + rpb - 1) / rpb;
-    if (scratch_floats < blocks * 3L * c) return PN2_ESCRATCH;
+    ApplyRelArgs a;
+    long blocks = 0;
+    if (int rc = apply_rel_args(rows, c, g, ldg, y, ldy, mean, invstd, gamma, beta, relu, sums, dy, ldo, dgamma, dbeta, dbias, rel, scratch,
+                                scratch_floats, dwx, a, blocks)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_relu_bwd_apply_rel_kernel, dim3((unsigned)blocks), dim3(kTT), 0, st, rows, c, g, ldg, y, ldy, mean, invstd, gamma,
-                       beta, sums, rpb, relu, dy, ldo, dgamma, dbeta, dbias, rel, scratch);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_rel_kernel, dim3((unsigned)blocks), dim3(kTT), 0, st, a);
     hipLaunchKernelGGL(rows_outer3_sum_kernel, dim3((3 * c + 15) / 16), dim3(kTT), 0, st, (int)blocks, 3 * c, scratch, dwx);
+    return check_launch();
+}
+
+// Two problems (the two neighbourhood sizes of a keypoint-query module: pointnet_utils.py:566-581) in ONE launch each: the K = 16
+// scale alone is a 16 us launch for a quarter of the K = 64 scale's rows.
+extern "C" int pn2x_bn_bwd_apply_rel_pair(long rows_a, int c_a, const float *g_a, int ldg_a, const float *y_a, int ldy_a, const float *mean_a,
+                                          const float *invstd_a, const float *gamma_a, const float *beta_a, int relu_a, const double *sums_a,
+                                          float *dy_a, int ldo_a, float *dgamma_a, float *dbeta_a, float *dbias_a, const float *rel_a,
+                                          float *scratch_a, long scratch_floats_a, float *dwx_a, long rows_b, int c_b, const float *g_b,
+                                          int ldg_b, const float *y_b, int ldy_b, const float *mean_b, const float *invstd_b,
+                                          const float *gamma_b, const float *beta_b, int relu_b, const double *sums_b, float *dy_b, int ldo_b,
+                                          float *dgamma_b, float *dbeta_b, float *dbias_b, const float *rel_b, float *scratch_b,
+                                          long scratch_floats_b, float *dwx_b, void *stream) {
+    using namespace pn2;
+    ApplyRelArgs a, b;
+    long na = 0, nb = 0;
+    if (int rc = apply_rel_args(rows_a, c_a, g_a, ldg_a, y_a, ldy_a, mean_a, invstd_a, gamma_a, beta_a, relu_a, sums_a, dy_a, ldo_a, dgamma_a,
+                                dbeta_a, dbias_a, rel_a, scratch_a, scratch_floats_a, dwx_a, a, na)) return rc;
+    if (int rc = apply_rel_args(rows_b, c_b, g_b, ldg_b, y_b, ldy_b, mean_b, invstd_b, gamma_b, beta_b, relu_b, sums_b, dy_b, ldo_b, dgamma_b,
+                                dbeta_b, dbias_b, rel_b, scratch_b, scratch_floats_b, dwx_b, b, nb)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_rel_pair_kernel, dim3((unsigned)(na + nb)), dim3(kTT), 0, st, a, b, (unsigned)na);
+    const unsigned sa = (3 * c_a + 15) / 16, sb = (3 * c_b + 15) / 16;
+    hipLaunchKernelGGL(rows_outer3_sum_pair_kernel, dim3(sa + sb), dim3(kTT), 0, st, (int)na, 3 * c_a, scratch_a, dwx_a, (int)nb, 3 * c_b, scratch_b,
+                       dwx_b, sa);
     return check_launch();
 }
 
@@ -1130,14 +1287,52 @@ extern "C" int pn2x_bn_relu_max(long groups, int k, int c, const float *y, int l
     while (split < 64 && 2 * split <= k && items * split < 131072) split *= 2;
     if (split >= 4) {
         const int ipb = kTT / split;
-        hipLaunchKernelGGL(bn_relu_max_split_kernel, dim3((unsigned)((items + ipb - 1) / ipb)), dim3(kTT), 0, (hipStream_t)stream, groups, k, c,
-                           split, y, ldy, sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, num_batches_tracked,
-                           save_mean, save_invstd, out, arg);
+        const MaxSplitArgs a{groups, k, c, split, y, ldy, sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
+                             num_batches_tracked, save_mean, save_invstd, out, arg};
+        hipLaunchKernelGGL(bn_relu_max_split_kernel, dim3((unsigned)((items + ipb - 1) / ipb)), dim3(kTT), 0, (hipStream_t)stream, a);
         return check_launch();
     }
     hipLaunchKernelGGL(bn_relu_max_kernel, dim3((unsigned)((items + kTT - 1) / kTT)), dim3(kTT), 0, (hipStream_t)stream, groups, k, c, y, ldy,
                        sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd,
                        out, arg);
+    return check_launch();
+}
+
+// pn2x_bn_relu_max for two problems (the two neighbourhood sizes of a module) in ONE launch where both take the split kernel (few
+// groups: rows of a group over several lanes); two calls otherwise.  Same results.
+extern "C" int pn2x_bn_relu_max_pair(long groups_a, int k_a, int c_a, const float *y_a, int ldy_a, const double *sums_a, const float *gamma_a,
+                                     const float *beta_a, const float *conv_bias_a, float eps_a, float momentum_a, float *running_mean_a,
+                                     float *running_var_a, long long *nbt_a, float *save_mean_a, float *save_invstd_a, float *out_a, int *arg_a,
+                                     long groups_b, int k_b, int c_b, const float *y_b, int ldy_b, const double *sums_b, const float *gamma_b,
+                                     const float *beta_b, const float *conv_bias_b, float eps_b, float momentum_b, float *running_mean_b,
+                                     float *running_var_b, long long *nbt_b, float *save_mean_b, float *save_invstd_b, float *out_b, int *arg_b,
+                                     void *stream) {
+    using namespace pn2;
+    auto split_of = [](long groups, int k, int c) {
+        const long items = groups * (c / 4);
+        int split = 1;
+        while (split < 64 && 2 * split <= k && items * split < 131072) split *= 2;
+        return split;
+    };
+    const bool ok_a = groups_a >= 1 && k_a >= 1 && !bad_c(c_a) && ldy_a >= c_a && ldy_a % 4 == 0 && y_a && sums_a && gamma_a && beta_a &&
+                      save_mean_a && save_invstd_a && out_a && arg_a && (((uintptr_t)y_a | (uintptr_t)out_a | (uintptr_t)arg_a) % 16) == 0;
+    const bool ok_b = groups_b >= 1 && k_b >= 1 && !bad_c(c_b) && ldy_b >= c_b && ldy_b % 4 == 0 && y_b && sums_b && gamma_b && beta_b &&
+                      save_mean_b && save_invstd_b && out_b && arg_b && (((uintptr_t)y_b | (uintptr_t)out_b | (uintptr_t)arg_b) % 16) == 0;
+    const int sa = ok_a ? split_of(groups_a, k_a, c_a) : 1, sb = ok_b ? split_of(groups_b, k_b, c_b) : 1;
+    if (!ok_a || !ok_b || sa < 4 || sb < 4) {
+        const int rc = pn2x_bn_relu_max(groups_a, k_a, c_a, y_a, ldy_a, sums_a, gamma_a, beta_a, conv_bias_a, eps_a, momentum_a, running_mean_a,
+                                        running_var_a, nbt_a, save_mean_a, save_invstd_a, out_a, arg_a, stream);
+        if (rc != PN2_OK) return rc;
+        return pn2x_bn_relu_max(groups_b, k_b, c_b, y_b, ldy_b, sums_b, gamma_b, beta_b, conv_bias_b, eps_b, momentum_b, running_mean_b,
+                                running_var_b, nbt_b, save_mean_b, save_invstd_b, out_b, arg_b, stream);
+    }
+    const MaxSplitArgs a{groups_a, k_a, c_a, sa, y_a, ldy_a, sums_a, gamma_a, beta_a, conv_bias_a, eps_a, momentum_a, running_mean_a,
+                         running_var_a, nbt_a, save_mean_a, save_invstd_a, out_a, arg_a};
+    const MaxSplitArgs b{groups_b, k_b, c_b, sb, y_b, ldy_b, sums_b, gamma_b, beta_b, conv_bias_b, eps_b, momentum_b, running_mean_b,
+                         running_var_b, nbt_b, save_mean_b, save_invstd_b, out_b, arg_b};
+    const long ia = groups_a * (c_a / 4), ib = groups_b * (c_b / 4);
+    const unsigned na = (unsigned)((ia + kTT / sa - 1) / (kTT / sa)), nb = (unsigned)((ib + kTT / sb - 1) / (kTT / sb));
+    hipLaunchKernelGGL(bn_relu_max_split_pair_kernel, dim3(na + nb), dim3(kTT), 0, (hipStream_t)stream, a, b, na);
     return check_launch();
 }
 
@@ -1222,19 +1417,16 @@ extern "C" int pn2x_sa_layer1_ld(int b, int n, int s, int k, int c1, const float
 // pn2x_sa_layer1_ld that also accumulates the BatchNorm statistics of its output into `sums` (pn2x_bn_sums_doubles(c1) doubles, zeroed
 // by the caller; the layout pn2x_bn_stats writes): in the same launch when the channel quads divide the workgroup, by a
 // pn2x_bn_stats launch behind it otherwise.
-extern "C" int pn2x_sa_layer1_stats(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
-                                    const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
-                                    double *sums, void *stream) {
-    using namespace pn2;
+namespace pn2 {
+// 1: the statistics cannot be taken in the launch (channel quads do not divide the workgroup): the caller runs the two-launch form
+static int sa_layer1_stats_args(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
+                                const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
+                                double *sums, SaLayer1Args &a, unsigned &nbx) {
     if (!sums) return PN2_ENULL;
     const int Q = c1 >= 4 ? c1 / 4 : 1;
-    if (c1 % 4 || c1 < 4 || kTT % Q || (long)b * s * k > 2147483647L) {
-        const int rc = pn2x_sa_layer1_ld(b, n, s, k, c1, a1f, a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, stream);
-        if (rc != PN2_OK || b == 0 || s == 0) return rc;
-        return pn2x_bn_stats((long)b * s * k, c1, out, c1, sums, stream);
-    }
+    if (c1 % 4 || c1 < 4 || kTT % Q || (long)b * s * k > 2147483647L) return 1;
     if (b < 0 || n < 1 || s < 0 || k < 1 || (xyz && wx_ld < 3)) return PN2_EINVAL;
-    if (b == 0 || s == 0) return PN2_OK;
+    if (b == 0 || s == 0) { nbx = 0; return PN2_OK; }
     if (!idx || !out || (!a1f && !xyz)) return PN2_ENULL;
     if (xyz && (!cxyz || !wx)) return PN2_ENULL;
     if ((a1f && (a1f_ld < c1 || a1f_ld % 4)) || (cadd && (cadd_ld < c1 || cadd_ld % 4))) return PN2_EINVAL;
@@ -1244,8 +1436,55 @@ extern "C" int pn2x_sa_layer1_stats(int b, int n, int s, int k, int c1, const fl
     int rpb = (int)(((long)sk * b + target_wgs - 1) / target_wgs);  // ~2048 workgroups on a large problem, at least 8 rows per thread
     if (rpb < 8 * rpp) rpb = 8 * rpp;
     rpb = (rpb + rpp - 1) / rpp * rpp;
-    hipLaunchKernelGGL(sa_layer1_stats_kernel, dim3((unsigned)((sk + rpb - 1) / rpb), b), dim3(kTT), 0, (hipStream_t)stream, n, s, k, Q, a1f,
-                       a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, rpb, sums);
+    nbx = (unsigned)((sk + rpb - 1) / rpb);
+    a = SaLayer1Args{n, s, k, Q, a1f, a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, rpb, sums};
+    return PN2_OK;
+}
+}  // namespace pn2
+
+// pn2x_sa_layer1_ld that also accumulates the BatchNorm statistics of its output into `sums` (pn2x_bn_sums_doubles(c1) doubles, zeroed
+// by the caller; the layout pn2x_bn_stats writes): in the same launch when the channel quads divide the workgroup, by a
+// pn2x_bn_stats launch behind it otherwise.
+extern "C" int pn2x_sa_layer1_stats(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
+                                    const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
+                                    double *sums, void *stream) {
+    using namespace pn2;
+    SaLayer1Args a;
+    unsigned nbx = 0;
+    const int rc0 = sa_layer1_stats_args(b, n, s, k, c1, a1f, a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, sums, a, nbx);
+    if (rc0 == 1) {
+        const int rc = pn2x_sa_layer1_ld(b, n, s, k, c1, a1f, a1f_ld, xyz, cxyz, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, stream);
+        if (rc != PN2_OK || b == 0 || s == 0) return rc;
+        return pn2x_bn_stats((long)b * s * k, c1, out, c1, sums, stream);
+    }
+    if (rc0 != PN2_OK || nbx == 0) return rc0;
+    hipLaunchKernelGGL(sa_layer1_stats_kernel, dim3(nbx, b), dim3(kTT), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+// ... for the two neighbourhood sizes of one module (same clouds, coordinates and centres; own neighbour lists, weights, outputs and
+// statistics) in ONE launch; falls back to two pn2x_sa_layer1_stats calls where a scale cannot take its statistics in the launch.
+extern "C" int pn2x_sa_layer1_stats_pair(int b, int n, int s, const float *xyz, const float *cxyz, int k_a, int c1_a, const float *a1f_a,
+                                         int a1f_ld_a, const float *wx_a, int wx_ld_a, const float *cadd_a, int cadd_ld_a, const int *idx_a,
+                                         float *out_a, float *rel_out_a, double *sums_a, int k_b, int c1_b, const float *a1f_b, int a1f_ld_b,
+                                         const float *wx_b, int wx_ld_b, const float *cadd_b, int cadd_ld_b, const int *idx_b, float *out_b,
+                                         float *rel_out_b, double *sums_b, void *stream) {
+    using namespace pn2;
+    SaLayer1Args a, c;
+    unsigned na = 0, nb = 0;
+    const int ra = sa_layer1_stats_args(b, n, s, k_a, c1_a, a1f_a, a1f_ld_a, xyz, cxyz, wx_a, wx_ld_a, cadd_a, cadd_ld_a, idx_a, out_a, rel_out_a,
+                                        sums_a, a, na);
+    const int rb = sa_layer1_stats_args(b, n, s, k_b, c1_b, a1f_b, a1f_ld_b, xyz, cxyz, wx_b, wx_ld_b, cadd_b, cadd_ld_b, idx_b, out_b, rel_out_b,
+                                        sums_b, c, nb);
+    if (ra != PN2_OK || rb != PN2_OK || na == 0 || nb == 0) {
+        if ((ra != PN2_OK && ra != 1) || (rb != PN2_OK && rb != 1)) return ra != PN2_OK && ra != 1 ? ra : rb;
+        const int rc = pn2x_sa_layer1_stats(b, n, s, k_a, c1_a, a1f_a, a1f_ld_a, xyz, cxyz, wx_a, wx_ld_a, cadd_a, cadd_ld_a, idx_a, out_a,
+                                            rel_out_a, sums_a, stream);
+        if (rc != PN2_OK) return rc;
+        return pn2x_sa_layer1_stats(b, n, s, k_b, c1_b, a1f_b, a1f_ld_b, xyz, cxyz, wx_b, wx_ld_b, cadd_b, cadd_ld_b, idx_b, out_b, rel_out_b,
+                                    sums_b, stream);
+    }
+    hipLaunchKernelGGL(sa_layer1_stats_pair_kernel, dim3(na + nb, b), dim3(kTT), 0, (hipStream_t)stream, a, c, na);
     return check_launch();
 }
 
@@ -1293,9 +1532,33 @@ extern "C" int pn2x_rows_segment_sum(int b, int n_dst, int m_src, int t, int c, 
     }
     const long total = (long)n_dst * Q;
     const dim3 grid((unsigned)((total + kTT - 1) / kTT), b);
+    const SegSumArgs a{n_dst, m_src, Q, dout, ldo, offsets, order, weight, din, ldi, accumulate};
     if (t == 1)
-        hipLaunchKernelGGL(rows_segment_sum_kernel<1>, grid, dim3(kTT), 0, (hipStream_t)stream, n_dst, m_src, Q, dout, ldo, offsets, order, weight, din, ldi, accumulate);
+        hipLaunchKernelGGL(rows_segment_sum_kernel<1>, grid, dim3(kTT), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(rows_segment_sum_kernel<3>, grid, dim3(kTT), 0, (hipStream_t)stream, n_dst, m_src, Q, dout, ldo, offsets, order, weight, din, ldi, accumulate);
+        hipLaunchKernelGGL(rows_segment_sum_kernel<3>, grid, dim3(kTT), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+// pn2x_rows_segment_sum (t = 1) for two index lists over the same destination rows in ONE launch where both take the
+// one-thread-per-(destination, quad) kernel (short segments); two calls otherwise.  Same results.
+extern "C" int pn2x_rows_segment_sum_pair(int b, int n_dst, int m_a, int c_a, const float *dout_a, int ldo_a, const int *offsets_a,
+                                          const int *order_a, float *din_a, int ldi_a, int m_b, int c_b, const float *dout_b, int ldo_b,
+                                          const int *offsets_b, const int *order_b, float *din_b, int ldi_b, int accumulate, void *stream) {
+    using namespace pn2;
+    auto split = [&](int m, int c) { const int Q = c / 4; return c >= 4 && (long)m >= 4L * n_dst && Q <= 64 && kTT % Q == 0; };
+    const bool ok = b > 0 && n_dst >= 1 && c_a >= 4 && c_b >= 4 && c_a % 4 == 0 && c_b % 4 == 0 && !split(m_a, c_a) && !split(m_b, c_b) &&
+                    dout_a && dout_b && offsets_a && offsets_b && order_a && order_b && din_a && din_b && ldo_a >= c_a && ldo_b >= c_b &&
+                    ldo_a % 4 == 0 && ldo_b % 4 == 0 && ldi_a >= c_a && ldi_b >= c_b && ldi_a % 4 == 0 && ldi_b % 4 == 0 &&
+                    (((uintptr_t)dout_a | (uintptr_t)dout_b | (uintptr_t)din_a | (uintptr_t)din_b) % 16) == 0 && m_a >= 0 && m_b >= 0;
+    if (!ok) {
+        const int rc = pn2x_rows_segment_sum(b, n_dst, m_a, 1, c_a, dout_a, ldo_a, offsets_a, order_a, nullptr, din_a, ldi_a, accumulate, stream);
+        if (rc != PN2_OK) return rc;
+        return pn2x_rows_segment_sum(b, n_dst, m_b, 1, c_b, dout_b, ldo_b, offsets_b, order_b, nullptr, din_b, ldi_b, accumulate, stream);
+    }
+    const SegSumArgs a{n_dst, m_a, c_a / 4, dout_a, ldo_a, offsets_a, order_a, nullptr, din_a, ldi_a, accumulate};
+    const SegSumArgs c{n_dst, m_b, c_b / 4, dout_b, ldo_b, offsets_b, order_b, nullptr, din_b, ldi_b, accumulate};
+    const unsigned na = (unsigned)(((long)n_dst * a.Q + kTT - 1) / kTT), nb = (unsigned)(((long)n_dst * c.Q + kTT - 1) / kTT);
+    hipLaunchKernelGGL(rows_segment_sum_pair_kernel, dim3(na + nb, b), dim3(kTT), 0, (hipStream_t)stream, a, c, na);
     return check_launch();
 }

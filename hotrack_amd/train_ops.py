@@ -32,6 +32,12 @@ _lib.pn2x_sa_layer1_stats.argtypes = [_ci] * 5 + [_vp, _ci, _vp, _vp, _vp, _ci, 
 _lib.pn2x_sa_layer1_stats.restype = _ci
 _lib.pn2x_bn_sums_doubles.argtypes = [_ci]
 _lib.pn2x_bn_sums_doubles.restype = _ci
+_SCALE = [_ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp]  # k, c1, a1f, a1f_ld, wx, wx_ld, cadd, cadd_ld, idx, out, rel_out, sums
+_lib.pn2x_sa_layer1_stats_pair.argtypes = [_ci, _ci, _ci, _vp, _vp] + _SCALE + _SCALE + [_vp]
+_lib.pn2x_sa_layer1_stats_pair.restype = _ci
+_lib.pn2x_rows_segment_sum_pair.argtypes = [_ci, _ci] + [_ci, _ci, _vp, _ci, _vp, _vp, _vp, _ci] * 2 + [_ci, _vp]
+_lib.pn2x_rows_segment_sum_pair.restype = _ci
+PAIR_SCALES = __import__("os").environ.get("HOTRACK_PAIR_SCALES", "1") != "0"  # the two scales of a module: one launch where a pair kernel exists
 _lib.pn2x_rows_outer3.argtypes = [_cl, _ci, _vp, _ci, _vp, _vp, _vp, _cl, _vp]
 _lib.pn2x_rows_outer3.restype = _ci
 _lib.pn2x_rows_outer3_scratch_floats.argtypes = [_cl, _ci]
@@ -259,6 +265,7 @@ class _SaLayer1(torch.autograd.Function):
         col = 0
         st = _native._stream(xyz)
         ws = aux.get("ws") if aux is not None else None  # the consumer stacks' workspace: BatchNorm statistics taken on the way
+        pending = []  # per scale (common args, per-scale args, sums slice): launched alone, or two scales as one pair launch
         for idx, wx in zip(idxs, wxs):
             K, C1 = idx.shape[2], wx.shape[0]
             out = torch.empty((B, S * K, C1), dtype=_f32, device=xyz.device)
@@ -266,20 +273,27 @@ class _SaLayer1(torch.autograd.Function):
             if wx.dim() != 2 or wx.shape[1] != 3 or wx.stride(1) != 1 or wx.dtype != _f32:
                 wx = wx.contiguous().float()
             sm = ws.take(_lib.pn2x_bn_sums_doubles(C1)) if ws is not None else None
-            args = (B, N, S, K, C1, None if a1f is None else a1f.data_ptr() + 4 * col, 0 if a1f is None else a1f.stride(1),
-                    xyz.data_ptr(), cxyz.data_ptr(), wx.data_ptr(), wx.stride(0) if C1 > 1 else 3,
-                    None if cadd is None else cadd.data_ptr() + 4 * col,
-                    0 if cadd is None else cadd.stride(1), _native._ptr(idx, "idx", torch.int32, B * S * K), out.data_ptr(),
-                    rel.data_ptr())
-            with torch.cuda.device(xyz.device):  # the (C1, 3) block is read in place (a column block of the layer's weight)
-                if sm is not None:
-                    _native._check(_lib.pn2x_sa_layer1_stats(*args, sm.data_ptr(), st), "sa_layer1_stats")
-                else:
-                    _native._check(_lib.pn2x_sa_layer1_ld(*args, st), "sa_layer1")
+            # (the (C1, 3) block is read in place: a column block of the layer's weight)
+            pending.append((K, C1, None if a1f is None else a1f.data_ptr() + 4 * col, 0 if a1f is None else a1f.stride(1),
+                            wx.data_ptr(), wx.stride(0) if C1 > 1 else 3, None if cadd is None else cadd.data_ptr() + 4 * col,
+                            0 if cadd is None else cadd.stride(1), _native._ptr(idx, "idx", torch.int32, B * S * K), out.data_ptr(),
+                            rel.data_ptr(), sm, wx))
             outs.append(out)
             rels.append(rel)
             sums.append(sm)
             col += C1
+        with torch.cuda.device(xyz.device):
+            if PAIR_SCALES and len(pending) == 2 and all(p[11] is not None for p in pending):
+                pa, pb = pending
+                _native._check(_lib.pn2x_sa_layer1_stats_pair(B, N, S, xyz.data_ptr(), cxyz.data_ptr(), *pa[:11], pa[11].data_ptr(),
+                                                              *pb[:11], pb[11].data_ptr(), st), "sa_layer1_stats_pair")
+            else:
+                for (K, C1, pa1f, lda, pwx, ldw, pcadd, ldc, pidx, pout, prel, sm, _wx) in pending:
+                    args = (B, N, S, K, C1, pa1f, lda, xyz.data_ptr(), cxyz.data_ptr(), pwx, ldw, pcadd, ldc, pidx, pout, prel)
+                    if sm is not None:
+                        _native._check(_lib.pn2x_sa_layer1_stats(*args, sm.data_ptr(), st), "sa_layer1_stats")
+                    else:
+                        _native._check(_lib.pn2x_sa_layer1_ld(*args, st), "sa_layer1")
         ctx.aux = aux
         if aux is not None:
             aux["rel"], aux["dwx"] = list(rels), {}
@@ -298,10 +312,24 @@ class _SaLayer1(torch.autograd.Function):
         d_cadd = torch.empty(cadd_shape, dtype=_f32, device=dev) if cadd_shape is not None else None
         d_wx = []
         col = 0
+        douts = [dy.contiguous() for dy in douts]
+        paired = False
+        if PAIR_SCALES and n == 2 and d_a1f is not None and fits and invs:
+            # the two scales scatter into two column blocks of the same rows: one launch (pn2x_rows_segment_sum_pair)
+            (da, db_), Bq = douts, douts[0].shape[0]
+            ca, cb = da.shape[2], db_.shape[2]
+            blk_a, blk_b = d_a1f[:, :, :ca], d_a1f[:, :, ca:ca + cb]
+            with torch.cuda.device(dev):
+                _native._check(_lib.pn2x_rows_segment_sum_pair(
+                    Bq, a1f_shape[1], da.shape[1], ca, da.data_ptr(), da.stride(1), invs[0].data_ptr(), invs[1].data_ptr(), blk_a.data_ptr(),
+                    blk_a.stride(1), db_.shape[1], cb, db_.data_ptr(), db_.stride(1), invs[2].data_ptr(), invs[3].data_ptr(), blk_b.data_ptr(),
+                    blk_b.stride(1), 0, _native._stream(da)), "rows_segment_sum_pair")
+            paired = True
         for i, (dy, idx, rel) in enumerate(zip(douts, idxs, rels)):
-            dy = dy.contiguous()
             B, SK, C1 = dy.shape
-            if d_a1f is not None and fits:  # owner-computes segment sum over the inverted neighbour lists: no atomics, no pre-zeroing
+            if paired:
+                pass
+            elif d_a1f is not None and fits:  # owner-computes segment sum over the inverted neighbour lists: no atomics, no pre-zeroing
                 inv = (invs[2 * i], invs[2 * i + 1]) if invs else inverse_index(idx.view(B, SK), a1f_shape[1])
                 rows_segment_sum(dy, inv, a1f_shape[1], d_a1f[:, :, col:col + C1])
             elif d_a1f is not None:

@@ -244,6 +244,12 @@ def _reduce_items(items):
 
 _lib.pn2x_bn_bwd_apply_rel.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _cl, _vp, _vp]
 _lib.pn2x_bn_bwd_apply_rel.restype = _ci
+_lib.pn2x_bn_bwd_reduce_routed_pair.argtypes = _lib.pn2x_bn_bwd_reduce_routed.argtypes[:-1] * 2 + [_vp]
+_lib.pn2x_bn_bwd_reduce_routed_pair.restype = _ci
+_lib.pn2x_bn_relu_max_pair.argtypes = _t._lib.pn2x_bn_relu_max.argtypes[:-1] * 2 + [_vp]
+_lib.pn2x_bn_relu_max_pair.restype = _ci
+_lib.pn2x_bn_bwd_apply_rel_pair.argtypes = _lib.pn2x_bn_bwd_apply_rel.argtypes[:-1] * 2 + [_vp]
+_lib.pn2x_bn_bwd_apply_rel_pair.restype = _ci
 _lib.pn2x_bn_bwd_apply_rel_scratch_floats.argtypes = [_cl, _ci]
 _lib.pn2x_bn_bwd_apply_rel_scratch_floats.restype = _cl
 _lib.pn2x_bn_bwd_apply.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp]
@@ -323,9 +329,9 @@ class _Fwd:
                 G = R // K
                 out = torch.empty((G, C), dtype=_f32, device=dev)
                 arg = torch.empty((G, C), dtype=torch.int32, device=dev)
-                _native._check(_lib.pn2x_bn_relu_max(G, K, C, yl.data_ptr(), yl.stride(0), ws_f[L - 1].data_ptr(), gamma.data_ptr(),
-                                                     beta.data_ptr(), _p(bias), float(eps), float(mom), _p(rm), _p(rv), _p(nbt),
-                                                     sv[0].data_ptr(), sv[1].data_ptr(), out.data_ptr(), arg.data_ptr(), st), "bn_relu_max")
+                yield ("max", (G, K, C, yl.data_ptr(), yl.stride(0), ws_f[L - 1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(bias),
+                               float(eps), float(mom), _p(rm), _p(rv), _p(nbt), sv[0].data_ptr(), sv[1].data_ptr(), out.data_ptr(),
+                               arg.data_ptr()), st, dev)  # (issued by _drive: alone, or with the sibling stack's as one pair launch)
             else:
                 out = torch.empty((R, C), dtype=_f32, device=dev)
                 _native._check(_lib.pn2x_bn_relu_apply(R, C, yl.data_ptr(), yl.stride(0), ws_f[L - 1].data_ptr(), gamma.data_ptr(),
@@ -396,9 +402,9 @@ class _Bwd:
             if routed:
                 # the routed gradient is non-zero in one row per (group, channel): the sums need the arg-max rows only, and the
                 # one-kernel layer backward below routes dout on load (no rows x C gradient tensor at all)
-                _native._check(_lib.pn2x_bn_bwd_reduce_routed(R // K, K, Cl, dout.data_ptr(), dout.stride(0), arg.data_ptr(), Cl, yl.data_ptr(),
-                                                              yl.stride(0), svl[0].data_ptr(), svl[1].data_ptr(), gam(L - 1).data_ptr(),
-                                                              bet(L - 1).data_ptr(), sums[L - 1].data_ptr(), st), "bn_bwd_reduce_routed")
+                yield ("routed", (R // K, K, Cl, dout.data_ptr(), dout.stride(0), arg.data_ptr(), Cl, yl.data_ptr(), yl.stride(0),
+                                  svl[0].data_ptr(), svl[1].data_ptr(), gam(L - 1).data_ptr(), bet(L - 1).data_ptr(),
+                                  sums[L - 1].data_ptr()), st, dev)
             elif K and ROUTE_DENSE:
                 # the reduction reads dout / arg / y_L anyway: it also writes the routed, masked gradient once (dense), and the two
                 # GEMMs of the top layer read that instead of routing through arg-max on every load (their slowest variant)
@@ -480,10 +486,10 @@ class _Bwd:
                 nf = int(_lib.pn2x_bn_bwd_apply_rel_scratch_floats(R, C1))
                 scratch = torch.empty(nf, dtype=_f32, device=dev)
                 dwx = torch.empty((C1, 3), dtype=_f32, device=dev)
-                _native._check(_lib.pn2x_bn_bwd_apply_rel(R, C1, g.data_ptr(), g.stride(0), y1.data_ptr(), y1.stride(0), sv1[0].data_ptr(),
-                                                          sv1[1].data_ptr(), gam(0).data_ptr(), bet(0).data_ptr(), 0, sums[0].data_ptr(),
-                                                          dy1.data_ptr(), C1, dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(),
-                                                          rel.data_ptr(), scratch.data_ptr(), nf, dwx.data_ptr(), st), "bn_bwd_apply_rel")
+                # (issued by _drive: alone, or with the sibling stack's as one pair launch)
+                yield ("apply_rel", (R, C1, g.data_ptr(), g.stride(0), y1.data_ptr(), y1.stride(0), sv1[0].data_ptr(), sv1[1].data_ptr(),
+                                     gam(0).data_ptr(), bet(0).data_ptr(), 0, sums[0].data_ptr(), dy1.data_ptr(), C1, dpar[0].data_ptr(),
+                                     dpar[1].data_ptr(), dpar[2].data_ptr(), rel.data_ptr(), scratch.data_ptr(), nf, dwx.data_ptr()), st, dev)
                 adict["dwx"][ai] = dwx
             else:
                 _native._check(_lib.pn2x_bn_bwd_apply(R, C1, g.data_ptr(), g.stride(0), y1.data_ptr(), y1.stride(0), sv1[0].data_ptr(),
@@ -502,6 +508,8 @@ def _pairable(a, b):
         return False
     if a[0] == "fwd2":
         return a[1][1:3] == b[1][1:3] and bool(_lib.pn2x_tg_fwd2_pair_supported(a[1][1], a[1][2]))
+    if a[0] in ("apply_rel", "max", "routed"):
+        return True
     return a[1][1:4] == b[1][1:4] and bool(_lib.pn2x_tg_bwd_pair_supported(a[1][2], a[1][1]))
 
 
@@ -510,6 +518,15 @@ def _issue(req):
     with torch.cuda.device(dev):
         if kind == "fwd2":
             _native._check(_lib.pn2x_tg_fwd2(*args, st), "tg_fwd2")
+            return None
+        if kind == "apply_rel":
+            _native._check(_lib.pn2x_bn_bwd_apply_rel(*args, st), "bn_bwd_apply_rel")
+            return None
+        if kind == "max":
+            _native._check(_lib.pn2x_bn_relu_max(*args, st), "bn_relu_max")
+            return None
+        if kind == "routed":
+            _native._check(_lib.pn2x_bn_bwd_reduce_routed(*args, st), "bn_bwd_reduce_routed")
             return None
         _native._check(_lib.pn2x_tg_bwd_slice(*args, st), "tg_bwd")
         return req[4]
@@ -520,6 +537,15 @@ def _issue_pair(a, b):
     with torch.cuda.device(dev):
         if kind == "fwd2":
             _native._check(_lib.pn2x_tg_fwd2_pair(*a[1], b[1][0], *b[1][3:], st), "tg_fwd2_pair")
+            return None, None
+        if kind == "apply_rel":
+            _native._check(_lib.pn2x_bn_bwd_apply_rel_pair(*a[1], *b[1], st), "bn_bwd_apply_rel_pair")
+            return None, None
+        if kind == "max":
+            _native._check(_lib.pn2x_bn_relu_max_pair(*a[1], *b[1], st), "bn_relu_max_pair")
+            return None, None
+        if kind == "routed":
+            _native._check(_lib.pn2x_bn_bwd_reduce_routed_pair(*a[1], *b[1], st), "bn_bwd_reduce_routed_pair")
             return None, None
         nparts = (_ci * 2)()
         _native._check(_lib.pn2x_tg_bwd_slice_pair(*a[1], *b[1], nparts, st), "tg_bwd_pair")

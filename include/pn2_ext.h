@@ -328,6 +328,14 @@ int pn2x_sa_layer1_ld(int b, int n, int s, int k, int c1, const float *a1f, int 
 int pn2x_sa_layer1_stats(int b, int n, int s, int k, int c1, const float *a1f, int a1f_ld, const float *xyz, const float *cxyz,
                          const float *wx, int wx_ld, const float *cadd, int cadd_ld, const int *idx, float *out, float *rel_out,
                          double *sums, void *stream);
+/* ... for the TWO neighbourhood sizes of one module (pointnet_utils.py:566-581: same clouds, coordinates and centres; per scale its
+ * neighbour list, weight block, per-point / per-centre terms, output, relative coordinates and statistics) in ONE launch: alone, the
+ * K = 16 scale is a 12 us launch for a quarter of the K = 64 scale's rows.  Same results as two pn2x_sa_layer1_stats calls. */
+int pn2x_sa_layer1_stats_pair(int b, int n, int s, const float *xyz, const float *cxyz, int k_a, int c1_a, const float *a1f_a, int a1f_ld_a,
+                              const float *wx_a, int wx_ld_a, const float *cadd_a, int cadd_ld_a, const int *idx_a, float *out_a,
+                              float *rel_out_a, double *sums_a, int k_b, int c1_b, const float *a1f_b, int a1f_ld_b, const float *wx_b,
+                              int wx_ld_b, const float *cadd_b, int cadd_ld_b, const int *idx_b, float *out_b, float *rel_out_b,
+                              double *sums_b, void *stream);
 /*
  * Transpose of pn2x_gather_rows (group_points_grad on point-major rows, reference group_points_gpu.cu:8-25):
  *   din[b, idx[b,j], :] += dout[b, j, :]      dout (b, m, ldo), idx (b, m) int32, din (b, n, ldi) accumulated into.
@@ -354,6 +362,11 @@ int pn2x_three_interpolate_pm_grad(int b, int c, int m, int n, const float *dout
 int pn2x_inverse_index(int b, int n_dst, int l, const int *idx, int *offsets, int *order, void *stream);
 int pn2x_rows_segment_sum(int b, int n_dst, int m_src, int t, int c, const float *dout, int ldo, const int *offsets,
                           const int *order, const float *weight, float *din, int ldi, int accumulate, void *stream);
+/* t = 1 for TWO index lists over the same destination rows (the two neighbourhood sizes of a module scatter into two column blocks of
+ * one gradient) in one launch where both take the one-thread-per-(destination, quad) kernel; two calls otherwise.  Same results. */
+int pn2x_rows_segment_sum_pair(int b, int n_dst, int m_a, int c_a, const float *dout_a, int ldo_a, const int *offsets_a, const int *order_a,
+                               float *din_a, int ldi_a, int m_b, int c_b, const float *dout_b, int ldo_b, const int *offsets_b,
+                               const int *order_b, float *din_b, int ldi_b, int accumulate, void *stream);
 
 /*
  * Backward of group_points / gather_points (t = 1) and three_interpolate (t = 3) on the reference's channel-major layout with
@@ -379,6 +392,14 @@ int pn2x_scatter_cm(int t, int b, int c, int n_dst, int m_src, const float *grad
 int pn2x_bn_relu_max(long groups, int k, int c, const float *y, int ldy, const double *sums, const float *gamma, const float *beta,
                      const float *conv_bias, float eps, float momentum, float *running_mean, float *running_var,
                      long long *num_batches_tracked, float *save_mean, float *save_invstd, float *out, int *arg, void *stream);
+/* two problems (the two neighbourhood sizes of a module) in ONE launch where both take the few-groups kernel; two calls otherwise */
+int pn2x_bn_relu_max_pair(long groups_a, int k_a, int c_a, const float *y_a, int ldy_a, const double *sums_a, const float *gamma_a,
+                          const float *beta_a, const float *conv_bias_a, float eps_a, float momentum_a, float *running_mean_a,
+                          float *running_var_a, long long *nbt_a, float *save_mean_a, float *save_invstd_a, float *out_a, int *arg_a,
+                          long groups_b, int k_b, int c_b, const float *y_b, int ldy_b, const double *sums_b, const float *gamma_b,
+                          const float *beta_b, const float *conv_bias_b, float eps_b, float momentum_b, float *running_mean_b,
+                          float *running_var_b, long long *nbt_b, float *save_mean_b, float *save_invstd_b, float *out_b, int *arg_b,
+                          void *stream);
 int pn2x_bn_relu_max_bwd(long groups, int k, int c, const float *dout, const int *arg, const float *y, int ldy, const float *mean,
                          const float *invstd, const float *gamma, const float *beta, double *sums, float *dy, int ldo, float *dgamma,
                          float *dbeta, float *dbias, void *stream);
@@ -402,6 +423,12 @@ int pn2x_bn_bwd_reduce_g(long rows, int c, const float *dh, int ldd, const int *
  * dout (groups x c, row stride ldd: may be a column block of a wider gradient), arg (groups x c, row stride lda), y ((groups * k) x c).  The layer below then routes on load (pn2x_tg_bwd, gmode 2). */
 int pn2x_bn_bwd_reduce_routed(long groups, int k, int c, const float *dout, int ldd, const int *arg, int lda, const float *y, int ldy,
                               const float *mean, const float *invstd, const float *gamma, const float *beta, double *sums, void *stream);
+/* two problems of the same channel count in one launch (two launches when the counts differ); same results */
+int pn2x_bn_bwd_reduce_routed_pair(long groups_a, int k_a, int c_a, const float *dout_a, int ldd_a, const int *arg_a, int lda_a,
+                                   const float *y_a, int ldy_a, const float *mean_a, const float *invstd_a, const float *gamma_a,
+                                   const float *beta_a, double *sums_a, long groups_b, int k_b, int c_b, const float *dout_b, int ldd_b,
+                                   const int *arg_b, int lda_b, const float *y_b, int ldy_b, const float *mean_b, const float *invstd_b,
+                                   const float *gamma_b, const float *beta_b, double *sums_b, void *stream);
 /* out (c x 3) = dy^T rel: dy (rows x c, row stride ldy), rel (rows x 3) -- the gradient of the three xyz columns of a grouped
  * layer-1 weight.  c / 4 must divide 256; scratch of pn2x_rows_outer3_scratch_floats(rows, c) floats (per-workgroup partials). */
 long pn2x_rows_outer3_scratch_floats(long rows, int c);
@@ -418,6 +445,15 @@ long pn2x_bn_bwd_apply_rel_scratch_floats(long rows, int c);
 int pn2x_bn_bwd_apply_rel(long rows, int c, const float *g, int ldg, const float *y, int ldy, const float *mean, const float *invstd,
                           const float *gamma, const float *beta, int relu, const double *sums, float *dy, int ldo, float *dgamma,
                           float *dbeta, float *dbias, const float *rel, float *scratch, long scratch_floats, float *dwx, void *stream);
+/* two problems (the two neighbourhood sizes of a module) in one launch each of the two kernels; same results as two calls */
+int pn2x_bn_bwd_apply_rel_pair(long rows_a, int c_a, const float *g_a, int ldg_a, const float *y_a, int ldy_a, const float *mean_a,
+                               const float *invstd_a, const float *gamma_a, const float *beta_a, int relu_a, const double *sums_a,
+                               float *dy_a, int ldo_a, float *dgamma_a, float *dbeta_a, float *dbias_a, const float *rel_a,
+                               float *scratch_a, long scratch_floats_a, float *dwx_a, long rows_b, int c_b, const float *g_b, int ldg_b,
+                               const float *y_b, int ldy_b, const float *mean_b, const float *invstd_b, const float *gamma_b,
+                               const float *beta_b, int relu_b, const double *sums_b, float *dy_b, int ldo_b, float *dgamma_b,
+                               float *dbeta_b, float *dbias_b, const float *rel_b, float *scratch_b, long scratch_floats_b, float *dwx_b,
+                               void *stream);
 
 /*
  * Train-mode [Conv 1x1 + BatchNorm + ReLU] layers with the BatchNorm folded into fp32-MFMA GEMMs (csrc/train_gemm.hip;

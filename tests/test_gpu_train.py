@@ -967,3 +967,54 @@ def test_mlp_stack_pair_equals_two_stacks(widths, Ka, Kb, G):
             torch.testing.assert_close(b, a, rtol=2e-4, atol=2e-5 * max(1.0, float(a.abs().max())), msg=lambda m: f"tensor {i}: {m}")
     for a, b in zip(res[False][1], res[True][1]):
         torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("with_centre", [False, True])
+def test_query_module_pair_launches_equal_single_launches(monkeypatch, with_centre):
+    """One keypoint-query module (two neighbourhood sizes, reference pointnet_utils.py:566-581) through train_ops.sa_layer1 +
+    train_stack.mlp_stack_pair with every two-problem launch on (layer-1 assembly + statistics, BatchNorm + ReLU + max, the
+    routed reduction, the first-layer BatchNorm backward + d(W_xyz), the two row scatters: csrc/train_ops.hip *_pair) against the
+    same module with one launch per scale: the streaming kernels run the same per-element code, so everything they produce is
+    bit-equal; what passes through the fused GEMM kernels agrees to round-off."""
+    from hotrack_amd import train_ops, train_stack
+    from hotrack_amd.train_ops import Workspace, inverse_index, sa_layer1
+    B, N, S, C = 3, 512, 21, 128
+    Ks = (16, 64)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xyz = torch.rand(B, N, 3, device="cuda", generator=g)
+    cxyz = torch.rand(B, S, 3, device="cuda", generator=g)
+    idxs = [torch.randint(0, N, (B, S, K), device="cuda", generator=g, dtype=torch.int32) for K in Ks]
+    invs = [inverse_index(i.view(B, -1), N) for i in idxs]
+    a1f0 = torch.randn(B, N, 2 * C, device="cuda", generator=g)
+    cadd0 = torch.randn(B, S, 2 * C, device="cuda", generator=g) if with_centre else None
+    go = [torch.randn(B * S, 192, device="cuda", generator=g) for _ in Ks]
+    res = {}
+    for paired in (False, True):
+        monkeypatch.setattr(train_ops, "PAIR_SCALES", paired)
+        monkeypatch.setattr(train_stack, "PAIR_LAUNCH", paired)
+        torch.manual_seed(11)
+        wxs = [torch.randn(C, 3, device="cuda").requires_grad_(True) for _ in Ks]
+        stacks = []
+        for _ in Ks:
+            convs = [torch.nn.Conv1d(128, 128, 1).cuda(), torch.nn.Conv1d(128, 192, 1).cuda()]
+            bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in (128, 128, 192)]
+            stacks.append((convs, bns))
+        ws = Workspace("cuda")
+        a1f = a1f0.clone().requires_grad_(True)
+        cadd = cadd0.clone().requires_grad_(True) if with_centre else None
+        aux = {}
+        y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, wxs, invs=invs, aux=aux, ws=ws)
+        layers = [[train_stack.Layer(None, bns[0], None)] + [train_stack.Layer(c.weight, bn, c.bias) for c, bn in zip(convs, bns[1:])]
+                  for convs, bns in stacks]
+        oa, ob = train_stack.mlp_stack_pair(y1s[0].view(-1, C), y1s[1].view(-1, C), layers[0], layers[1], ws, Ks[0], Ks[1],
+                                            aux_a=(aux, 0), aux_b=(aux, 1))
+        ((oa * go[0]).sum() + (ob * go[1]).sum()).backward()
+        params = [p for convs, bns in stacks for m in convs + bns for p in m.parameters()]
+        res[paired] = ([y.detach() for y in y1s], [oa.detach(), ob.detach(), a1f.grad] + ([cadd.grad] if with_centre else [])
+                       + [w.grad for w in wxs] + [p.grad for p in params])
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b)  # layer-1 pre-activations: the same expressions
+    for i, (a, b) in enumerate(zip(res[False][1], res[True][1])):
+        assert (a is None) == (b is None), i
+        if a is not None:
+            torch.testing.assert_close(b, a, rtol=2e-4, atol=2e-5 * max(1.0, float(a.abs().max())), msg=lambda m: f"tensor {i}: {m}")
