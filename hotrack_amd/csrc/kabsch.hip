@@ -267,15 +267,16 @@ __constant__ int kHlPalmIdx[kHlPalm] = {0, 1, 5, 9, 13, 17};  // hand_utils.hand
 
 constexpr int kHlChunk = 128;  // clouds per pass of the single workgroup
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(512)
 hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const float *__restrict__ init_hf, const float *__restrict__ gt_kp,
                      const float *__restrict__ pred_kp, const float *__restrict__ Rc, const float *__restrict__ tc, float s,
                      const float *__restrict__ palm, float *__restrict__ out, float *__restrict__ saved,
                      const float *__restrict__ weights) {
     // saved per cloud: [0:63) gt_s (3,21 channel-major) | [63:72) R | [72:75) t | [75:84) R_gt | [84:87) t_gt
-    // One workgroup of 16 waves, clouds in passes of 128: (1) a wave per cloud with lanes 0..20 = the keypoints (all loads of a cloud
+    // One workgroup of 8 waves (512 threads: the closed-form rigid fit needs more than the 128 registers a 1024-thread workgroup
+    // leaves a thread), clouds in passes of 128: (1) a wave per cloud with lanes 0..20 = the keypoints (all loads of a cloud
     // in flight together), palm points to LDS; (2) 2 x 128 threads each solve ONE rigid fit (ground truth / predicted) -- all fits of a
-    // pass run side by side, the Jacobi solve is the long pole (~15 us once); (3) a thread per cloud forms the rotation / translation terms.
+    // pass run side by side (closed form; the Jacobi sweep -- ~15 us -- only for ill-separated fits); (3) a thread per cloud forms the rotation / translation terms.
     __shared__ float acc[9];
     __shared__ float yl[kHlChunk][2][kHlPalm * 3];
     __shared__ float fit[kHlChunk][2][12];
@@ -285,7 +286,7 @@ hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const flo
     for (int b0 = 0; b0 < B; b0 += kHlChunk) {
         const int nb = (B - b0) < kHlChunk ? (B - b0) : kHlChunk;
         __syncthreads();
-        for (int i = w; i < nb; i += 16) {
+        for (int i = w; i < nb; i += 8) {
             const int b = b0 + i;
             const float *Rb = Rc + 9 * (size_t)b, *tb = tc + 3 * (size_t)b;
             float *sv = saved + 87 * (size_t)b;
@@ -321,7 +322,7 @@ hand_loss_fwd_kernel(int B, int pb, const float *__restrict__ pred_hf, const flo
             float y[kHlPalm * 3];
             for (int e = 0; e < kHlPalm * 3; ++e) y[e] = yl[i][role][e];
             double R[3][3], t[3];
-            kabsch_solve<false>(kHlPalm, palm + (size_t)(pb == 1 ? 0 : b) * kHlPalm * 3, y, 3, R, t);
+            kabsch_solve<true>(kHlPalm, palm + (size_t)(pb == 1 ? 0 : b) * kHlPalm * 3, y, 3, R, t);
             float *dst = saved + 87 * (size_t)b + (role == 0 ? 75 : 63);
             for (int a = 0; a < 3; ++a) {
                 for (int c = 0; c < 3; ++c) dst[3 * a + c] = fit[i][role][3 * a + c] = (float)R[a][c];
@@ -481,7 +482,7 @@ extern "C" int pn2x_hand_losses2(int b, int pb, const float *pred_hf, const floa
                                  const float *weights, void *stream) {
     if (b < 1 || !(pb == 1 || pb == b) || !(scale > 0.f)) return PN2_EINVAL;
     if (!pred_hf || !init_hf || !gt_kp || !pred_kp || !R || !t || !palm || !out || !saved) return PN2_ENULL;
-    hipLaunchKernelGGL(pn2::hand_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, b, pb, pred_hf, init_hf, gt_kp, pred_kp, R, t,
+    hipLaunchKernelGGL(pn2::hand_loss_fwd_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, b, pb, pred_hf, init_hf, gt_kp, pred_kp, R, t,
                        scale, palm, out, saved, weights);
     return pn2::check_launch();
 }

@@ -2,6 +2,7 @@
 
     linear(x, weight, bias=None)                     torch.nn.functional.linear for 2-D x and a weight PARAMETER
                                                      (C_out, C_in[, 1[, 1]]); same values forward
+    linear_blocks(blocks, weight)                    the same for an input that is a column concatenation, without the concatenation
     per_point_first_layer(x, groups, D)              the per-point halves x . W_f^T of the first layers of set-abstraction
                                                      modules whose weights are [feature | xyz | centre] column blocks
                                                      (reference pointnet_utils.py:389-403, :566-581), plus the xyz / centre
@@ -109,6 +110,76 @@ class _Linear(torch.autograd.Function):
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
     """x (R, C_in) . weight^T (+ bias): `weight` the PARAMETER itself, (C_out, C_in) or a 1x1 convolution's (C_out, C_in, 1[, 1])."""
     return _Linear.apply(x, weight, bias)
+
+
+class _LinearBlocks(torch.autograd.Function):
+    """y (R, N) = sum_i X_i . W[:, cols_i]^T for an input that is the column concatenation of the blocks X_i -- without the
+    concatenation.  reps[i] = 1: X_i (R, k_i); reps[i] = n > 1: X_i (R / n, k_i) whose every row stands for n consecutive rows of
+    the input (a per-cloud feature broadcast over the cloud's points: reference pointnet_utils.py:437-438 repeats it), its product
+    is then formed once per source row and added to the n rows it covers.  Input gradients are written contiguous (no slice of a
+    wider gradient to be copied); weight gradients per column block at the end of the pass."""
+
+    @staticmethod
+    def forward(ctx, weight, reps, *xs):
+        w2 = weight.view(weight.shape[0], -1)
+        y, col, cols = None, 0, []
+        order = sorted(range(len(xs)), key=lambda i: reps[i] != 1)  # a full-rows block first: it creates y
+        for i in range(len(xs)):
+            cols.append(col)
+            col += xs[i].shape[1]
+        for i in order:
+            x, wb = xs[i], w2[:, cols[i]:cols[i] + xs[i].shape[1]]
+            if reps[i] == 1:
+                y = torch.mm(x, wb.t()) if y is None else y.addmm_(x, wb.t())
+            else:
+                t = torch.mm(x, wb.t())  # (R / n, N)
+                if y is None:
+                    y = t.repeat_interleave(reps[i], dim=0)
+                else:
+                    y.view(x.shape[0], reps[i], -1).add_(t.unsqueeze(1))
+        ctx.save_for_backward(weight, *xs)
+        ctx.reps, ctx.cols = tuple(reps), tuple(cols)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        weight, *xs = ctx.saved_tensors
+        reps, cols = ctx.reps, ctx.cols
+        w2 = weight.view(weight.shape[0], -1)
+        N = w2.shape[0]
+        gs = {}  # g summed over the rows a broadcast row covers, per repeat factor
+
+        def gsum(n):
+            if n not in gs:
+                gs[n] = g.view(g.shape[0] // n, n, N).sum(1)
+            return gs[n]
+        dxs = []
+        for i, x in enumerate(xs):
+            if not ctx.needs_input_grad[2 + i]:
+                dxs.append(None)
+                continue
+            wb = w2[:, cols[i]:cols[i] + x.shape[1]]
+            dxs.append(torch.mm(g if reps[i] == 1 else gsum(reps[i]), wb))
+        dw = None
+        if ctx.needs_input_grad[0]:
+            if g.is_cuda and _defer_ok([weight]):
+                gg = _rows(g)
+                dw = torch.empty(w2.shape, dtype=_f32, device=g.device)
+                for i, x in enumerate(xs):
+                    gi = gg if reps[i] == 1 else _rows(gsum(reps[i]))
+                    _record(gi, _rows(x), dw, dw.data_ptr() + 4 * cols[i], w2.shape[1], N, x.shape[1])
+                dw = dw.view(weight.shape)
+            else:
+                dw = torch.cat([torch.mm((g if reps[i] == 1 else gsum(reps[i])).t(), x) for i, x in enumerate(xs)], dim=1).view(weight.shape)
+        return (dw, None, *dxs)
+
+
+def linear_blocks(blocks, weight: torch.Tensor) -> torch.Tensor:
+    """torch.nn.functional.linear(cat(blocks, dim=1), weight) without materialising the concatenation.  blocks: list of X (R, k)
+    or (X (R / n, k), n) -- a block whose rows are each repeated n times; weight: the PARAMETER (N, sum k[, 1[, 1]])."""
+    xs = [b[0] if isinstance(b, tuple) else b for b in blocks]
+    reps = tuple(int(b[1]) if isinstance(b, tuple) else 1 for b in blocks)
+    return _LinearBlocks.apply(weight, reps, *xs)
 
 
 class _PerPoint(torch.autograd.Function):

@@ -211,11 +211,18 @@ class FastTrain:
         else:
             w, i3, inv = nn3 if nn3 is not None else (*ext.three_nn_weights(xyz1, xyz2), None)
             interp = interpolate_rows(points2, i3, w, inv=inv)
-        x = interp if points1 is None else torch.cat([points1, interp], dim=2)
         convs, bns = list(mod.mlp_convs), list(mod.mlp_bns)
         if extra is not None:
             convs.append(extra[0])
             bns.append(extra[1])
+        if self.defer_wgrad and self.use_fused_stacks:
+            # layer 1 over [skip | interpolated] as the sum of its column blocks' products: no concatenation forward, no copy of a
+            # gradient slice backward; a broadcast per-cloud feature (fp3: the global feature) is multiplied once per cloud
+            from hotrack_amd.linear_dw import linear_blocks
+            blocks = [] if points1 is None else [points1.reshape(B * N, -1)]
+            blocks.append((points2.reshape(B, -1), N) if xyz2.shape[1] == 1 else interp.reshape(B * N, -1))
+            return self._stack(linear_blocks(blocks, convs[0].weight), convs, bns, first_done=True)
+        x = interp if points1 is None else torch.cat([points1, interp], dim=2)
         return self._stack(x.reshape(B * N, -1), convs, bns)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -278,8 +285,14 @@ class FastTrain:
         l1_feat = self._sa_scales(bh.sa1, xyz, l1_xyz, None, [geo["idx1"]])                            # (B,S1,64)
         l2_feat = self._sa_scales(bh.sa2, l1_xyz, l2_xyz, l1_feat.reshape(B * S1, -1), [geo["idx2"]],
                                   invs=None if geo["inv2"] is None else [geo["inv2"]])                  # (B,S2,128)
-        x = torch.cat([l2_xyz, l2_feat], dim=2).view(B * S2, -1)   # group-all: [xyz | feat], centre = origin (not subtracted)
-        l3 = self._stack(x, bh.sa3.mlp_convs, bh.sa3.mlp_bns, max_over=S2).view(B, 1, -1)                    # (B,1,512)
+        # group-all: [xyz | feat], centre = origin (not subtracted)
+        if self.defer_wgrad and self.use_fused_stacks:
+            from hotrack_amd.linear_dw import linear_blocks
+            y1 = linear_blocks([l2_xyz.reshape(B * S2, 3), l2_feat.reshape(B * S2, -1)], bh.sa3.mlp_convs[0].weight)
+            l3 = self._stack(y1, bh.sa3.mlp_convs, bh.sa3.mlp_bns, first_done=True, max_over=S2).view(B, 1, -1)  # (B,1,512)
+        else:
+            x = torch.cat([l2_xyz, l2_feat], dim=2).view(B * S2, -1)
+            l3 = self._stack(x, bh.sa3.mlp_convs, bh.sa3.mlp_bns, max_over=S2).view(B, 1, -1)
         l2_out = self._fp(bh.fp3, l2_xyz, l2_xyz[:, :1], l2_feat, l3).view(B, S2, -1)
         l1_out = self._fp(bh.fp2, l1_xyz, l2_xyz, l1_feat, l2_out, nn3=geo["fp2"]).view(B, S1, -1)
         # fp1 (skip = xyz) and the backbone's conv1 / bn1 as one stack [131 -> 128 -> 128 -> C]
