@@ -627,6 +627,15 @@ __device__ __forceinline__ void sa_layer1_stats_body(const SaLayer1Args &A, unsi
     const int sk = S * K, rpp = kTT / Q;  // kTT % Q == 0 (checked by the launcher)
     const int q = threadIdx.x % Q, rr = threadIdx.x / Q;
     const int r0 = (int)bx * rows_per_block, r1 = min(sk, r0 + rows_per_block);
+    // Rows go through the workgroup in batches of kTT.  Phase A: thread t fetches what row r + t needs besides its feature quads --
+    // neighbour index, the neighbour's and the centre's coordinates -- ONCE (the Q threads that share a row used to fetch them Q
+    // times: 56 load instructions per 128-byte output row at sa1, which made this kernel load-issue bound at 1.4 TB/s), leaves
+    // index and relative coordinates in LDS and writes the relative coordinates out with one 12-byte run per thread.  Phase B:
+    // thread (q, rr) forms channel quad q of rows rr, rr + rpp, ... of the batch from LDS + its own feature / centre-term quads,
+    // four rows per round with their gathers in flight together.  Same floats, same order of the statistics' additions as one
+    // thread per (row, quad).
+    __shared__ int s_j[kTT];
+    __shared__ float s_rel[kTT][3];
     float w[4][3] = {{0.f}};
     if (xyz) {
 #pragma unroll
@@ -635,67 +644,59 @@ __device__ __forceinline__ void sa_layer1_stats_body(const SaLayer1Args &A, unsi
             for (int c = 0; c < 3; ++c) w[i][c] = wx[(size_t)(4 * q + i) * wx_ld + c];
     }
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sq = sm;
-    // one row: the expressions of sa_layer1_kernel (same floats); sums taken in row order
-    auto finish = [&](int r, float4 acc, float px, float py, float pz, float cx, float cy, float cz, float4 cv) {
+    typedef float v4 __attribute__((ext_vector_type(4)));  // (an array of float4 STRUCTS stays in scratch memory)
+    auto finish = [&](int r, int lr, v4 a, v4 cv) {
+        float4 acc = make_float4(a.x, a.y, a.z, a.w);
         if (xyz) {
-            const float rx = px - cx, ry = py - cy, rz = pz - cz;
-            acc.x += w[0][0] * rx + w[0][1] * ry + w[0][2] * rz;
+            const float rx = s_rel[lr][0], ry = s_rel[lr][1], rz = s_rel[lr][2];
+            acc.x += w[0][0] * rx + w[0][1] * ry + w[0][2] * rz;  // the expressions of sa_layer1_kernel: same floats
             acc.y += w[1][0] * rx + w[1][1] * ry + w[1][2] * rz;
             acc.z += w[2][0] * rx + w[2][1] * ry + w[2][2] * rz;
             acc.w += w[3][0] * rx + w[3][1] * ry + w[3][2] * rz;
-            if (rel_out && q == 0) {
-                float *o = rel_out + ((size_t)b * sk + r) * 3;
-                o[0] = rx; o[1] = ry; o[2] = rz;
-            }
         }
         if (cadd) { acc.x += cv.x; acc.y += cv.y; acc.z += cv.z; acc.w += cv.w; }
         *reinterpret_cast<float4 *>(out + ((size_t)b * sk + r) * (4 * Q) + 4 * q) = acc;
         sm.x += acc.x; sm.y += acc.y; sm.z += acc.z; sm.w += acc.w;
         sq.x += acc.x * acc.x; sq.y += acc.y * acc.y; sq.z += acc.z * acc.z; sq.w += acc.w * acc.w;
     };
-    int r = r0 + rr;
-    // four rows per round: their neighbour indices first, then every gather of the round in flight together (a row is two
-    // dependent memory round trips -- index, then the rows it names -- and one row at a time made this kernel a latency chain:
-    // 1.4 TB/s on sa1's 262144 x 32 output).  (Native vector types: an array of float4 STRUCTS stays in scratch memory.)
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    for (; r + 3 * rpp < r1; r += 4 * rpp) {
-        int j[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) j[u] = idx[(size_t)b * sk + r + u * rpp];
-        v4 acc[4], cv[4];
-        float px[4], py[4], pz[4], cx[4], cy[4], cz[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc[u] = a1f ? *reinterpret_cast<const v4 *>(a1f + ((size_t)b * n + j[u]) * a1f_ld + 4 * q) : v4{0.f, 0.f, 0.f, 0.f};
-            px[u] = py[u] = pz[u] = cx[u] = cy[u] = cz[u] = 0.f;
-            cv[u] = v4{0.f, 0.f, 0.f, 0.f};
-            const int s = (r + u * rpp) / K;
-            if (xyz) {
-                const float *p = xyz + ((size_t)b * n + j[u]) * 3, *c = cxyz + ((size_t)b * S + s) * 3;
-                px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
-                cx[u] = c[0]; cy[u] = c[1]; cz[u] = c[2];
+    const v4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int rb = r0; rb < r1; rb += kTT) {
+        __syncthreads();  // (the previous batch's rows are consumed)
+        {
+            const int r = rb + (int)threadIdx.x;
+            if (r < r1) {
+                const int j = idx[(size_t)b * sk + r];
+                s_j[threadIdx.x] = j;
+                if (xyz) {
+                    const float *p = xyz + ((size_t)b * n + j) * 3, *c = cxyz + ((size_t)b * S + r / K) * 3;
+                    const float rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
+                    s_rel[threadIdx.x][0] = rx; s_rel[threadIdx.x][1] = ry; s_rel[threadIdx.x][2] = rz;
+                    if (rel_out) {
+                        float *o = rel_out + ((size_t)b * sk + r) * 3;
+                        o[0] = rx; o[1] = ry; o[2] = rz;
+                    }
+                }
             }
-            if (cadd) cv[u] = *reinterpret_cast<const v4 *>(cadd + ((size_t)b * S + s) * cadd_ld + 4 * q);
         }
+        __syncthreads();
+        const int nb = min(kTT, r1 - rb);
+        int lr = rr;
+        for (; lr + 3 * rpp < nb; lr += 4 * rpp) {
+            v4 a[4], cv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            finish(r + u * rpp, make_float4(acc[u].x, acc[u].y, acc[u].z, acc[u].w), px[u], py[u], pz[u], cx[u], cy[u], cz[u],
-                   make_float4(cv[u].x, cv[u].y, cv[u].z, cv[u].w));
-    }
-    for (; r < r1; r += rpp) {
-        const int s = r / K;
-        const int j = idx[(size_t)b * sk + r];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a1f) acc = *reinterpret_cast<const float4 *>(a1f + ((size_t)b * n + j) * a1f_ld + 4 * q);
-        float px = 0.f, py = 0.f, pz = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
-        if (xyz) {
-            const float *p = xyz + ((size_t)b * n + j) * 3, *c = cxyz + ((size_t)b * S + s) * 3;
-            px = p[0]; py = p[1]; pz = p[2];
-            cx = c[0]; cy = c[1]; cz = c[2];
+            for (int u = 0; u < 4; ++u) {
+                const int l = lr + u * rpp;
+                a[u] = a1f ? *reinterpret_cast<const v4 *>(a1f + ((size_t)b * n + s_j[l]) * a1f_ld + 4 * q) : z4;
+                cv[u] = cadd ? *reinterpret_cast<const v4 *>(cadd + ((size_t)b * S + (rb + l) / K) * cadd_ld + 4 * q) : z4;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) finish(rb + lr + u * rpp, lr + u * rpp, a[u], cv[u]);
         }
-        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cadd) cv = *reinterpret_cast<const float4 *>(cadd + ((size_t)b * S + s) * cadd_ld + 4 * q);
-        finish(r, acc, px, py, pz, cx, cy, cz, cv);
+        for (; lr < nb; lr += rpp) {
+            const v4 a = a1f ? *reinterpret_cast<const v4 *>(a1f + ((size_t)b * n + s_j[lr]) * a1f_ld + 4 * q) : z4;
+            const v4 cv = cadd ? *reinterpret_cast<const v4 *>(cadd + ((size_t)b * S + (rb + lr) / K) * cadd_ld + 4 * q) : z4;
+            finish(rb + lr, lr, a, cv);
+        }
     }
     block_reduce_to_sums(sm, sq, Q, rpp, 4 * Q, sums);
 }
