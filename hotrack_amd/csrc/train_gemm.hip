@@ -26,6 +26,7 @@
 // of the MFMAs that consume the previous one.  The fp32 MFMA issues at the fp32 vector rate (64 cycles per 32x32x2), so two
 // ds_read_b32 per instruction keep the LDS pipe under a tenth of its rate and the kernels are bound by the matrix pipe for
 // wide layers (128+ channels) and by HBM for the narrow ones (32 / 64 channels x 262144 rows).
+#include <cstdlib>
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
@@ -890,7 +891,10 @@ extern "C" int pn2x_tg_reduce_multi2(int count, const float *const *partial, con
             a.P[i] = n_partials[j]; a.numel[i] = numel[j]; a.N[i] = channels[j];
             a.sld[i] = sums_ld ? sums_ld[j] : channels[j];
             if (a.sld[i] < channels[j]) return PN2_EINVAL;
-            int ps = a.P[i] / 32;
+            static const int per_slice = [] { const char *e = getenv("PN2_TGR_SLICE"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+            // partial tiles per slice (PN2_TGR_SLICE: probes).  32 per slice = 8 slices x numel atomics per layer: 59.6 us for the step's
+            // 200 MB of partial tiles; 128 per slice: 50.0 us (fewer atomics, still thousands of workgroups)
+            int ps = a.P[i] / per_slice;
             if (ps < 1) ps = 1;
             if (ps > 64) ps = 64;
             a.ps[i] = ps;
