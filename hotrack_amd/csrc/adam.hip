@@ -37,9 +37,17 @@ adam_kernel(Pack a, double lr_d, double beta1_d, double beta2_d, double eps_d, d
     const long n = a.numel[t];
     const long end = off + kChunk < n ? off + kChunk : n;
     // scalar constants in double like torch's kernel (its hyper-parameters are doubles: 1 - 0.999f is off by 1.3e-5 relative)
-    const double step = (double)a.step[t][0] + 1.0;  // the counters are advanced after all update kernels (adam_step_kernel)
-    const double bc1 = 1.0 - pow(beta1_d, step), bc2 = 1.0 - pow(beta2_d, step);
-    const float step_size = (float)(lr_d / bc1), bc2_sqrt = (float)sqrt(bc2);
+    // the bias corrections need two fp64 pow() and a sqrt(): ONE thread of the workgroup computes them (every thread doing so cost
+    // more than the 8 elements it then updates: a workgroup moves 57 KB and spent its time in the fp64 library code)
+    __shared__ float bias_corr[2];
+    if (threadIdx.x == 0) {
+        const double step = (double)a.step[t][0] + 1.0;  // the counters are advanced after all update kernels (adam_step_kernel)
+        const double bc1 = 1.0 - pow(beta1_d, step), bc2 = 1.0 - pow(beta2_d, step);
+        bias_corr[0] = (float)(lr_d / bc1);
+        bias_corr[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = bias_corr[0], bc2_sqrt = bias_corr[1];
     const float beta2 = (float)beta2_d, omb1 = (float)(1.0 - beta1_d), omb2 = (float)(1.0 - beta2_d), eps = (float)eps_d, wd = (float)wd_d;
     float *__restrict__ p = a.p[t];
     const float *__restrict__ g = a.g[t];
