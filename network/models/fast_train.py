@@ -84,6 +84,7 @@ class FastTrain:
         import os
         self.use_fused_stacks = os.environ.get("HOTRACK_FUSED_STACKS", "1") != "0"  # 0: round-2 path (library GEMMs + streaming BN)
         self.defer_wgrad = os.environ.get("HOTRACK_DEFER_WGRAD", "1") != "0"  # 0: every weight gradient a library GEMM inside the pass
+        self.small_stack_rows = int(os.environ.get("HOTRACK_SMALL_STACK_ROWS", "4096"))  # stacks with at most this many rows: unfused layers
 
     @staticmethod
     def supported(net) -> bool:
@@ -104,7 +105,11 @@ class FastTrain:
         (hotrack_amd.train_stack: normalise + ReLU on load, statistics in the epilogue, dY on load in the backward) when
         their widths are covered; otherwise as library GEMM + streaming BatchNorm kernels (hotrack_amd.train_ops)."""
         from hotrack_amd.train_ops import bn_relu, bn_relu_max
-        if self.use_fused_stacks and len(convs) > 1:
+        # few rows (the group-all sa3 and the two coarse feature-propagation stacks: 4096 - 8192 rows at 32 clouds): a fused layer
+        # is a latency chain of 32 - 64 workgroups per launch, and since the weight gradients of plain linears left the pass
+        # (linear_dw) the unfused form has only the small input-gradient GEMM on the critical path
+        small = self.defer_wgrad and x2d.shape[0] <= self.small_stack_rows
+        if self.use_fused_stacks and len(convs) > 1 and not small:
             from hotrack_amd import train_stack
             widths = [c.weight.shape[0] for c in convs]
             if train_stack.stack_supported(widths[0], widths[1:]):
