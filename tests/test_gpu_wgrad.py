@@ -224,3 +224,40 @@ def test_deferred_weight_gradients_are_run_to_run_bit_equal_and_graph_capturable
     torch.cuda.synchronize()
     for u, v in zip(a, grads):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("mode", ["defer", "no_defer"])
+def test_linear_blocks_equals_linear_of_the_concatenation(mode):
+    """linear_dw.linear_blocks -- layer 1 over [skip | interpolated | per-cloud feature broadcast over the cloud's points] as the sum
+    of its column blocks' products (reference pointnet_utils.py:437-438, 451-453: repeat + cat + Conv1d) -- against
+    torch.nn.functional.linear of the materialised concatenation: values, every input gradient (the broadcast block's summed over
+    the rows it covers), the weight gradient written block by block with a column offset."""
+    import torch.nn.functional as F
+    from hotrack_amd import train_stack as ts
+    from hotrack_amd.linear_dw import linear_blocks
+    dev = torch.device("cuda")
+    torch.manual_seed(2)
+    B, n, ka, kb, kc, N = 6, 50, 3, 40, 24, 72
+    xa = torch.randn(B * n, ka, device=dev)                       # e.g. coordinates: no gradient
+    xb = torch.randn(B * n, kb, device=dev, requires_grad=True)
+    xc = torch.randn(B, kc, device=dev, requires_grad=True)       # one row per cloud
+    conv = torch.nn.Conv1d(ka + kb + kc, N, 1).to(dev)
+    go = torch.randn(B * n, N, device=dev)
+    full = torch.cat([xa, xb, xc.repeat_interleave(n, dim=0)], dim=1)
+    y0 = F.linear(full, conv.weight.squeeze(-1))
+    (y0 * go).sum().backward()
+    ref = (y0.detach(), xb.grad.clone(), xc.grad.clone(), conv.weight.grad.clone())
+    xb.grad = xc.grad = conv.weight.grad = None
+    old = ts.DEFER_REDUCE
+    try:
+        if mode == "no_defer":
+            ts.DEFER_REDUCE = False
+        y1 = linear_blocks([xa, xb, (xc, n)], conv.weight)
+        (y1 * go).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        ts.DEFER_REDUCE = old
+    assert not ts._pending
+    for got, want in zip((y1.detach(), xb.grad, xc.grad, conv.weight.grad), ref):
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= 3e-5 * float(want.abs().max()) + 1e-6
