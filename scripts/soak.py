@@ -1,6 +1,7 @@
 """Soak test (not part of pytest): minutes of randomised launches looking for rare failures -- races in the SA kernel's
 two-role pipeline, the optimiser's last-workgroup protocol, the two-level FPS shortcut and its co-launches (k-NN inside the sampling launch,
-tie check inside the ball-query launch), the one-launch three-NN + interpolation.  usage: python scripts/soak.py [seconds] [seed]"""
+tie check inside the ball-query launch), the one-launch three-NN + interpolation, the grouped weight-gradient launch (stream-K shares over
+random problem lists: csrc/train_wgrad.hip).  usage: python scripts/soak.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -18,7 +19,7 @@ t_end = time.time() + budget
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 g = torch.Generator().manual_seed(seed + 1)
-n_sa = n_opt = n_fps = 0
+n_sa = n_opt = n_fps = n_wg = 0
 vol = torch.from_numpy(make_volume(81, 0.005, "capsule", np.float16)).cuda()
 cvol = sdf.CornerVolume(vol)
 while time.time() < t_end:
@@ -92,5 +93,37 @@ while time.time() < t_end:
         ext.three_interpolate_pm(pts, i3_, w3_, ob)
         assert torch.equal(oa, ob), ("three_nn_interpolate_pm", Bq, nn, mm, Cc)
         n_fps += 1
+    # ---- grouped weight gradients: random problem lists (sizes, row strides, column-block outputs), twice (bit-equal), vs fp64 ----
+    if n_sa % 3 == 0:
+        from hotrack_amd import train_stack as ts
+        probs = []
+        for _ in range(int(rng.integers(1, 12))):
+            r = int(rng.choice([1, 7, 33, 672, 1000, 4096, 9000, 20000]))
+            nn_, kk_ = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+            pg, px_, pw = int(rng.integers(0, 9)), int(rng.integers(0, 9)), int(rng.integers(0, 9))
+            gw = torch.randn(r, nn_ + pg, generator=g).cuda()
+            xw = torch.randn(r, kk_ + px_, generator=g).cuda()
+            full = torch.full((nn_, kk_ + pw), 7.0, device="cuda")
+            c0 = int(rng.integers(0, pw + 1))
+            probs.append((gw[:, pg // 2:pg // 2 + nn_], xw[:, px_ // 2:px_ // 2 + kk_], full, c0, kk_))
+        st_ = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for rep in range(2):
+            for (gv, xv, full, c0, kk_) in probs:
+                full.fill_(7.0)
+            ts.wgrad_multi([ts.WgradItem(gv, xv, full, full.data_ptr() + 4 * c0, full.stride(0), gv.shape[1], kk_, st_)
+                            for (gv, xv, full, c0, kk_) in probs])
+            outs.append([full.clone() for (_, _, full, _, _) in probs])
+        for (gv, xv, full, c0, kk_), a_, b_ in zip(probs, outs[0], outs[1]):
+            assert torch.equal(a_, b_), "wgrad_multi not deterministic"
+            ref64 = gv.double().t() @ xv.double()
+            got = a_[:, c0:c0 + kk_].double()
+            tol = 1e-5 * float(ref64.abs().max()) * max(1.0, (gv.shape[0] / 1000.0) ** 0.5) + 1e-6
+            assert float((got - ref64).abs().max()) <= tol, ("wgrad_multi", tuple(gv.shape), tuple(xv.shape), c0)
+            keep = torch.ones_like(a_, dtype=torch.bool)
+            keep[:, c0:c0 + kk_] = False
+            assert bool((a_[keep] == 7.0).all()), "wgrad_multi wrote outside its column block"
+        n_wg += 1
 torch.cuda.synchronize()
-print(f"soak ok: {n_sa} SA launches x2, {n_opt} optimiser pairs, {n_fps} two-level FPS cases in {budget:.0f} s")
+print(f"soak ok: {n_wg} grouped weight-gradient lists x2,", end=" ")
+print(f" {n_sa} SA launches x2, {n_opt} optimiser pairs, {n_fps} two-level FPS cases in {budget:.0f} s")
