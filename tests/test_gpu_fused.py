@@ -573,3 +573,33 @@ def test_fast_path_nan_contract():
             assert model._fast.finite_weights and torch.equal(again, good)
     finally:
         pointnet_utils.set_fused_backend(None)
+
+
+@pytest.mark.parametrize("rows,n,relu,bias", [(65536, 384, True, True), (16, 384, True, True), (1, 128, False, False), (1000, 256, True, True),
+                                              (4099, 384, False, True), (33, 384, True, False)])
+def test_linear_k128_matches_torch(rows, n, relu, bias):
+    """pn2x_linear_k128 (both MFMA operands in registers, no LDS; the backbone's conv1 + bn1 layer, reference backbones.py:131-133)
+    against torch.nn.functional.linear in fp64: ragged row counts (blocks of 16, workgroups that own an odd number of blocks), a
+    padded input row stride and an output written into a column block of a wider buffer; nothing outside the block is touched."""
+    import ctypes
+    from hotrack_amd import ext
+    lib = ext._lib
+    g = torch.Generator(device="cuda").manual_seed(rows + n)
+    xw = torch.randn(rows, 132, device="cuda", generator=g)
+    x = xw[:, :128]
+    w = torch.randn(n, 128, device="cuda", generator=g) * 0.2
+    b = torch.randn(n, device="cuda", generator=g) if bias else None
+    out = torch.full((rows + 3, n + 8), 9.0, device="cuda")
+    y = out[:rows, 4:4 + n]
+    rc = lib.pn2x_linear_k128(rows, n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), None if b is None else b.data_ptr(), 1 if relu else 0,
+                              y.data_ptr(), y.stride(0), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.linear(x.double(), w.double(), None if b is None else b.double())
+    if relu:
+        ref = torch.relu(ref)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    keep = torch.ones_like(out, dtype=torch.bool)
+    keep[:rows, 4:4 + n] = False
+    assert bool((out[keep] == 9.0).all())
+    assert lib.pn2x_linear_k128_supported(128, 192) == 0 and lib.pn2x_linear_k128_supported(64, 384) == 0
