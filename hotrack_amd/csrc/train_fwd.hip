@@ -66,7 +66,7 @@ __device__ __forceinline__ void tgf_body(const FwdArgs &a, const int wg, const i
     // tile operands: a wave fetches 8 rows x 8 float4 (128 contiguous bytes per row) per step; the first 8 waves (all of
     // them where there are fewer) cover the tile's eight 8-row groups
     const int arow = lane >> 3, aq = lane & 7;
-    const bool loader = wave < 8;
+    const bool loader = P::WAVES <= 8 ? true : wave < 8;  // (a compile-time `true` where every wave loads: no branch around the prefetch)
     float4 px[P::GROUPS * KB];
     auto prefetch = [&](long tile) {
         if (!loader) return;
@@ -148,11 +148,23 @@ __device__ __forceinline__ void tgf_body(const FwdArgs &a, const int wg, const i
     const float *ap = Hs + (rblk * 32 + l31) * LDK + kh;
     const float *bp = Ws + (nb * 32 + l31) * LDK + kh;
     float cs = 0.f, cq = 0.f;
-    while (tile < tiles) {
+    // the outputs leave through a buffer descriptor over the rows of the problem: rows beyond R are dropped by the hardware, every
+    // tile issues the same sixteen stores -- no full / ragged branch (see the note on s_waitcnt at the tile step below)
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    const size_t ybytes = ((size_t)(a.R - 1) * a.ldy + (size_t)a.N) * 4;
+    const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ybytes > 0x7ffffff0u ? 0x7ffffff0 : (int)ybytes, 0x00020000);
+    const unsigned yrow = (unsigned)__builtin_amdgcn_readfirstlane(4 * a.ldy);
+    // One tile.  hipcc's s_waitcnt insertion merges the memory operations in flight over every path into a block: with a loop whose
+    // first trip arrives with only the prefetched operands outstanding and whose later trips arrive with [operands, then 16 output
+    // stores], it waited at the top of EVERY trip until all but one operation had completed -- i.e. for the previous tile's stores
+    // to be acknowledged, with the matrix pipe idle.  Hence: no conditional loads or stores inside the step (the prefetch of a tile
+    // beyond the last re-reads the last row, the stores are bounds-checked), and the first tile is peeled off the loop, so that both
+    // ways into the loop carry the same operations in the same order and the wait in front of the commit counts the stores out.
+    auto step = [&](long tile) __attribute__((always_inline)) -> long {
         commit(tile);
         __syncthreads();
         const long ntile = tile + nwg;
-        if (ntile < tiles) prefetch(ntile);  // nothing else of this tile reads global memory
+        prefetch(ntile);  // nothing else of this tile reads global memory (rows are clamped to the problem's last one)
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -184,18 +196,13 @@ __device__ __forceinline__ void tgf_body(const FwdArgs &a, const int wg, const i
         }
         __syncthreads();  // every wave is done with Hs: the next commit may overwrite it while the stores below drain
         {
-            const long row0 = tile * BM + rblk * 32 + 4 * kh;
-            float *dst = a.Y + n0 + nb * 32 + l31;
-            if (tile * BM + BM <= a.R) {
+            const unsigned row0 = (unsigned)(tile * BM + rblk * 32 + 4 * kh);  // (rows < 2^31 / ldy: launcher)
+            const unsigned base = row0 * yrow + 4u * (unsigned)(n0 + nb * 32 + l31);
+            typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+            const u32x16 bits = __builtin_bit_cast(u32x16, acc);  // (whole-vector cast: a cast of a vector ELEMENT reads element 0)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[(row0 + (r & 3) + 8 * (r >> 2)) * a.ldy] = acc[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = row0 + (r & 3) + 8 * (r >> 2);
-                    if (row < a.R) dst[row * a.ldy] = acc[r];
-                }
-            }
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(bits[r], ry, (int)(base + (unsigned)((r & 3) + 8 * (r >> 2)) * yrow), 0, 0);
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {  // rows beyond R are exact zeros
@@ -205,7 +212,11 @@ __device__ __forceinline__ void tgf_body(const FwdArgs &a, const int wg, const i
             cs += s;
             cq += q;
         }
-        tile = ntile;
+        return ntile;
+    };
+    if (tile < tiles) {
+        tile = step(tile);
+        while (tile < tiles) tile = step(tile);
     }
     if (a.sums_out) {
         const float s = cs + __shfl_xor(cs, 32), q = cq + __shfl_xor(cq, 32);  // lanes l and l ^ 32 hold the same column
