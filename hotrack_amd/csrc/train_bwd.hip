@@ -284,7 +284,7 @@ __device__ __forceinline__ void tg_bwd_body(const BwdArgs &a, const int wg, cons
         TGB_T(t2);
         const long ntile = tile + nwg;
         if constexpr (P::WLDS) {  // nothing else of this tile touches global memory before the epilogue's stores
-            if (ntile < T) prefetch(ntile);
+            prefetch(ntile);
         }
         {
             f32x16 acc;
@@ -322,7 +322,7 @@ __device__ __forceinline__ void tg_bwd_body(const BwdArgs &a, const int wg, cons
         // own global loads would otherwise queue behind these in the in-order load counter)
         TGB_T(t3);
         if constexpr (!P::WLDS) {
-            if (ntile < T) prefetch(ntile);
+            prefetch(ntile);
         }
         {
             const float *xp = Xs + (kh + 2 * ksw * steps_w) * LDX + nbw * 32 + l31;
@@ -693,7 +693,7 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
         __syncthreads();
         TGB_T(t2);
         const long ntile = tile + nwg;
-        if (ntile < T) prefetch(ntile);  // nothing else of this tile reads global memory before the epilogue
+        prefetch(ntile);  // (unconditional: rows clamp to the last one) nothing else of this tile reads global memory before the epilogue
         {
             // data gradient: acc[t] (16 x 16: row 4 g4 + r, column li) of row tile rt0 + t; instruction (q, j) multiplies
             // dY[.][16 q + 4 g4 + j] by W_i[16 q + 4 g4 + j][.]: every k once, in the order the fragments are laid out
@@ -736,7 +736,7 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
                 for (int r = 0; r < 4; ++r) gs[(t * 16 + r) * LDX] = acc[t][r];
         }
         TGB_T(t3);
-        if (ntile < T) prefetch_p(ntile);
+        prefetch_p(ntile);
         {
             const float *xp = Xs + (kh + 2 * ksw * steps_w) * LDX + nbw * 32 + l31;
             const float *ap = dYs + (kh + 2 * ksw * steps_w) * LDY + kb0 * 32 + l31;
@@ -752,7 +752,7 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
         }
         TGB_T(t4);
         if constexpr (kEarlyG) {
-            if (ntile < T) fetch_g(ntile, 0);
+            fetch_g(ntile, 0);
         }
         __syncthreads();
         TGB_T(t5);
@@ -790,14 +790,21 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
     }
     TGB_T(t_loop);
 
+    // (the indices of the code below are re-derived from an opaque copy of the thread index: left to itself hipcc forms the
+    // output addresses BEFORE the tile loop and spills them across it on the 128 -> 192 kernel)
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6, l31_e = lane_e & 31, kh_e = lane_e >> 5;
+    const int wb0_e = P::WBLK >= 8 ? wave_e * P::WB : wave_e % P::WBLK, ksw_e = P::WBLK >= 8 ? 0 : wave_e / P::WBLK;
+    const int nbw_e = wb0_e / KB, kb0_e = wb0_e % KB, cq_e = tid_e % P::QN, rg_e = tid_e / P::QN;
     {  // weight-gradient partial tile of this workgroup (and row slice)
-        float *out = a.partial + ((size_t)wg * P::KS_W + ksw) * (size_t)(Kd * N);
+        float *out = a.partial + ((size_t)wg * P::KS_W + ksw_e) * (size_t)(Kd * N);
 #pragma unroll
         for (int j = 0; j < P::WB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kd = (kb0 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                out[(size_t)kd * N + nbw * 32 + l31] = accw[j][r];
+                const int kd = (kb0_e + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh_e;
+                out[(size_t)kd * N + nbw_e * 32 + l31_e] = accw[j][r];
             }
     }
     if (a.raw_out) return;  // (workgroup-uniform)
@@ -805,19 +812,19 @@ __device__ __forceinline__ void tg_bwd2_body(const BwdArgs &a, const int wg, con
     float *redS = Gs, *redQ = Gs + P::RG * N;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        redS[rg * N + 4 * cq + e] = cs[e];
-        redQ[rg * N + 4 * cq + e] = cqs[e];
+        redS[rg_e * N + 4 * cq_e + e] = cs[e];
+        redQ[rg_e * N + 4 * cq_e + e] = cqs[e];
     }
     __syncthreads();
-    if (tid < N) {
+    if (tid_e < N) {
         double s = 0.0, q = 0.0;
         for (int r = 0; r < P::RG; ++r) {
-            s += (double)redS[r * N + tid];
-            q += (double)redQ[r * N + tid];
+            s += (double)redS[r * N + tid_e];
+            q += (double)redQ[r * N + tid_e];
         }
         double *dst = a.sums_bwd_p + (size_t)(wg % kBnRep) * 2 * N;
-        unsafeAtomicAdd(dst + tid, s);
-        unsafeAtomicAdd(dst + N + tid, q);
+        unsafeAtomicAdd(dst + tid_e, s);
+        unsafeAtomicAdd(dst + N + tid_e, q);
     }
 #ifdef PN2_TGB_PROFILE
     if (lane == 0 && a.prof) {
