@@ -14,6 +14,7 @@
 //     iteration (double-buffered by iteration parity; the reference needs 11);
 //   * all waves redundantly combine the <=16 wave candidates with DPP inside one row and
 //     pull the winner's coordinates into SGPRs with v_readlane.
+#include <stdlib.h>
 #include "pn2_common.h"
 #include "knn_wave.h"
 #include "fps_tie.h"
@@ -216,7 +217,7 @@ fps_knn_kernel(int b, int n, int m, int bs, int lg, int Q, const float *__restri
     knn_wave_body<KP>(cloud, q, nq, n, k, query_all, xyz_all, nullptr, kidx_all, k2, kidx2_all);
 }
 
-// Large-cloud fallback (n > 16384): running distances in the caller's `temp` (HBM), the
+// Large-cloud fallback (n > 65536): running distances in the caller's `temp` (HBM), the
 // reference's thread structure (bs = 1024 threads, strided ownership) with the tie key
 // carried explicitly through a 64-bit LDS tree.  Correct for any n; not tuned.
 __global__ void __launch_bounds__(1024)
@@ -258,6 +259,63 @@ fps_large_kernel(int n, int m, const float *__restrict__ xyz_all, float *__restr
         old = (int)(((wlo & 0x1FFFFFu) << 10) | wt);
         if (tid == 0) idx[it] = old;
         __syncthreads();
+    }
+}
+
+// Clouds of 16385 .. 65536 points: one workgroup of 1024 threads per cloud, thread t owns the points t + 1024 q like the
+// reference (sampling_gpu.cu:143-167), their RUNNING DISTANCES live in QMAX registers per lane for the whole kernel and only the
+// coordinates are re-read every pick (786 KB per cloud at most: L2-resident, coalesced 12-byte records through a buffer
+// descriptor whose bounds check returns zeros for the slots beyond n) -- no `temp` traffic at all, against 1 MB read + 256 KB
+// written per pick by fps_large_kernel below.  The arg-max follows the reference's tie order without a tree: wave maximum of the
+// distance bits (6 DPP steps), then the smallest (bitrev10(thread), q) among the lanes that hold it (6 more), one LDS entry per
+// wave, ONE barrier per pick (entries double-buffered by parity), every wave combines the 16 entries on its own.
+template <int QMAX>
+__global__ void __launch_bounds__(1024)
+fps_stream_kernel(int n, int m, const float *__restrict__ xyz_all, int *__restrict__ idx_all) {
+    __shared__ unsigned ent[2][2][16];  // [parity][distance bits | tie key][wave]
+    const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    int *__restrict__ idx = idx_all + (size_t)blockIdx.x * m;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned trank = __builtin_bitreverse32((unsigned)tid) >> 22;  // rank of this thread in the reference's tree: smaller wins ties
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xyz), 0, 12 * n, 0x00020000);
+    float pt[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) pt[q] = tid + 1024 * q < n ? 1e10f : -1.0f;  // slots beyond n can never win (real distances >= 0)
+    float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+    if (tid == 0) idx[0] = 0;
+    typedef float f32x3v __attribute__((ext_vector_type(3)));
+    for (int it = 1; it < m; ++it) {
+        float best = -1.0f;
+        int bestq = 0;
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            // (whole-vector cast: a bit cast of a vector ELEMENT reads element 0 with this hipcc)
+            const f32x3v p = __builtin_bit_cast(f32x3v, __builtin_amdgcn_raw_buffer_load_b96(rx, 12 * tid + 12 * 1024 * q, 0, 0));
+            const float d = sqdist(p.x, p.y, p.z, cx, cy, cz);
+            const float tt = fmin_raw(d, pt[q]);
+            pt[q] = tt;
+            const bool gt = tt > best;  // strict: the first maximum in increasing k wins inside a thread
+            bestq = gt ? q : bestq;
+            best = gt ? tt : best;
+        }
+        const int bi = f2i(best);  // fp32 >= 0 (or exactly -1.0f) orders like its bit pattern as a signed int
+        const int wmax = wave_max_i32(bi);
+        const unsigned wkey = wave_min_u32(bi == wmax ? ((trank << 21) | (unsigned)bestq) : 0xffffffffu);
+        if (lane == 0) {
+            ent[it & 1][0][w] = (unsigned)wmax;
+            ent[it & 1][1][w] = wkey;
+        }
+        __syncthreads();
+        const int ev = (int)ent[it & 1][0][lane & 15];
+        const unsigned ek = ent[it & 1][1][lane & 15];
+        const int gmax = __builtin_amdgcn_readfirstlane(row_group_max_i32<16>(ev));
+        const unsigned gkey = (unsigned)__builtin_amdgcn_readfirstlane((int)row_group_min_u32<16>(ev == gmax ? ek : 0xffffffffu));
+        const unsigned wt = __builtin_bitreverse32(gkey >> 21) >> 22;
+        const int old = (int)(((gkey & 0x1FFFFFu) << 10) | wt);
+        if (tid == 0) idx[it] = old;
+        cx = xyz[3 * old];
+        cy = xyz[3 * old + 1];
+        cz = xyz[3 * old + 2];
     }
 }
 
@@ -312,6 +370,12 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
     const int slots = bs * Q;
     if (slots > 1024 * 16) {
         if (skip_flags || radii) return PN2_ERANGE;  // the shortcut covers the register-resident kernels only
+        static const bool no_stream = getenv("PN2_FPS_NO_STREAM") != nullptr;  // (A/B against the HBM-temp kernel: tests, probes)
+        if (Q <= 64 && !no_stream) {  // running distances in registers, coordinates streamed from L2: no scratch buffer
+            if (Q <= 32) hipLaunchKernelGGL(fps_stream_kernel<32>, dim3(b), dim3(1024), 0, st, n, m, xyz, idx);
+            else hipLaunchKernelGGL(fps_stream_kernel<64>, dim3(b), dim3(1024), 0, st, n, m, xyz, idx);
+            return check_launch();
+        }
         if (!temp) return PN2_ESCRATCH;
         hipLaunchKernelGGL(fps_large_kernel, dim3(b), dim3(1024), 0, st, n, m, xyz, temp, idx);
         return check_launch();

@@ -357,6 +357,7 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
     // ---- COMPUTE role: weights -> registers (B operand: lane holds W[out = tile*16 + li][in = 16*tq + 4*g + j])
     float w2r[NT2][C1 / 4], w3r[NT3][C2 / 4];
     float bias2[NT2], bias3[NT3];
+    f32x4 bias3v[ROWS ? NT3 : 1];  // rows mode: layer 3 runs with the operands swapped (see below), a lane owns 4 consecutive channels
     float w2e[NT2][3] = {{0.f}};
     if (compute) {
         if constexpr (ROWS_EXTRA) {
@@ -379,6 +380,10 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
         for (int ct = 0; ct < NT3; ++ct) {
             const int oc = (wc * NT3 + ct) * 16 + li;
             bias3[ct] = b3[oc];
+            if constexpr (ROWS) {
+                const float *bp = b3 + (wc * NT3 + ct) * 16 + 4 * g;
+                bias3v[ct] = (f32x4){bp[0], bp[1], bp[2], bp[3]};
+            }
 #pragma unroll
             for (int tq = 0; tq < C2 / 16; ++tq) {
                 const float4 v = *reinterpret_cast<const float4 *>(W3 + (size_t)oc * C2 + 16 * tq + 4 * g);
@@ -614,7 +619,7 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
 #pragma unroll
                 for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < NT3; ++ct) acc[rt][ct] = (f32x4){bias3[ct], bias3[ct], bias3[ct], bias3[ct]};
+                    for (int ct = 0; ct < NT3; ++ct) acc[rt][ct] = ROWS ? bias3v[ct] : (f32x4){bias3[ct], bias3[ct], bias3[ct], bias3[ct]};
 #pragma unroll
                 for (int tq = 0; tq < NQ3; ++tq) {
                     float4 a[RTC];
@@ -634,21 +639,29 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
                         for (int rt = 0; rt < RTC; ++rt) {
                             const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
 #pragma unroll
-                            for (int ct = 0; ct < NT3; ++ct)
-                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w3r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
+                            for (int ct = 0; ct < NT3; ++ct) {
+                                // rows mode: the two operands trade places (their register layouts are the same: lane (li, g)
+                                // holds element [li][k = g]), so the product comes out transposed -- D[channel 4 g + r][row li]:
+                                // a lane owns FOUR CONSECUTIVE CHANNELS of one row, and the tile leaves as 16-byte stores
+                                if constexpr (ROWS) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3r[ct][4 * tq + j], av, acc[rt][ct], 0, 0, 0);
+                                else acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w3r[ct][4 * tq + j], acc[rt][ct], 0, 0, 0);
+                            }
                         }
                 }
-                if constexpr (ROWS) {  // relu -> out rows (D tile: row = g*4 + r, col = li); rows past the end are dropped by the bounds check
+                if constexpr (ROWS) {  // relu -> out rows; rows past the end are dropped by the bounds check.  One store instruction
+                    // per 16 x 16 block instead of four: next to the matrix stream a vector-memory instruction costs the wave
+                    // 100+ cycles whatever its width (see the LOAD role), and a 64-row tile of 128 channels was 32 of them per wave
 #pragma unroll
                     for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
-                        for (int ct = 0; ct < NT3; ++ct)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = cc.t * TM + wp * 64 + (p * RTC + rt) * 16 + g * 4 + r;
-                                const unsigned off = 4u * ((unsigned)row * (unsigned)A.out_s + (unsigned)((wc * NT3 + ct) * 16 + li));
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc[rt][ct][r], 0.f)), ro_rows, (int)off, 0, 0);
-                            }
+                        for (int ct = 0; ct < NT3; ++ct) {
+                            const int row = cc.t * TM + wp * 64 + (p * RTC + rt) * 16 + li;
+                            const unsigned off = 4u * ((unsigned)row * (unsigned)A.out_s + (unsigned)((wc * NT3 + ct) * 16 + 4 * g));
+                            f32x4 v = acc[rt][ct];
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro_rows, (int)off, 0, 0);
+                        }
                 } else {
 #pragma unroll
                     for (int rt = 0; rt < RTC; ++rt)
@@ -894,11 +907,11 @@ extern "C" int pn2x_mlp2_rows_supported(int c1, int c2, int c3) { return (c1 == 
 extern "C" int pn2x_mlp2_rows(long rows, int c1, int c2, int c3, const float *x, int ldx, const float *w2, const float *w2e, const float *b2,
                               const float *w3, const float *b3, float *out, int ldo, void *stream) {
     using namespace pn2;
-    if (rows < 0 || ldx < c1 + (w2e ? 4 : 0) || ldo < c3 || ldx % 4 || ldo < 1) return PN2_EINVAL;
+    if (rows < 0 || ldx < c1 + (w2e ? 4 : 0) || ldo < c3 || ldx % 4 || ldo % 4) return PN2_EINVAL;  // (16-byte row segments in and out)
     if (rows == 0) return PN2_OK;
     if (!x || !w2 || !b2 || !w3 || !b3 || !out) return PN2_ENULL;
     if (!pn2x_mlp2_rows_supported(c1, c2, c3)) return PN2_ERANGE;
-    if (((uintptr_t)x | (uintptr_t)w2 | (uintptr_t)w3) % 16 != 0) return PN2_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)w2 | (uintptr_t)w3 | (uintptr_t)out) % 16 != 0) return PN2_EINVAL;
     if (rows >= (1L << 24) - 64 || 4L * ldx >= (1L << 24) || 4L * rows * ldx > 0xffffffffL || 4L * rows * ldo > 0xffffffffL) return PN2_ERANGE;
     SaArgs a;
     a.B = 1; a.N = (int)rows; a.K = 16; a.S = (int)((rows + 15) / 16); a.lgK = 4;

@@ -42,7 +42,10 @@ class FurthestPointSampling(Function):
         B, N, _ = xyz.shape
         npoint = int(npoint)
         output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-        pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, None, output)
+        # (running distances are register-resident up to 65536 points per cloud; beyond that the kernel keeps them in the
+        # reference's HBM scratch, pre-filled with 1e10 as at reference :28)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device) if N > 65536 else None
+        pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
         ctx.mark_non_differentiable(output)
         return output
 

@@ -263,6 +263,7 @@ typedef struct pn2x_sa_problem {
  * pn2x_sa_mlp_max without neighbourhoods, both weight matrices register-resident, the intermediate activation never
  * written to HBM.  w2 (c2, c1), w3 (c3, c2) row-major, 16-byte aligned.  w2e (c2, 3) or NULL: weights of three more input
  * columns stored right behind the c1 features (the coordinates of an [interpolated | xyz] row; needs ldx >= c1 + 4).
+ * x and out 16-byte aligned, ldx and ldo multiples of 4 floats (rows are read and written in 16-byte segments), else PN2_EINVAL.
  * PN2_ERANGE unless pn2x_mlp2_rows_supported(c1, c2, c3).
  */
 /*

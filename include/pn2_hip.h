@@ -54,7 +54,8 @@ int pn2_last_hip_error(void);
  * -- the reference's shared-memory tree reduction order (sampling_gpu.cu:86-91,143-203).
  * `temp` (b,n) is the reference's HBM scratch (pre-filled 1e10 by the caller,
  * pointnet2_utils.py:28).  On CDNA4 the running distances live in registers, so temp may be
- * NULL and is neither read nor written for n <= 16384; larger clouds need it
+ * NULL and is neither read nor written for n <= 65536 (up to 16384 points the coordinates are
+ * register-resident too; from there to 65536 they are re-read from L2 every pick); larger clouds need it
  * (PN2_ESCRATCH otherwise) and it must then be pre-filled with 1e10 as in the reference.
  */
 int pn2_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,

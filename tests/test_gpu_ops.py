@@ -85,16 +85,35 @@ def test_fps_thread_configs_agree(ops, oracle, threads, monkeypatch):
         np.testing.assert_array_equal(got.cpu().numpy(), ref)
 
 
+# 16385 .. 65536 points: running distances in registers, coordinates streamed (fps_stream_kernel); beyond: the HBM-temp kernel
+FPS_STREAM_CASES = [(2, 16385, 200, "uniform"), (1, 20000, 300, "lattice"), (2, 32768, 128, "uniform"), (1, 32769, 64, "dup"),
+                    (1, 65536, 96, "uniform"), (2, 50000, 150, "hand"), (1, 40000, 40, "same"), (1, 65535, 50, "line")]
+
+
+@pytest.mark.parametrize("B,N,M,kind", FPS_STREAM_CASES)
+def test_fps_streamed_clouds_index_exact(ops, oracle, B, N, M, kind, monkeypatch):
+    from hotrack_amd import pointnet2_hip as native
+    xyz = _large_cloud(B * 31 + N, B, N, kind)
+    ref = oracle.furthest_point_sample(xyz, M)
+    out = torch.empty((B, M), dtype=torch.int32, device="cuda")
+    native.furthest_point_sampling_wrapper(B, N, M, dev(xyz), None, out)  # no scratch buffer needed
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    np.testing.assert_array_equal(ops.furthest_point_sample(dev(xyz), M).cpu().numpy(), ref)
+
+
 def test_fps_large_needs_temp(oracle):
     from hotrack_amd import pointnet2_hip as native
-    B, N, M = 1, 20000, 32
+    B, N, M = 1, 70000, 24
     xyz = cloud(5, B, N, "uniform")
     out = torch.empty((B, M), dtype=torch.int32, device="cuda")
     with pytest.raises(native.Pn2Error):
         native.furthest_point_sampling_wrapper(B, N, M, dev(xyz), None, out)
     temp = torch.full((B, N), 1e10, dtype=torch.float32, device="cuda")
     native.furthest_point_sampling_wrapper(B, N, M, dev(xyz), temp, out)
-    np.testing.assert_array_equal(out.cpu().numpy(), oracle.furthest_point_sample(xyz, M))
+    ref = oracle.furthest_point_sample(xyz, M)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    from hotrack_amd import pointnet2_utils
+    np.testing.assert_array_equal(pointnet2_utils.furthest_point_sample(dev(xyz), M).cpu().numpy(), ref)  # the op brings its own scratch
 
 
 BALL_CASES = [
