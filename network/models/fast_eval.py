@@ -228,6 +228,23 @@ class FastEval:
             return self._forward(input, flag_dict)
 
     def _forward(self, input, flag_dict):
+        G = self._geometry(input, flag_dict)
+        return None if G is None else self._dense(G, flag_dict)
+
+    # The forward in two halves, for callers that launch them on different streams (bench.py --split-geometry: the sampling /
+    # search prefix -- one workgroup per cloud, latency chains -- as its own graph on a high-priority stream, the dense rest on
+    # the normal one).  forward_dense(forward_geometry(x)) == forward(x).
+    def forward_geometry(self, input, flag_dict):
+        from hotrack_amd import gemm_tuning
+        with gemm_tuning.scope(tune=False):
+            return self._geometry(input, flag_dict)
+
+    def forward_dense(self, G, flag_dict):
+        from hotrack_amd import gemm_tuning
+        with gemm_tuning.scope(tune=False):
+            return self._dense(G, flag_dict)
+
+    def _geometry(self, input, flag_dict):
         from hotrack_amd import ext
         from hotrack_amd import pointnet2_utils as ops
         net = self.net
@@ -281,6 +298,19 @@ class FastEval:
             l1_xyz = ext.gather_rows(xyz2, ops.furthest_point_sample(xyz2, S1))
             i_l2 = ops.furthest_point_sample(l1_xyz, bh.sa2.npoint)
             idx1 = ops.ball_query(bh.sa1.radius_list[0], K1, xyz2, l1_xyz)
+        return dict(P=P, pts=pts, B=B, N=N, J=J, c_i=c_i, fp1_in=fp1_in, nonfinite=nonfinite, R=R, t=t, xyz2=xyz2, xyz1=xyz1,
+                    canon=canon, S1=S1, K1=K1, l1_xyz=l1_xyz, i_l2=i_l2, idx1=idx1, knn_lists=knn_lists)
+
+    def _dense(self, G, flag_dict):
+        from hotrack_amd import ext
+        from hotrack_amd import pointnet2_utils as ops
+        net, bh = self.net, self.net.bhand
+        P, pts, B, N, J, c_i, fp1_in, nonfinite = G["P"], G["pts"], G["B"], G["N"], G["J"], G["c_i"], G["fp1_in"], G["nonfinite"]
+        R, t, xyz2, xyz1, canon, S1, K1 = G["R"], G["t"], G["xyz2"], G["xyz1"], G["canon"], G["S1"], G["K1"]
+        l1_xyz, i_l2, idx1, knn_lists = G["l1_xyz"], G["i_l2"], G["idx1"], G["knn_lists"]
+        f32 = dict(dtype=torch.float32, device=pts.device)
+        dev = net.device
+        p = P["sa1"]
         c_l1 = p["l3"][0].shape[0]
         fp2_w = P["fp2"][0][0].shape[1]
         fp2_in = torch.empty((B, S1, fp2_w), **f32)  # [l1_feat | interp(l2 -> l1)]
