@@ -356,20 +356,26 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
 
     // ---- COMPUTE role: weights -> registers (B operand: lane holds W[out = tile*16 + li][in = 16*tq + 4*g + j])
     float w2r[NT2][C1 / 4], w3r[NT3][C2 / 4];
-    float bias2[NT2], bias3[NT3];
+    f32x4 bias2v[NT2];  // layer 2 runs with the operands exchanged (see writeout2): a lane owns channels 4 g .. 4 g + 3 of a column tile
+    float bias3[NT3];
     f32x4 bias3v[ROWS ? NT3 : 1];  // rows mode: layer 3 runs with the operands swapped (see below), a lane owns 4 consecutive channels
-    float w2e[NT2][3] = {{0.f}};
+    float w2e[NT2][4][3] = {{{0.f}}};
     if (compute) {
         if constexpr (ROWS_EXTRA) {
 #pragma unroll
             for (int ct = 0; ct < NT2; ++ct)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) w2e[ct][k] = A.w2e[((wc * NT2 + ct) * 16 + li) * 3 + k];
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) w2e[ct][r][k] = A.w2e[((wc * NT2 + ct) * 16 + 4 * g + r) * 3 + k];
         }
 #pragma unroll
         for (int ct = 0; ct < NT2; ++ct) {
             const int oc = (wc * NT2 + ct) * 16 + li;
-            bias2[ct] = b2[oc];
+            {
+                const float *bp = b2 + (wc * NT2 + ct) * 16 + 4 * g;
+                bias2v[ct] = (f32x4){bp[0], bp[1], bp[2], bp[3]};
+            }
 #pragma unroll
             for (int tq = 0; tq < C1 / 16; ++tq) {
                 const float4 v = *reinterpret_cast<const float4 *>(W2 + (size_t)oc * C1 + 16 * tq + 4 * g);
@@ -538,23 +544,27 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
             // wave of this SIMD is a LOAD wave, nothing fills it), and a pass's ReLU -> H2 write-out is issued after the
             // first k-step of the NEXT pass (its own accumulator set), i.e. in the shadow of running MFMAs.
             f32x4 acc[2][RTC][NT2];
-            auto writeout2 = [&](int p) {  // relu -> H2 (D tile: row = g*4 + r, col = li)
+            // The two operands of the layer-2 instructions trade places (their register layouts are the same: lane (li, g) holds
+            // element [li][k = g]), so a 16 x 16 block comes out TRANSPOSED -- D[channel 4 g + r][row li]: a lane owns four
+            // consecutive channels of one row and the block goes to H2 as ONE ds_write_b128 per lane instead of four ds_write_b32
+            // (conflict-free: LD2 = 4 mod 32, eight lanes cover the 32 banks).  Per-phase stamps of the 32-32-64 instance
+            // (scripts/probes/sa1_trace.py): beside the other workgroup's matrix stream this write-out took 2.4 k cycles of an
+            // 8.2 k-cycle tile for 16 stores + 16 maxima -- every instruction here waits for an issue slot between two MFMAs.
+            auto writeout2 = [&](int p) {  // relu -> H2 (D tile: channel = 4 g + r, row = li)
 #pragma unroll
                 for (int rt = 0; rt < RTC; ++rt) {
-                    float4 e[4];
-                    if constexpr (ROWS_EXTRA) {  // the rows' extra input columns (wave-uniform per lane row: LDS broadcast reads)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) e[r] = *reinterpret_cast<const float4 *>(H1 + (wp * 64 + (p * RTC + rt) * 16 + g * 4 + r) * LD1 + C1);
-                    }
+                    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (ROWS_EXTRA) e = *reinterpret_cast<const float4 *>(H1 + (wp * 64 + (p * RTC + rt) * 16 + li) * LD1 + C1);  // the row's extra input columns
 #pragma unroll
                     for (int ct = 0; ct < NT2; ++ct) {
-                        float *dst = H2 + (wp * 64 + (p * RTC + rt) * 16 + g * 4) * LD2 + (wc * NT2 + ct) * 16 + li;
+                        float *dst = H2 + (wp * 64 + (p * RTC + rt) * 16 + li) * LD2 + (wc * NT2 + ct) * 16 + 4 * g;
+                        f32x4 v = acc[p & 1][rt][ct];
+                        if constexpr (ROWS_EXTRA) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = acc[p & 1][rt][ct][r];
-                            if constexpr (ROWS_EXTRA) v = __builtin_fmaf(w2e[ct][0], e[r].x, __builtin_fmaf(w2e[ct][1], e[r].y, __builtin_fmaf(w2e[ct][2], e[r].z, v)));
-                            dst[r * LD2] = fmaxf(v, 0.f);
+                            for (int r = 0; r < 4; ++r)
+                                v[r] = __builtin_fmaf(w2e[ct][r][0], e.x, __builtin_fmaf(w2e[ct][r][1], e.y, __builtin_fmaf(w2e[ct][r][2], e.z, v[r])));
                         }
+                        *reinterpret_cast<float4 *>(dst) = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                     }
                 }
             };
@@ -566,7 +576,7 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
 #pragma unroll
                 for (int rt = 0; rt < RTC; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < NT2; ++ct) acc[p & 1][rt][ct] = (f32x4){bias2[ct], bias2[ct], bias2[ct], bias2[ct]};
+                    for (int ct = 0; ct < NT2; ++ct) acc[p & 1][rt][ct] = bias2v[ct];
 #pragma unroll
                 for (int tq = 0; tq < NQ2; ++tq) {
                     float4 a[RTC];
@@ -584,7 +594,7 @@ __device__ __forceinline__ void sa_body(const SaArgs &A, const int wg, const int
                             const float av = j == 0 ? a[rt].x : j == 1 ? a[rt].y : j == 2 ? a[rt].z : a[rt].w;
 #pragma unroll
                             for (int ct = 0; ct < NT2; ++ct)
-                                acc[p & 1][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2r[ct][4 * tq + j], acc[p & 1][rt][ct], 0, 0, 0);
+                                acc[p & 1][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[ct][4 * tq + j], av, acc[p & 1][rt][ct], 0, 0, 0);
                         }
 #if SA_DEFER_EPILOGUE
                     if (!ROWS && tq == 0 && p == 0) epilogue();  // the previous tile's max-pool + store (nothing is written when there was none)
