@@ -1,7 +1,7 @@
 """Soak test (not part of pytest): minutes of randomised launches looking for rare failures -- races in the SA kernel's
 two-role pipeline, the optimiser's last-workgroup protocol, the two-level FPS shortcut and its co-launches (k-NN inside the sampling launch,
 tie check inside the ball-query launch), the one-launch three-NN + interpolation, the grouped weight-gradient launch (stream-K shares over
-random problem lists: csrc/train_wgrad.hip).  usage: python scripts/soak.py [seconds] [seed]"""
+random problem lists: csrc/train_wgrad.hip), the streamed-coordinate FPS of large clouds, the two-layer row MLP.  usage: python scripts/soak.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -19,7 +19,7 @@ t_end = time.time() + budget
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 g = torch.Generator().manual_seed(seed + 1)
-n_sa = n_opt = n_fps = n_wg = 0
+n_sa = n_opt = n_fps = n_wg = n_fs = n_m2 = 0
 vol = torch.from_numpy(make_volume(81, 0.005, "capsule", np.float16)).cuda()
 cvol = sdf.CornerVolume(vol)
 while time.time() < t_end:
@@ -124,6 +124,50 @@ while time.time() < t_end:
             keep[:, c0:c0 + kk_] = False
             assert bool((a_[keep] == 7.0).all()), "wgrad_multi wrote outside its column block"
         n_wg += 1
+    # ---- streamed-coordinate FPS (16385 .. 65536 points) against the register-resident kernel's answer on the same cloud cut to
+    # its tie-free prefix is not available: compare with the HBM-temp kernel through the C entry (scratch given) in a second
+    # process?  The switch is read once per process -- so here: twice (bit-equal) and against a torch evaluation of the picks ----
+    if n_sa % 16 == 0:
+        from hotrack_amd import pointnet2_hip as native
+        Bs, Ns, Ms = int(rng.integers(1, 4)), int(rng.integers(16385, 65537)), int(rng.integers(2, 40))
+        xs = torch.rand(Bs, Ns, 3, generator=g)
+        if rng.random() < 0.5:
+            xs[:, : Ns // 4] = torch.round(xs[:, : Ns // 4] * 8) / 8    # lattice patch: exact distance ties
+        xs = xs.cuda()
+        o1 = torch.empty(Bs, Ms, dtype=torch.int32, device="cuda")
+        o2 = torch.empty_like(o1)
+        native.furthest_point_sampling_wrapper(Bs, Ns, Ms, xs, None, o1)
+        native.furthest_point_sampling_wrapper(Bs, Ns, Ms, xs, None, o2)
+        assert torch.equal(o1, o2), "fps_stream not deterministic"
+        # every pick is an arg-max of the running distance (ties: any maximiser is acceptable here; the exact tie order is
+        # the pytest cases' business, against the oracle)
+        dmin = torch.full((Bs, Ns), 1e10, device="cuda")
+        for it in range(1, Ms):
+            c = xs[torch.arange(Bs, device="cuda"), o1[:, it - 1].long()]
+            d = xs - c[:, None]
+            dd = torch.addcmul(torch.addcmul(d[..., 1] * d[..., 1], d[..., 0], d[..., 0]), d[..., 2], d[..., 2])  # fma order of sqdist: close enough for a maximum check
+            dmin = torch.minimum(dmin, dd)
+            picked = dmin[torch.arange(Bs, device="cuda"), o1[:, it].long()]
+            assert bool((picked >= dmin.max(dim=1)[0] * (1 - 1e-6)).all()), ("fps_stream pick is not a maximiser", Bs, Ns, it)
+        n_fs += 1
+    # ---- mlp2_rows (transposed layer-3 product, 16-byte stores): random row counts / strides / column-block outputs vs fp64 ----
+    if n_sa % 8 == 0:
+        Rm = int(rng.choice([1, 5, 63, 64, 65, 1000, 4097, 70001]))
+        ldx, ldo = 128 + 4 * int(rng.integers(0, 4)), 128 + 4 * int(rng.integers(0, 4))
+        xb = torch.randn(Rm, ldx, generator=g).cuda()
+        w2m, b2m = (torch.randn(128, 128, generator=g) / 11.3).cuda(), (torch.randn(128, generator=g) * 0.1).cuda()
+        w3m, b3m = (torch.randn(128, 128, generator=g) / 11.3).cuda(), (torch.randn(128, generator=g) * 0.1).cuda()
+        w2e = torch.randn(128, 3, generator=g).cuda() if ldx >= 132 and rng.random() < 0.5 else None
+        ob = torch.full((Rm, ldo), 7.0, device="cuda")
+        ext.mlp2_rows(xb if w2e is not None else xb[:, :128], w2m, b2m, w3m, b3m, out=ob[:, :128] if ldo != 128 else ob, w2e=w2e)
+        h = xb[:, :128].double() @ w2m.double().t() + b2m.double()
+        if w2e is not None:
+            h = h + xb[:, 128:131].double() @ w2e.double().t()
+        refm = torch.relu(torch.relu(h) @ w3m.double().t() + b3m.double())
+        assert float((ob[:, :128].double() - refm).abs().max()) <= 5e-5, ("mlp2_rows", Rm, ldx, ldo)
+        assert ldo == 128 or bool((ob[:, 128:] == 7.0).all()), "mlp2_rows wrote beyond its columns"
+        n_m2 += 1
 torch.cuda.synchronize()
-print(f"soak ok: {n_wg} grouped weight-gradient lists x2,", end=" ")
+print(f"soak ok: {n_fs} streamed-FPS clouds x2, {n_m2} mlp2_rows cases,", end=" ")
+print(f"{n_wg} grouped weight-gradient lists x2,", end=" ")
 print(f" {n_sa} SA launches x2, {n_opt} optimiser pairs, {n_fps} two-level FPS cases in {budget:.0f} s")

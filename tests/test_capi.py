@@ -61,6 +61,7 @@ def test_argument_validation_without_gpu(hip_lib_path):
     assert lib.pn2x_mlp2_rows(-1, 128, 128, 128, None, 128, None, None, None, None, None, None, 128, None) == -1  # rows < 0
     assert lib.pn2x_mlp2_rows(8, 128, 128, 128, None, 126, None, None, None, None, None, None, 128, None) == -1   # ldx < c1
     assert lib.pn2x_mlp2_rows(0, 128, 128, 128, None, 128, None, None, None, None, None, None, 128, None) == 0    # no rows: no-op
+    assert lib.pn2x_mlp2_rows(8, 128, 128, 128, None, 128, None, None, None, None, None, None, 130, None) == -1   # ldo not a multiple of 4
     assert lib.pn2x_mlp2_rows(8, 128, 128, 128, None, 128, None, None, None, None, None, None, 128, None) == -2   # NULL pointers
     assert lib.pn2x_mlp2_rows_supported(128, 128, 128) == 1 and lib.pn2x_mlp2_rows_supported(96, 96, 96) == 0
     lib.pn2x_kabsch_backward.argtypes = [ci, ci, ci] + [vp] * 7
