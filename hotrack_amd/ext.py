@@ -472,6 +472,42 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, relu: bo
     return y
 
 
+_lib.pn2x_ln_linear_small.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _cf, _vp, _vp, _ci, _vp, _ci, _vp, _ci, _vp]
+_lib.pn2x_ln_linear_small.restype = _ci
+LN_LINEAR_MAX_ROWS = int(__import__("os").environ.get("HOTRACK_LN_LINEAR_MAX_ROWS", "64"))  # 0: always the two launches
+
+
+def ln_linear_supported(rows: int, c: int) -> bool:
+    """The LayerNorm launch in front of a small Linear folded into it (pn2x_ln_linear_small): few rows, c <= 384."""
+    return 0 < rows <= LN_LINEAR_MAX_ROWS and c <= 384
+
+
+def ln_linear(x: torch.Tensor, ln1, w: torch.Tensor, bias: torch.Tensor = None, relu: bool = False, y: torch.Tensor = None,
+              ybias: torch.Tensor = None, ln2=None):
+    """(xn, act(xn w^T + bias)) with xn = ln2(ln1(x + y + ybias)) over the last dimension of x (rows, C) -- add_layernorm and
+    linear in one launch (include/pn2_ext.h: pn2x_ln_linear_small; same bits as the two).  Inference only."""
+    rows, C = x.shape
+    N = w.shape[0]
+    f32 = torch.float32
+    for ln in (ln1, ln2):
+        if ln is not None and (tuple(ln.normalized_shape) != (C,) or ln.weight is None or ln.bias is None):
+            raise ValueError("ln_linear: LayerNorm over the last dimension with affine parameters expected")
+    if x.dtype != f32 or not x.is_cuda or not x.is_contiguous() or w.dtype != f32 or w.stride(1) != 1 or w.shape[1] != C:
+        raise TypeError("ln_linear: contiguous float32 GPU rows and a (N, C) float32 weight expected")
+    if y is not None and (y.shape != x.shape or not y.is_contiguous() or y.dtype != f32):
+        raise TypeError("ln_linear: y must match x")
+    xn = torch.empty_like(x)
+    out = torch.empty((rows, N), dtype=f32, device=x.device)
+    with torch.cuda.device(x.device):
+        _native._check(_lib.pn2x_ln_linear_small(
+            rows, C, N, x.data_ptr(), None if y is None else y.data_ptr(), None if ybias is None else _native._ptr(ybias, "ybias", f32, C),
+            _native._ptr(ln1.weight, "ln1.weight", f32, C), _native._ptr(ln1.bias, "ln1.bias", f32, C), ln1.eps,
+            None if ln2 is None else _native._ptr(ln2.weight, "ln2.weight", f32, C), None if ln2 is None else _native._ptr(ln2.bias, "ln2.bias", f32, C),
+            0.0 if ln2 is None else ln2.eps, xn.data_ptr(), w.data_ptr(), w.stride(0), None if bias is None else _native._ptr(bias, "bias", f32, N),
+            1 if relu else 0, out.data_ptr(), N, _native._stream(x)), "ln_linear_small")
+    return xn, out
+
+
 _lib.pn2x_knn_indices.argtypes = [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]
 _lib.pn2x_knn_indices.restype = _ci
 

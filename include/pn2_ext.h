@@ -659,6 +659,15 @@ int pn2x_linear_k128(long rows, int n, const float *x, int ldx, const float *w, 
 int pn2x_linear_small(int m, int k, int n, const float *x, int ldx, const float *w, int ldw, const float *bias, int relu, float *y,
                       int ldy, void *stream);
 
+/* y (m x n) = act(LN2(LN1(xa + ya + ybias)) . w^T + bias): pn2x_add_layernorm followed by pn2x_linear_small as ONE launch for the
+ * 21-token tail at small batch (reference transformer.py:65-67,72-82 with attn = False: norm -> linear1 -> ReLU -> linear2 ->
+ * residual + norm; hand_network.py:139-141).  xa, ya (m x k, contiguous rows; ya / ybias may be NULL), LayerNorm 1 (g1, b1, eps1),
+ * optional LayerNorm 2 (g2, b2, eps2; g2 NULL: none), k <= 384.  xout (m x k | NULL) receives the normalised rows (the next
+ * residual's input).  The LayerNorm arithmetic is pn2x_add_layernorm's, the product pn2x_linear_small's: same bits as the pair. */
+int pn2x_ln_linear_small(int m, int k, int n, const float *xa, const float *ya, const float *ybias, const float *g1, const float *b1,
+                         float eps1, const float *g2, const float *b2, float eps2, float *xout, const float *w, int ldw,
+                         const float *bias, int relu, float *y, int ldy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

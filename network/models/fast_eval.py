@@ -336,8 +336,11 @@ class FastEval:
         # ---- fp3: S == 1 -> the global feature is broadcast; first layer split so it is applied once per cloud
         p = P["fp3"]
         g = _lin(l3, p["wb"], p["b"])  # (B,256) per-cloud half, bias included
-        h = _lin(sa3_in.view(B * S2, c_l2 + 4)[:, :c_l2], p["wa"]).view(B, S2, -1)
-        ext.bias_act_pm_(h, g, rows_per_bias=S2, relu=True)
+        if B == 1:  # one cloud: the per-cloud half IS the layer's bias vector (one launch less in the tracking loop; same operations)
+            h = _lin_relu(sa3_in.view(S2, c_l2 + 4)[:, :c_l2], p["wa"], g.view(-1)).view(B, S2, -1)
+        else:
+            h = _lin(sa3_in.view(B * S2, c_l2 + 4)[:, :c_l2], p["wa"]).view(B, S2, -1)
+            ext.bias_act_pm_(h, g, rows_per_bias=S2, relu=True)
         x = h.view(B * S2, -1)
         for W, b in p["rest"]:
             x = _lin_relu(x, W, b)
@@ -410,11 +413,21 @@ class FastEval:
         # ---- "TransT" with attn=False: only LayerNorms and FFNs are live; the element-wise runs between the GEMMs
         # (residual add, bias, one or two LayerNorms) are one launch each --------------------------------------
         s11, c11, c3 = net.transt.s11, net.transt.c11, net.c3
-        x = ext.add_layernorm(f14, s11.norm1, ln2=c11.norm1)
-        for blk, nxt in ((c11, c3.norm1), (c3, None)):
-            hdn = _lin_relu(x, blk.linear1.weight, blk.linear1.bias)
-            x = ext.add_layernorm(x, blk.norm2, y=_lin(hdn, blk.linear2.weight), bias=blk.linear2.bias, ln2=nxt)
-        hdn = _lin_relu(x, net.final_mlp[0].weight.squeeze(-1), net.final_mlp[0].bias)
+        wf, bf = net.final_mlp[0].weight.squeeze(-1), net.final_mlp[0].bias
+        if ext.ln_linear_supported(f14.shape[0], f14.shape[1]):
+            # few tokens (the tracking loop): every launch here sits at the floor of a graph node, so each LayerNorm launch rides in
+            # the Linear that consumes it (pn2x_ln_linear_small: same bits as the two launches) -- 9 launches -> 6
+            x, hdn = ext.ln_linear(f14, s11.norm1, c11.linear1.weight, c11.linear1.bias, relu=True, ln2=c11.norm1)
+            y = _lin(hdn, c11.linear2.weight)
+            x, hdn = ext.ln_linear(x, c11.norm2, c3.linear1.weight, c3.linear1.bias, relu=True, y=y, ybias=c11.linear2.bias, ln2=c3.norm1)
+            y = _lin(hdn, c3.linear2.weight)
+            x, hdn = ext.ln_linear(x, c3.norm2, wf, bf, relu=True, y=y, ybias=c3.linear2.bias)
+        else:
+            x = ext.add_layernorm(f14, s11.norm1, ln2=c11.norm1)
+            for blk, nxt in ((c11, c3.norm1), (c3, None)):
+                hdn = _lin_relu(x, blk.linear1.weight, blk.linear1.bias)
+                x = ext.add_layernorm(x, blk.norm2, y=_lin(hdn, blk.linear2.weight), bias=blk.linear2.bias, ln2=nxt)
+            hdn = _lin_relu(x, wf, bf)
         # head: last 1x1 conv + residual on the initial keypoints + back to the camera frame, one launch
         pred_hf, pred_kp = ext.pose_head(hdn, P["head_w"], net.final_mlp[2].bias, xyz1, R, t, 0.2, nonfinite=nonfinite)
 

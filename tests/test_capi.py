@@ -64,6 +64,10 @@ def test_argument_validation_without_gpu(hip_lib_path):
     assert lib.pn2x_mlp2_rows(8, 128, 128, 128, None, 128, None, None, None, None, None, None, 130, None) == -1   # ldo not a multiple of 4
     assert lib.pn2x_mlp2_rows(8, 128, 128, 128, None, 128, None, None, None, None, None, None, 128, None) == -2   # NULL pointers
     assert lib.pn2x_mlp2_rows_supported(128, 128, 128) == 1 and lib.pn2x_mlp2_rows_supported(96, 96, 96) == 0
+    lib.pn2x_ln_linear_small.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, cf, vp, vp, ci, vp, ci, vp, ci, vp]
+    assert lib.pn2x_ln_linear_small(21, 385, 64, None, None, None, None, None, 1e-5, None, None, 0.0, None, None, 385, None, 0, None, 64, None) == -1  # k > 384
+    assert lib.pn2x_ln_linear_small(21, 192, 64, None, None, None, None, None, 1e-5, None, None, 0.0, None, None, 192, None, 0, None, 64, None) == -2  # NULL
+    assert lib.pn2x_ln_linear_small(0, 192, 64, None, None, None, None, None, 1e-5, None, None, 0.0, None, None, 192, None, 0, None, 64, None) == 0   # no rows
     lib.pn2x_kabsch_backward.argtypes = [ci, ci, ci] + [vp] * 7
     assert lib.pn2x_kabsch_backward(4, 2, 6, None, None, None, None, None, None, None) == -1   # x batch neither 1 nor b
     assert lib.pn2x_kabsch_backward(4, 1, 6, None, None, None, None, None, None, None) == -2   # NULL pointers

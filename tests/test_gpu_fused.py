@@ -526,6 +526,70 @@ def test_serving_loop_several_graphs_in_flight_equals_eager():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,ldx_pad,off", [(21, 192, 96, 0, 0), (128, 131, 128, 1, 0), (2, 3, 5, 0, 0), (512, 384, 512, 4, 0), (33, 257, 65, 0, 1),
+                                               (100, 128, 256, 0, 0), (21, 385, 64, 0, 0), (40, 700, 33, 3, 0), (1, 64, 64, 0, 0)])
+def test_linear_small_matches_fp64(M, K, N, ldx_pad, off):
+    """pn2x_linear_small through the C ABI: both variants (all operands requested up front for K <= 384, chunk-by-chunk beyond), ragged
+    reductions, row strides, unaligned operands, bias / ReLU on and off; twice (bit-equal)."""
+    import ctypes
+    from hotrack_amd import pointnet2_hip as native
+    lib = native._lib
+    g = torch.Generator().manual_seed(M * 31 + K)
+    xb = torch.randn(M, K + ldx_pad + off, generator=g).cuda()
+    x = xb[:, off:off + K]
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for bias in (b, None):
+        for relu in (0, 1):
+            outs = []
+            for _ in range(2):
+                y = torch.full((M, N + 3), 7.0, device="cuda")
+                rc = lib.pn2x_linear_small(M, K, N, ctypes.c_void_p(x.data_ptr()), x.stride(0), ctypes.c_void_p(w.data_ptr()), K,
+                                           None if bias is None else ctypes.c_void_p(bias.data_ptr()), relu, ctypes.c_void_p(y.data_ptr()), N + 3,
+                                           ctypes.c_void_p(st))
+                assert rc == 0
+                outs.append(y)
+            assert torch.equal(outs[0], outs[1])
+            ref = x.double() @ w.double().t() + (0 if bias is None else bias.double())
+            ref = torch.relu(ref) if relu else ref
+            assert float((outs[0][:, :N].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+            assert bool((outs[0][:, N:] == 7.0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C,N,two,resid", [(21, 192, 1024, True, False), (21, 192, 1024, True, True), (21, 192, 96, False, True),
+                                                (1, 64, 32, False, False), (42, 384, 200, True, True), (33, 100, 40, False, True), (64, 192, 512, True, True)])
+def test_ln_linear_equals_layernorm_then_linear(rows, C, N, two, resid):
+    """pn2x_ln_linear_small == pn2x_add_layernorm followed by pn2x_linear_small, bit for bit (the normalised rows always; the product
+    wherever the dispatcher would have used pn2x_linear_small for it), and torch within round-off."""
+    from hotrack_amd import ext
+    g = torch.Generator().manual_seed(rows * 7 + C)
+    x = torch.randn(rows, C, generator=g).cuda()
+    y = torch.randn(rows, C, generator=g).cuda() if resid else None
+    yb = torch.randn(C, generator=g).cuda() if resid else None
+    ln1, ln2 = torch.nn.LayerNorm(C).cuda(), (torch.nn.LayerNorm(C, eps=1e-6).cuda() if two else None)
+    with torch.no_grad():
+        for ln in (ln1, ln2):
+            if ln is not None:
+                ln.weight.copy_(torch.randn(C, generator=g).cuda())
+                ln.bias.copy_(torch.randn(C, generator=g).cuda())
+        w, b = (torch.randn(N, C, generator=g) / C ** 0.5).cuda(), torch.randn(N, generator=g).cuda()
+        xn_ref = ext.add_layernorm(x, ln1, y=y, bias=yb, ln2=ln2)
+        for relu in (True, False):
+            xn, out = ext.ln_linear(x, ln1, w, b, relu=relu, y=y, ybias=yb, ln2=ln2)
+            assert torch.equal(xn, xn_ref)
+            ref = torch.nn.functional.linear(xn_ref.double(), w.double(), b.double())
+            ref = torch.relu(ref) if relu else ref
+            assert float((out.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+            if 2 <= rows <= ext.LINEAR_SMALL_MAX_ROWS and C <= ext.LINEAR_SMALL_MAX_K and N <= ext.LINEAR_SMALL_MAX_N:
+                assert torch.equal(out, ext.linear(xn_ref, w, b, relu=relu))
+        xn, out = ext.ln_linear(x, ln1, w, None, y=y, ybias=yb, ln2=ln2)  # no bias
+        assert torch.equal(xn, xn_ref)
+    assert ext.ln_linear_supported(21, 192) and not ext.ln_linear_supported(21, 512) and not ext.ln_linear_supported(100000, 192)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 7])
 def test_forward_in_two_halves_equals_forward(B):
     """FastEval.forward_dense(forward_geometry(x)) == forward(x), bit for bit, eagerly and as two graphs on two streams (the
