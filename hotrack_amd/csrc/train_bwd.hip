@@ -26,6 +26,7 @@
 // A layer wider than the instantiated C_i (fp1's 128 -> 384 top, sa3's 128 -> 512) runs as 2 - 4 launches over column slices of
 // layer i: every slice owns its rows of dW_i completely; the data gradient is a sum over the slices, so all but the last launch
 // write their raw partial product (raw_out) and the next one adds it (Gadd, in place) before the mask and the sums.
+#include <stdlib.h>
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
@@ -907,7 +908,8 @@ static bool find_shape(int c_in, int c_out, Shape &s) {
 static int grid_of(long rows, const Shape &s) {
     const long tiles = (rows + BM - 1) / BM;
     // persistent workgroups: one per CU where the LDS footprint admits only one, two otherwise
-    const long cap = (long)num_compute_units() * (!s.v2 && s.lds * 2 <= 160 * 1024 ? 2 : 1);
+    static const int v2_two = [] { const char *e = getenv("PN2_TGB2_TWO_PER_CU"); return e ? atoi(e) : 0; }();  // (A/B probe)
+    const long cap = (long)num_compute_units() * ((!s.v2 || v2_two) && s.lds * 2 <= 160 * 1024 ? 2 : 1);
     return (int)(tiles < cap ? tiles : cap);
 }
 
