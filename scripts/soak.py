@@ -124,9 +124,8 @@ while time.time() < t_end:
             keep[:, c0:c0 + kk_] = False
             assert bool((a_[keep] == 7.0).all()), "wgrad_multi wrote outside its column block"
         n_wg += 1
-    # ---- streamed-coordinate FPS (16385 .. 65536 points) against the register-resident kernel's answer on the same cloud cut to
-    # its tie-free prefix is not available: compare with the HBM-temp kernel through the C entry (scratch given) in a second
-    # process?  The switch is read once per process -- so here: twice (bit-equal) and against a torch evaluation of the picks ----
+    # ---- streamed-coordinate FPS (16385 .. 65536 points): twice (bit-equal), and every pick must be a maximiser of the running
+    # distance as torch computes it (the exact tie ORDER is the pytest cases' business, against the oracle) ----
     if n_sa % 16 == 0:
         from hotrack_amd import pointnet2_hip as native
         Bs, Ns, Ms = int(rng.integers(1, 4)), int(rng.integers(16385, 65537)), int(rng.integers(2, 40))
@@ -139,8 +138,6 @@ while time.time() < t_end:
         native.furthest_point_sampling_wrapper(Bs, Ns, Ms, xs, None, o1)
         native.furthest_point_sampling_wrapper(Bs, Ns, Ms, xs, None, o2)
         assert torch.equal(o1, o2), "fps_stream not deterministic"
-        # every pick is an arg-max of the running distance (ties: any maximiser is acceptable here; the exact tie order is
-        # the pytest cases' business, against the oracle)
         dmin = torch.full((Bs, Ns), 1e10, device="cuda")
         for it in range(1, Ms):
             c = xs[torch.arange(Bs, device="cuda"), o1[:, it - 1].long()]
