@@ -263,40 +263,65 @@ fps_large_kernel(int n, int m, const float *__restrict__ xyz_all, float *__restr
 }
 
 // Clouds of 16385 .. 65536 points: one workgroup of 1024 threads per cloud, thread t owns the points t + 1024 q like the
-// reference (sampling_gpu.cu:143-167), their RUNNING DISTANCES live in QMAX registers per lane for the whole kernel and only the
-// coordinates are re-read every pick (786 KB per cloud at most: L2-resident, coalesced 12-byte records through a buffer
-// descriptor whose bounds check returns zeros for the slots beyond n) -- no `temp` traffic at all, against 1 MB read + 256 KB
-// written per pick by fps_large_kernel below.  The arg-max follows the reference's tie order without a tree: wave maximum of the
-// distance bits (6 DPP steps), then the smallest (bitrev10(thread), q) among the lanes that hold it (6 more), one LDS entry per
-// wave, ONE barrier per pick (entries double-buffered by parity), every wave combines the 16 entries on its own.
-template <int QMAX>
+// reference (sampling_gpu.cu:143-167).  Their RUNNING DISTANCES live in QMAX registers per lane for the whole kernel -- no `temp`
+// traffic at all, against 1 MB read + 256 KB written per pick by fps_large_kernel below -- and the coordinates sit where there is
+// room, nearest first: slots q < QR in registers (3 QR per lane), the next QL slots in LDS (structure of arrays, 12 KB per slot:
+// conflict-free ds_read_b32), the rest is re-read every pick (L2-resident, coalesced 12-byte records through a buffer descriptor
+// whose bounds check returns zeros for the slots beyond n).  At 32768 points 28 of 32 slots are resident, at 65536 points 13 of 64 (LDS only).
+// The arg-max follows the reference's tie order without a tree: wave maximum of the distance bits (6 DPP steps), then the smallest
+// (bitrev10(thread), q) among the lanes that hold it (6 more), one LDS entry per wave, ONE barrier per pick (entries
+// double-buffered by parity), every wave combines the 16 entries on its own.
+template <int QMAX, int QR, int QL>
 __global__ void __launch_bounds__(1024)
 fps_stream_kernel(int n, int m, const float *__restrict__ xyz_all, int *__restrict__ idx_all) {
+    static_assert(QR + QL <= QMAX, "resident slots");
     __shared__ unsigned ent[2][2][16];  // [parity][distance bits | tie key][wave]
+    extern __shared__ __attribute__((aligned(16))) float lco[];  // [QL][3][1024]
     const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
     int *__restrict__ idx = idx_all + (size_t)blockIdx.x * m;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned trank = __builtin_bitreverse32((unsigned)tid) >> 22;  // rank of this thread in the reference's tree: smaller wins ties
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xyz), 0, 12 * n, 0x00020000);
+    typedef float f32x3v __attribute__((ext_vector_type(3)));
+    // (whole-vector cast: a bit cast of a vector ELEMENT reads element 0 with this hipcc)
+    auto record = [&](int q) { return __builtin_bit_cast(f32x3v, __builtin_amdgcn_raw_buffer_load_b96(rx, 12 * tid + 12 * 1024 * q, 0, 0)); };
     float pt[QMAX];
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) pt[q] = tid + 1024 * q < n ? 1e10f : -1.0f;  // slots beyond n can never win (real distances >= 0)
+    float rxs[QR > 0 ? QR : 1], rys[QR > 0 ? QR : 1], rzs[QR > 0 ? QR : 1];
+#pragma unroll
+    for (int q = 0; q < QR; ++q) {
+        const f32x3v p = record(q);
+        rxs[q] = p.x; rys[q] = p.y; rzs[q] = p.z;
+    }
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {  // (read back by the thread that wrote them: no barrier needed)
+        const f32x3v p = record(QR + q);
+        lco[(3 * q + 0) * 1024 + tid] = p.x;
+        lco[(3 * q + 1) * 1024 + tid] = p.y;
+        lco[(3 * q + 2) * 1024 + tid] = p.z;
+    }
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
     if (tid == 0) idx[0] = 0;
-    typedef float f32x3v __attribute__((ext_vector_type(3)));
     for (int it = 1; it < m; ++it) {
         float best = -1.0f;
         int bestq = 0;
-#pragma unroll
-        for (int q = 0; q < QMAX; ++q) {
-            // (whole-vector cast: a bit cast of a vector ELEMENT reads element 0 with this hipcc)
-            const f32x3v p = __builtin_bit_cast(f32x3v, __builtin_amdgcn_raw_buffer_load_b96(rx, 12 * tid + 12 * 1024 * q, 0, 0));
-            const float d = sqdist(p.x, p.y, p.z, cx, cy, cz);
+        auto visit = [&](int q, float x, float y, float z) {
+            const float d = sqdist(x, y, z, cx, cy, cz);
             const float tt = fmin_raw(d, pt[q]);
             pt[q] = tt;
             const bool gt = tt > best;  // strict: the first maximum in increasing k wins inside a thread
             bestq = gt ? q : bestq;
             best = gt ? tt : best;
+        };
+#pragma unroll
+        for (int q = 0; q < QR; ++q) visit(q, rxs[q], rys[q], rzs[q]);
+#pragma unroll
+        for (int q = 0; q < QL; ++q) visit(QR + q, lco[(3 * q + 0) * 1024 + tid], lco[(3 * q + 1) * 1024 + tid], lco[(3 * q + 2) * 1024 + tid]);
+#pragma unroll
+        for (int q = QR + QL; q < QMAX; ++q) {
+            const f32x3v p = record(q);
+            visit(q, p.x, p.y, p.z);
         }
         const int bi = f2i(best);  // fp32 >= 0 (or exactly -1.0f) orders like its bit pattern as a signed int
         const int wmax = wave_max_i32(bi);
@@ -317,6 +342,16 @@ fps_stream_kernel(int n, int m, const float *__restrict__ xyz_all, int *__restri
         cy = xyz[3 * old + 1];
         cz = xyz[3 * old + 2];
     }
+}
+
+template <int QMAX, int QR, int QL>
+static int launch_fps_stream(int b, int n, int m, const float *xyz, int *idx, hipStream_t st) {
+    const size_t lds = (size_t)QL * 3 * 1024 * sizeof(float);
+    static PerDeviceOnce raised;
+    if (lds > 48 * 1024 && raised.first_use())
+        (void)hipFuncSetAttribute((const void *)fps_stream_kernel<QMAX, QR, QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fps_stream_kernel<QMAX, QR, QL>), dim3(b), dim3(1024), lds, st, n, m, xyz, idx);
+    return check_launch();
 }
 
 template <int T, int P, bool RAD>
@@ -372,9 +407,10 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
         if (skip_flags || radii) return PN2_ERANGE;  // the shortcut covers the register-resident kernels only
         static const bool no_stream = getenv("PN2_FPS_NO_STREAM") != nullptr;  // (A/B against the HBM-temp kernel: tests, probes)
         if (Q <= 64 && !no_stream) {  // running distances in registers, coordinates streamed from L2: no scratch buffer
-            if (Q <= 32) hipLaunchKernelGGL(fps_stream_kernel<32>, dim3(b), dim3(1024), 0, st, n, m, xyz, idx);
-            else hipLaunchKernelGGL(fps_stream_kernel<64>, dim3(b), dim3(1024), 0, st, n, m, xyz, idx);
-            return check_launch();
+            static const bool plain = getenv("PN2_FPS_STREAM_PLAIN") != nullptr;  // (A/B: no resident coordinates)
+            if (plain) return Q <= 32 ? launch_fps_stream<32, 0, 0>(b, n, m, xyz, idx, st) : launch_fps_stream<64, 0, 0>(b, n, m, xyz, idx, st);
+            if (Q <= 32) return launch_fps_stream<32, 16, 12>(b, n, m, xyz, idx, st);
+            return launch_fps_stream<64, 0, 13>(b, n, m, xyz, idx, st);  // (64 distance registers leave no room for coordinates: hipcc spills from QR = 4)
         }
         if (!temp) return PN2_ESCRATCH;
         hipLaunchKernelGGL(fps_large_kernel, dim3(b), dim3(1024), 0, st, n, m, xyz, temp, idx);
