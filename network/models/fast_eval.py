@@ -415,7 +415,7 @@ class FastEval:
         s11, c11, c3 = net.transt.s11, net.transt.c11, net.c3
         wf, bf = net.final_mlp[0].weight.squeeze(-1), net.final_mlp[0].bias
         if ext.ln_linear_supported(f14.shape[0], f14.shape[1]):
-            # few tokens (the tracking loop): every launch here sits at the floor of a graph node, so each LayerNorm launch rides in
+            # few tokens (the tracking loop, B <= 12): every launch here sits at the floor of a graph node, so each LayerNorm launch rides in
             # the Linear that consumes it (pn2x_ln_linear_small: same bits as the two launches) -- 9 launches -> 6
             x, hdn = ext.ln_linear(f14, s11.norm1, c11.linear1.weight, c11.linear1.bias, relu=True, ln2=c11.norm1)
             y = _lin(hdn, c11.linear2.weight)

@@ -559,7 +559,8 @@ def test_linear_small_matches_fp64(M, K, N, ldx_pad, off):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,C,N,two,resid", [(21, 192, 1024, True, False), (21, 192, 1024, True, True), (21, 192, 96, False, True),
-                                                (1, 64, 32, False, False), (42, 384, 200, True, True), (33, 100, 40, False, True), (64, 192, 512, True, True)])
+                                                (1, 64, 32, False, False), (42, 384, 200, True, True), (33, 100, 40, False, True), (64, 192, 512, True, True),
+                                                (168, 192, 1024, True, True), (255, 192, 96, False, True)])
 def test_ln_linear_equals_layernorm_then_linear(rows, C, N, two, resid):
     """pn2x_ln_linear_small == pn2x_add_layernorm followed by pn2x_linear_small, bit for bit (the normalised rows always; the product
     wherever the dispatcher would have used pn2x_linear_small for it), and torch within round-off."""
@@ -586,7 +587,7 @@ def test_ln_linear_equals_layernorm_then_linear(rows, C, N, two, resid):
                 assert torch.equal(out, ext.linear(xn_ref, w, b, relu=relu))
         xn, out = ext.ln_linear(x, ln1, w, None, y=y, ybias=yb, ln2=ln2)  # no bias
         assert torch.equal(xn, xn_ref)
-    assert ext.ln_linear_supported(21, 192) and not ext.ln_linear_supported(21, 512) and not ext.ln_linear_supported(100000, 192)
+    assert ext.ln_linear_supported(21, 192) and ext.ln_linear_supported(168, 192) and not ext.ln_linear_supported(21, 512) and not ext.ln_linear_supported(100000, 192)
 
 
 @pytest.mark.gpu
