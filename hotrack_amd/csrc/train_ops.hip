@@ -139,13 +139,26 @@ bn_relu_apply_kernel(long rows, int C, const float *__restrict__ Y, int ldy, con
     }
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (long r = r0 + rr; r < r1; r += rpp) {
-        const float4 v = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
+    auto act = [&](const float4 v) {
         float4 h;
         h.x = bn_act(v.x, k, 0); h.y = bn_act(v.y, k, 1); h.z = bn_act(v.z, k, 2); h.w = bn_act(v.w, k, 3);
         if (relu) { h.x = relu_nan(h.x); h.y = relu_nan(h.y); h.z = relu_nan(h.z); h.w = relu_nan(h.w); }
-        *reinterpret_cast<float4 *>(H + r * ldh + 4 * q) = h;
+        return h;
+    };
+    long r = r0 + rr;
+    for (; r + 3L * rpp < r1; r += 4L * rpp) {  // four independent 16-byte loads in flight per thread
+        const float *p = Y + r * ldy + 4 * q;
+        const float4 v0 = *reinterpret_cast<const float4 *>(p);
+        const float4 v1 = *reinterpret_cast<const float4 *>(p + (long)rpp * ldy);
+        const float4 v2 = *reinterpret_cast<const float4 *>(p + 2L * rpp * ldy);
+        const float4 v3 = *reinterpret_cast<const float4 *>(p + 3L * rpp * ldy);
+        float *o = H + r * ldh + 4 * q;
+        *reinterpret_cast<float4 *>(o) = act(v0);
+        *reinterpret_cast<float4 *>(o + (long)rpp * ldh) = act(v1);
+        *reinterpret_cast<float4 *>(o + 2L * rpp * ldh) = act(v2);
+        *reinterpret_cast<float4 *>(o + 3L * rpp * ldh) = act(v3);
     }
+    for (; r < r1; r += rpp) *reinterpret_cast<float4 *>(H + r * ldh + 4 * q) = act(*reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q));
 }
 
 // gradient of  out[g, c] = max_k h[g*K + k, c]  seen from row r = g*K + k: dout[g, c] where k is the recorded arg-max, else 0
@@ -411,9 +424,7 @@ bn_relu_bwd_apply_kernel(long rows, int C, const float *__restrict__ dH, int ldd
     }
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (long r = r0 + rr; r < r1; r += rpp) {
-        const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
-        float4 g = arg ? max_grad(dH, ldd, arg, C, K, r, q) : *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q);
+    auto dy_of = [&](const float4 y, const float4 g) {
         const float yy[4] = {y.x, y.y, y.z, y.w};
         float gg[4] = {g.x, g.y, g.z, g.w}, o[4];
 #pragma unroll
@@ -422,7 +433,27 @@ bn_relu_bwd_apply_kernel(long rows, int C, const float *__restrict__ dH, int ldd
             const float xhat = (yy[i] - k.mean[i]) * k.invstd[i];
             o[i] = scale[i] * (gg[i] - sg[i] * inv_r - xhat * (sgx[i] * inv_r));
         }
-        *reinterpret_cast<float4 *>(dY + r * ldo + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        return make_float4(o[0], o[1], o[2], o[3]);
+    };
+    long r = r0 + rr;
+    if (!arg) {
+        for (; r + 3L * rpp < r1; r += 4L * rpp) {  // eight independent 16-byte loads in flight per thread
+            const float *py = Y + r * ldy + 4 * q, *pg = dH + r * ldd + 4 * q;
+            const float4 y0 = *reinterpret_cast<const float4 *>(py), g0 = *reinterpret_cast<const float4 *>(pg);
+            const float4 y1 = *reinterpret_cast<const float4 *>(py + (long)rpp * ldy), g1 = *reinterpret_cast<const float4 *>(pg + (long)rpp * ldd);
+            const float4 y2 = *reinterpret_cast<const float4 *>(py + 2L * rpp * ldy), g2 = *reinterpret_cast<const float4 *>(pg + 2L * rpp * ldd);
+            const float4 y3 = *reinterpret_cast<const float4 *>(py + 3L * rpp * ldy), g3 = *reinterpret_cast<const float4 *>(pg + 3L * rpp * ldd);
+            float *o = dY + r * ldo + 4 * q;
+            *reinterpret_cast<float4 *>(o) = dy_of(y0, g0);
+            *reinterpret_cast<float4 *>(o + (long)rpp * ldo) = dy_of(y1, g1);
+            *reinterpret_cast<float4 *>(o + 2L * rpp * ldo) = dy_of(y2, g2);
+            *reinterpret_cast<float4 *>(o + 3L * rpp * ldo) = dy_of(y3, g3);
+        }
+    }
+    for (; r < r1; r += rpp) {
+        const float4 y = *reinterpret_cast<const float4 *>(Y + r * ldy + 4 * q);
+        const float4 g = arg ? max_grad(dH, ldd, arg, C, K, r, q) : *reinterpret_cast<const float4 *>(dH + r * ldd + 4 * q);
+        *reinterpret_cast<float4 *>(dY + r * ldo + 4 * q) = dy_of(y, g);
     }
 }
 
@@ -767,14 +798,10 @@ static int slab_channels(int b, int n_dst, int C) {
 // 0.2-0.25 T adds/s.  Here the index list of a cloud is inverted once (counting sort by target row: offsets + order), and
 // every (target row, channel quad) SUMS its contributions with plain coalesced 16-byte row reads -- no atomics in the data
 // path, nothing to pre-zero, every output row written exactly once.
-__global__ void __launch_bounds__(kTT)
-inverse_index_kernel(int n_dst, int L, const int *__restrict__ idx_all, int *__restrict__ offsets_all, int *__restrict__ order_all) {
+__device__ __forceinline__ void inverse_index_body(int n_dst, int L, const int *__restrict__ idx, int *__restrict__ offsets,
+                                                   int *__restrict__ order) {
     extern __shared__ int cnt[];  // [n_dst + 1] counts -> running cursors; then [kTT] chunk totals
     int *part = cnt + n_dst + 1;
-    const int b = blockIdx.x;
-    const int *__restrict__ idx = idx_all + (size_t)b * L;
-    int *__restrict__ offsets = offsets_all + (size_t)b * (n_dst + 1);
-    int *__restrict__ order = order_all + (size_t)b * L;
     for (int i = threadIdx.x; i <= n_dst; i += kTT) cnt[i] = 0;
     __syncthreads();
     auto key = [&](int e) { const int k = idx[e]; return k < 0 ? 0 : (k >= n_dst ? n_dst - 1 : k); };  // (out-of-range indices cannot corrupt LDS)
@@ -802,6 +829,22 @@ inverse_index_kernel(int n_dst, int L, const int *__restrict__ idx_all, int *__r
     if (threadIdx.x == 0) offsets[n_dst] = L;
     __syncthreads();
     for (int e = threadIdx.x; e < L; e += kTT) order[atomicAdd(&cnt[key(e)], 1)] = e;
+}
+
+__global__ void __launch_bounds__(kTT)
+inverse_index_kernel(int n_dst, int L, const int *__restrict__ idx_all, int *__restrict__ offsets_all, int *__restrict__ order_all) {
+    const int b = blockIdx.x;
+    inverse_index_body(n_dst, L, idx_all + (size_t)b * L, offsets_all + (size_t)b * (n_dst + 1), order_all + (size_t)b * L);
+}
+
+// The same sort for every chunk of mt consecutive positions of a cloud's list on its own (scatter_cm.hip, long lists):
+// workgroup (cloud b, chunk k) -> offsets [b][k][n_dst + 1], order [b][k * mt ...] holding positions RELATIVE to the chunk.
+__global__ void __launch_bounds__(kTT)
+inverse_index_chunked_kernel(int n_dst, int L, int mt, int nchunks, const int *__restrict__ idx_all, int *__restrict__ offsets_all,
+                             int *__restrict__ order_all) {
+    const int b = blockIdx.x / nchunks, k = blockIdx.x - b * nchunks;
+    const int e0 = k * mt, len = (L - e0) < mt ? (L - e0) : mt;
+    inverse_index_body(n_dst, len, idx_all + (size_t)b * L + e0, offsets_all + (size_t)blockIdx.x * (n_dst + 1), order_all + (size_t)b * L + e0);
 }
 
 // acc += sum over p = p0, p0 + step, ... < p1 of [w] . row(order[p]), in that order.  Four list entries per round: their source
@@ -922,7 +965,11 @@ rows_segment_sum_split_kernel(int n_dst, int m_src, int Q, int EL, const float *
 static int rows_per_block_for(long rows, int C) {
     const int rpp = kTT / (C >> 2);
     long rpb = (rows + 1023) / 1024;  // ~1024 workgroups on a large problem
-    if (rpb < 16L * rpp) rpb = 16L * rpp;
+    // A thread walks rows_per_block / rpp rows.  Small tensors (the 4096 - 8192-row stacks of a 32-cloud step: <= 8 MB) used
+    // to get 16 rows per thread like the large ones -- 32 - 64 workgroups, each thread a chain of 16 dependent-in-time round
+    // trips: 9 - 10 us for a 4 MB tensor.  Four rows per thread (all four loads in flight, see the kernels) fill the chip.
+    const long min_rows = (rows * C <= (2L << 20) ? 4L : 16L) * rpp;
+    if (rpb < min_rows) rpb = min_rows;
     return (int)rpb;
 }
 
@@ -1496,6 +1543,13 @@ int inverse_index_launch(int b, int n_dst, int l, const int *idx, int *offsets, 
     const size_t lds = ((size_t)n_dst + 1 + kTT) * sizeof(int);
     if (lds > 64 * 1024) return PN2_ERANGE;
     hipLaunchKernelGGL(inverse_index_kernel, dim3(b), dim3(kTT), lds, st, n_dst, l, idx, offsets, order);
+    return check_launch();
+}
+
+int inverse_index_chunked_launch(int b, int n_dst, int l, int mt, int nchunks, const int *idx, int *offsets, int *order, hipStream_t st) {
+    const size_t lds = ((size_t)n_dst + 1 + kTT) * sizeof(int);
+    if (lds > 64 * 1024 || mt < 1 || (long)nchunks * mt < l) return PN2_ERANGE;
+    hipLaunchKernelGGL(inverse_index_chunked_kernel, dim3((unsigned)(b * nchunks)), dim3(kTT), lds, st, n_dst, l, mt, nchunks, idx, offsets, order);
     return check_launch();
 }
 }  // namespace pn2

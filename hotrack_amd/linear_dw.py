@@ -92,11 +92,11 @@ class _Linear(torch.autograd.Function):
         if params and g.is_cuda and _defer_ok(params):
             gg = _rows(g)
             if ctx.needs_input_grad[1]:
-                dw = torch.empty(w2.shape, dtype=_f32, device=g.device)
+                dw = _ts.grad_buffer(weight, w2.shape)  # (the parameter's slice of a flat exchange buffer where one is registered)
                 _record(gg, _rows(x), dw, dw.data_ptr(), w2.shape[1], w2.shape[0], w2.shape[1])
                 dw = dw.view(weight.shape)  # a fresh view: autograd adopts it (no clone); the late product lands in its storage
             if want_b:  # the column sums of g: one more (N x 1) problem of the grouped launch
-                db = torch.empty((w2.shape[0], 1), dtype=_f32, device=g.device)
+                db = _ts.grad_buffer(ctx.bias, (w2.shape[0], 1))
                 _record(gg, _ones(g.shape[0], g.device), db, db.data_ptr(), 1, w2.shape[0], 1)
                 db = db.view(-1)
         else:
@@ -151,7 +151,7 @@ class _LinearBlocks(torch.autograd.Function):
 
         def gsum(n):
             if n not in gs:
-                gs[n] = g.view(g.shape[0] // n, n, N).sum(1)
+                gs[n] = g.reshape(g.shape[0] // n, n, N).sum(1)
             return gs[n]
         dxs = []
         for i, x in enumerate(xs):
@@ -164,7 +164,7 @@ class _LinearBlocks(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if g.is_cuda and _defer_ok([weight]):
                 gg = _rows(g)
-                dw = torch.empty(w2.shape, dtype=_f32, device=g.device)
+                dw = _ts.grad_buffer(weight, w2.shape)
                 for i, x in enumerate(xs):
                     gi = gg if reps[i] == 1 else _rows(gsum(reps[i]))
                     _record(gi, _rows(x), dw, dw.data_ptr() + 4 * cols[i], w2.shape[1], N, x.shape[1])
@@ -248,7 +248,7 @@ class _PerPoint(torch.autograd.Function):
                 elif defer:
                     # [feature block | xyz | centre], every block written at the end of the pass by the grouped launch: the feature
                     # block as g^T x, the two small ones as eye^T . block (a copy as one more problem: no concatenation launch here)
-                    full = torch.empty((C, w.shape[1]), dtype=_f32, device=dev)
+                    full = _ts.grad_buffer(ws[j], (C, w.shape[1]))
                     ld = full.shape[1]
                     _record(g_m[:, c0:c0 + C], xx, full, full.data_ptr(), ld, C, D)
                     eye = _eye(C, dev)

@@ -174,6 +174,56 @@ def _pending_now(item):
     _reduce_items([item])
 
 
+# ---- gradient homes (network/trainer.py, dp = flat) ------------------------------------------------------------------------------
+# A data-parallel trainer exchanges gradients as a few flat buffers.  Instead of packing every .grad into them after the
+# backward (and scattering them back for the optimiser: two passes over 16.7 MB per step), it registers, per parameter, the
+# slice of the flat buffer its gradient belongs in; the producers below -- the fused stacks' end-of-pass reduction, the
+# grouped weight-gradient launch, the first-layer BatchNorm backward -- then write there directly and hand autograd a FRESH
+# view of the slice (adopted as .grad without a clone).  Only while the parameter has no gradient yet: an accumulating pass
+# gets an ordinary tensor (autograd would add the home to itself).
+_grad_home = {}
+
+
+def set_grad_homes(pairs) -> None:
+    """pairs: iterable of (parameter, tensor of the parameter's shape that is to receive its gradient); replaces the registry."""
+    _grad_home.clear()
+    for p, v in pairs:
+        if v.shape != p.shape or v.dtype != p.dtype or v.device != p.device or not v.is_contiguous():
+            raise ValueError("train_stack.set_grad_homes: a home must be a contiguous tensor of its parameter's shape / dtype / device")
+        _grad_home[p.data_ptr()] = (p, v)
+
+
+def clear_grad_homes() -> None:
+    _grad_home.clear()
+
+
+def grad_buffer(param, shape):
+    """Where this pass writes `param`'s gradient, as a tensor of `shape` (same element count): a fresh view of the registered
+    home, or a new tensor."""
+    if param is not None and param.numel():
+        h = _grad_home.get(param.data_ptr())
+        if h is not None and h[0].numel() == param.numel() and param.is_leaf and param.grad is None:
+            return h[1].view(shape)
+    return torch.empty(shape, dtype=_f32, device=param.device if param is not None else None)
+
+
+def _fv(t):
+    """A fresh tensor object on t's memory: autograd adopts a returned gradient without a clone only when nothing else holds
+    the very object (the deferred-reduction records do hold these)."""
+    return t.view(t.shape)
+
+
+def _dpar(gamma, beta, bias, n, dev):
+    """[d gamma, d beta, d conv bias] of one BatchNorm layer, each (n,): homes where registered (the conv bias' is all zeros)."""
+    out = []
+    for t in (gamma, beta, bias):
+        if t is not None and t.numel() == n:
+            out.append(grad_buffer(t, (n,)))
+        else:
+            out.append(torch.empty((n,), dtype=_f32, device=dev))
+    return out
+
+
 _lib.pn2x_wgrad_multi_max.restype = _ci
 _lib.pn2x_wgrad_multi_scratch_floats.argtypes = [_ci, ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_ci)]
 _lib.pn2x_wgrad_multi_scratch_floats.restype = _cl
@@ -424,8 +474,8 @@ class _Bwd:
                 yi, yp, svi, svp = ys[i], ys[i - 1], saved[i], saved[i - 1]
                 dy_args = (gmode, g.data_ptr(), g.stride(0), _p(arg) if gmode == 2 else None, K if gmode == 2 else 1, yi.data_ptr(),
                            yi.stride(0), svi[0].data_ptr(), svi[1].data_ptr(), gam(i).data_ptr(), bet(i).data_ptr(), sums[i].data_ptr())
-                dw = torch.empty((N, Kc), dtype=_f32, device=dev)
-                dpar = torch.empty((3, N), dtype=_f32, device=dev)
+                dw = grad_buffer(tensors[4 * i], (N, Kc))
+                dpar = _dpar(gam(i), bet(i), tensors[4 * i + 3] if ctx.has_bias[i] else None, N, dev)
                 gp = torch.empty((R, Kc), dtype=_f32, device=dev)
                 slices = _bwd_slices(Kc, N) if (FUSED_BWD and (gmode != 2 or routed)) else None
                 if slices:
@@ -444,14 +494,14 @@ class _Bwd:
                         # issued by _drive; the answer is the number of partial tiles actually written (a pair launch gives this
                         # problem a share of the grid, fewer workgroups than it would get alone)
                         np_ = yield ("bwd", bargs, st, dev, np_)
-                        item = (partial, np_, dw[off:off + wd], sums[i][off:], dpar[:, off:off + wd], st, N)
+                        item = (partial, np_, dw[off:off + wd], sums[i][off:], [t_[off:off + wd] for t_ in dpar], st, N)
                         if defer:
                             _defer(item)
                         else:
                             _pending_now(item)
-                    grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = dw.view(w_shape), dpar[0], dpar[1]
+                    grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = dw.view(w_shape), _fv(dpar[0]), _fv(dpar[1])
                     if ctx.has_bias[i]:
-                        grads[4 * i + 3] = dpar[2]
+                        grads[4 * i + 3] = _fv(dpar[2])
                     g, gmode = gp, 0
                     continue
                 pf = int(_lib.pn2x_tg_wgrad_partial_floats(R, N, Kc))
@@ -464,9 +514,9 @@ class _Bwd:
                 if defer:
                     _defer((partial, np_.value, dw, sums[i], dpar, st))
                 dw = dw.view(w_shape)  # a fresh view: autograd adopts it (no clone); a late reduction lands in the adopted storage
-                grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = dw, dpar[0], dpar[1]
+                grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = dw, _fv(dpar[0]), _fv(dpar[1])
                 if ctx.has_bias[i]:
-                    grads[4 * i + 3] = dpar[2]  # zeros: the bias of a convolution in front of a BatchNorm has no gradient
+                    grads[4 * i + 3] = _fv(dpar[2])  # zeros: the bias of a convolution in front of a BatchNorm has no gradient
                 _native._check(_lib.pn2x_tg_dgrad(R, N, Kc, *dy_args, wc.data_ptr(), wc.stride(0), yp.data_ptr(), yp.stride(0),
                                                   svp[0].data_ptr(), svp[1].data_ptr(), gam(i - 1).data_ptr(), bet(i - 1).data_ptr(),
                                                   gp.data_ptr(), Kc, sums[i - 1].data_ptr(), st), "tg_dgrad")
@@ -475,7 +525,7 @@ class _Bwd:
             y1, sv1 = ys[0], saved[0]
             C1 = y1.shape[1]
             dy1 = torch.empty((R, C1), dtype=_f32, device=dev)
-            dpar = torch.empty((3, C1), dtype=_f32, device=dev)
+            dpar = _dpar(gam(0), bet(0), tensors[3] if ctx.has_bias[0] else None, C1, dev)
             rel = None
             if ctx.aux is not None:  # (aux dict of train_ops.sa_layer1, scale index): also d(W_xyz) = dY_1^T rel from this pass
                 adict, ai = ctx.aux
@@ -496,9 +546,9 @@ class _Bwd:
                                                       sv1[1].data_ptr(), gam(0).data_ptr(), bet(0).data_ptr(), 0, sums[0].data_ptr(),
                                                       dy1.data_ptr(), C1, dpar[0].data_ptr(), dpar[1].data_ptr(), dpar[2].data_ptr(), st),
                                "bn_bwd_apply")
-            grads[1], grads[2] = dpar[0], dpar[1]
+            grads[1], grads[2] = _fv(dpar[0]), _fv(dpar[1])
             if ctx.has_bias[0]:
-                grads[3] = dpar[2]
+                grads[3] = _fv(dpar[2])
         return dy1, grads
 
 

@@ -136,14 +136,20 @@ class Trainer(nn.Module):
         if (self.world == 1 and dist.is_available() and dist.is_initialized() and self.optimizer is not None
                 and str(cfg.get("dp_force", os.environ.get("HOTRACK_DP_FORCE", ""))) == "flat"):
             self.dp_mode = "flat"  # a one-rank process group: the exchange path end to end on one GPU (bench_train.py --dp-selftest)
-        # "flat", backward in SEGMENTS (default 2: everything after the backbone | the backbone): the first segment's gradients
-        # (14.5 of the 16.7 MB) are exchanged while the second segment's backward runs; only the last segment's exchange is
-        # exposed.  bwd_segments: 1 restores the single exchange after the whole backward.  dp_overlap: False keeps the segments
-        # but issues every exchange in stream order (A/B measurements).
-        self.bwd_segments = int(cfg.get("bwd_segments", os.environ.get("HOTRACK_BWD_SEGMENTS", "2")))
+        # "flat", backward in SEGMENTS (bwd_segments: 2 = everything after the backbone | the backbone): the first segment's
+        # gradients (14.5 of the 16.7 MB) are exchanged while the second segment's backward runs, only the last segment's
+        # exchange is exposed.  Default 1 since round 6: measured with a one-rank RCCL group on one MI355X
+        # (profiles/r06_misc_measurements.md) the single exchange costs +42 us per step (35 of them RCCL's own one-rank kernel),
+        # two segments in stream order +95 us (a third graph, the end-of-pass weight-gradient launches once per segment) and
+        # with the first exchange on the collective's stream +160 us -- more than the 14.5 MB exchange it would hide is expected
+        # to take over xGMI.  dp_overlap: False keeps two segments but issues every exchange in stream order (A/B measurements).
+        self.bwd_segments = int(cfg.get("bwd_segments", os.environ.get("HOTRACK_BWD_SEGMENTS", "1")))
         self.dp_overlap = bool(cfg.get("dp_overlap", os.environ.get("HOTRACK_DP_OVERLAP", "1") == "1"))
         self._segs, self._active_segs = {}, []
         self._opt_graph = self._graph_rest = self._comm_stream = self._seg_done = None
+        if torch.cuda.is_available():  # gradient homes of an earlier trainer in this process (tests) are not this one's
+            from hotrack_amd import train_stack as _ts0
+            _ts0.clear_grad_homes()
         if self.world > 1 and self.optimizer is not None:
             if self.dp_mode == "ddp":
                 if torch.cuda.is_available():  # DDP's bucket hooks read .grad inside the pass: no deferred weight-gradient sums
@@ -286,20 +292,20 @@ class Trainer(nn.Module):
             return loss_dict
         # "flat", eager: segment 0's exchange is in flight (async) while segment 1's backward is issued
         loss_dict, cut = self._fb_head(data, zero)
-        self._pack_segment(0, cut is not None)
+        self._settle_segment(0, cut is not None)
         works = [self._exchange(0, async_op=cut is not None and self.dp_overlap)]
         if cut is not None:
             self._fb_rest(cut)
-            self._pack_segment(1, True)
+            self._settle_segment(1, True)
             works.append(self._exchange(1))
         self._finish_exchange(works)
-        self._scatter_flat()
-        self.optimizer.step()
+        self.optimizer.step()  # reads the reduced gradients in the flat buffers (every .grad is a view of one)
         return loss_dict
 
     def _forward_backward(self, data, zero=True, geo=None):
         """Forward, loss and the whole backward (both segments when the model was cut), no gradient exchange."""
         loss_dict, cut = self._fb_head(data, zero, geo)
+        self._last_cut = cut is not None
         if cut is not None:
             self._fb_rest(cut)
         return loss_dict
@@ -315,18 +321,23 @@ class Trainer(nn.Module):
         net = self._bare_model()
         can_cut = hasattr(net, "cut_backbone_grad")
         seg = can_cut and self.dp_mode == "flat" and self.bwd_segments > 1
-        if can_cut:
-            net.cut_backbone_grad, net.backward_cut = seg, None
-        if self.ddp is not None:
-            loss_dict = self.ddp(data, flags)  # forward + compute_loss inside the DDP-wrapped module
-        else:
-            ret = self.model(data, flags)
-            loss_dict, _ = self.model.compute_loss(data, ret, flags)
+        # the cut request is module state only for the duration of THIS forward (left set, every later training-mode
+        # forward of the model -- a plain loss.backward() outside the Trainer, a deepcopy -- silently detached the backbone)
+        cut = None
+        try:
+            if can_cut:
+                net.cut_backbone_grad, net.backward_cut = seg, None
+            if self.ddp is not None:
+                loss_dict = self.ddp(data, flags)  # forward + compute_loss inside the DDP-wrapped module
+            else:
+                ret = self.model(data, flags)
+                loss_dict, _ = self.model.compute_loss(data, ret, flags)
+        finally:
+            if can_cut:
+                cut, net.backward_cut = (net.backward_cut if seg else None), None
+                net.cut_backbone_grad = False
         loss_dict = self.summarize_losses(loss_dict)
         loss_dict["total_loss"].backward()  # "ddp": bucketed all-reduce overlapped with backward
-        cut = None
-        if seg:
-            cut, net.backward_cut = net.backward_cut, None
         return loss_dict, cut
 
     @staticmethod
@@ -349,27 +360,65 @@ class Trainer(nn.Module):
                                "(the model's cut does not separate its parameters); use bwd_segments=1")
         return [p for p in params if (id(p) in up) == (s == 1)]
 
-    def _pack_segment(self, s, cut_exists, in_capture=False):
-        """Segment s's gradients -> its flat buffer (one concatenation).  in_capture: the buffer is allocated by the
-        concatenation itself (from the capturing graph's pool) and re-filled by every replay."""
+    def _settle_segment(self, s, cut_exists):
+        """Segment s's gradients INTO its persistent flat buffer; afterwards every .grad of the segment IS a view of the buffer,
+        so the exchange reduces the gradients in place and the optimiser reads the reduced values where they lie: no packing
+        concatenation before and no scatter after the exchange (rounds 4-5: two passes over 16.7 MB per step).  The large
+        gradients are already there -- their producers write into the registered slice (hotrack_amd.train_stack.grad_buffer:
+        the fused stacks' end-of-pass reduction, the grouped weight-gradient launch, the first-layer BatchNorm backward);
+        whatever autograd produced elsewhere (LayerNorm / bias / small BatchNorm tensors; everything on the CPU, and on the first
+        step, before the slices are registered) is moved by ONE multi-tensor copy.  Capture-safe: the buffers are allocated
+        eagerly (Trainer._capture lays them out after its warm-up steps), only the copy is recorded."""
         params = self._segment_params(s, cut_exists)
-        grads = [p.grad for p in params]
-        n = sum(g.numel() for g in grads)
         if s == 0:
             self._active_segs = []
         self._active_segs.append(s)
         seg = self._segs.get(s)
-        dev = grads[0].device if grads else torch.device(self.device)
-        if in_capture or seg is None or seg["flat"].numel() != n or seg["flat"].device != dev or seg["count"] != len(grads):
-            flat = (torch.cat([g.reshape(-1) for g in grads]) if (in_capture and grads) else
-                    torch.empty(n, dtype=grads[0].dtype if grads else torch.float32, device=dev))
-            seg = self._segs[s] = {"flat": flat, "count": len(grads), "checked": False}
-            if in_capture:
-                seg["grads"] = grads
-                return
-        seg["grads"] = grads
-        if grads:
-            torch.cat([g.reshape(-1) for g in grads], out=seg["flat"])
+        key = tuple(id(p) for p in params)
+        if seg is None or seg["key"] != key:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("dp=flat: the gradient layout of segment %d changed inside a graph capture" % s)
+            seg = self._layout_segment(s, params)
+        src, dst = [], []
+        for p, v in zip(params, seg["views"]):
+            g = p.grad
+            if g.data_ptr() != v.data_ptr() or g.shape != v.shape or not g.is_contiguous():
+                src.append(g if g.dtype == v.dtype else g.to(v.dtype))
+                dst.append(v)
+        seg["moved"] = sum(t.numel() for t in dst)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(params, seg["views"]):
+            p.grad = v
+
+    def _segments_from_grads(self):
+        """[parameters of segment 0, (of segment 1)] from the gradients a WHOLE backward left (what _segment_params gives
+        segment by segment during a step)."""
+        net = self._bare_model()
+        params = [p for p in self.model.parameters() if p.grad is not None]
+        cut = (hasattr(net, "cut_backbone_grad") and self.dp_mode == "flat" and self.bwd_segments > 1
+               and getattr(self, "_last_cut", False))
+        if not cut:
+            return [params]
+        up = {id(p) for p in net.segment_upstream_parameters()}
+        return [[p for p in params if id(p) not in up], [p for p in params if id(p) in up]]
+
+    def _layout_segment(self, s, params):
+        """A flat buffer for `params`' gradients (parameter order: the same on every rank), every slice 16-byte aligned, and
+        the slices registered as the gradients' homes with the kernels that produce them."""
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        dev = params[0].device if params else torch.device(self.device)
+        flat = torch.zeros(n, dtype=params[0].dtype if params else torch.float32, device=dev)  # (the pads stay zero)
+        views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
+        seg = self._segs[s] = {"flat": flat, "views": views, "params": params, "key": tuple(id(p) for p in params),
+                               "count": len(params), "checked": False, "moved": 0}
+        if dev.type == "cuda":
+            from hotrack_amd import train_stack as _ts
+            _ts.set_grad_homes((p, v) for sg in self._segs.values() for p, v in zip(sg["params"], sg["views"]))
+        return seg
 
     def _exchange(self, s, async_op=False):
         """All-reduce (mean) of segment s's flat buffer; returns the work handle (async_op) or None.  Never inside a capture."""
@@ -418,18 +467,6 @@ class Trainer(nn.Module):
         t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t[0]))
-
-    def _scatter_flat(self):
-        """The exchanged flat buffers of this step's segments back into the parameters' .grad tensors (one multi-tensor copy)."""
-        dst, views = [], []
-        for s in self._active_segs:
-            seg, off = self._segs[s], 0
-            for g in seg["grads"]:
-                views.append(seg["flat"][off:off + g.numel()].view_as(g))
-                dst.append(g)
-                off += g.numel()
-        if dst:
-            torch._foreach_copy_(dst, views)
 
     @property
     def _flat(self):
@@ -505,7 +542,8 @@ class Trainer(nn.Module):
         steps; it needs 0.3 ms per step against 3.3 ms on the device.  One graph executable, so its replays are strictly
         ordered: a prefetch still in flight is always waited for before the graph or its buffers are touched."""
         cur = torch.cuda.current_stream()
-        if self._geo_ready_for is not None:
+        probe = os.environ.get("HOTRACK_GEO_PROBE", "")  # timing probes only (profiles/r06_misc_measurements.md)
+        if self._geo_ready_for is not None and probe != "nowait":
             cur.wait_event(self._geo_done)
         inline = self._geo_ready_for is None or self._geo_ready_for is not data
         if inline:  # not prefetched: here and now, on this stream
@@ -522,11 +560,11 @@ class Trainer(nn.Module):
             self._geo_copied[1 - slot].synchronize()  # the copy that last read the other pack (previous step) has finished
             if inline:  # the graph has just been replayed on THIS stream: its next replay must not start beside that one
                 self._geo_copied[slot].synchronize()
-            with torch.cuda.stream(self._geo_stream):
+            with torch.cuda.stream(cur if probe == "samestream" else self._geo_stream):
                 self._copy_leaves(self._geo_in, next_data)
                 self._geo_graph.replay()
                 self._pack_geometry(1 - slot)
-                self._geo_done.record(self._geo_stream)
+                self._geo_done.record(cur if probe == "samestream" else self._geo_stream)
             self._geo_ready_for = next_data
 
     def _pack_geometry(self, slot):
@@ -606,7 +644,7 @@ class Trainer(nn.Module):
         keep = {"keep_graph": True} if os.environ.get("HOTRACK_KEEP_GRAPH", "0") == "1" else {}
         graph = torch.cuda.CUDAGraph(**keep)
         self._opt_graph = self._graph_rest = None
-        self._segs, self._active_segs = {}, []  # flat buffers of an earlier capture belong to its pool
+        self._segs, self._active_segs = {}, []  # (laid out again below, from the warm-up's gradients)
         rest = None
         from hotrack_amd import gemm_tuning
         try:
@@ -627,6 +665,9 @@ class Trainer(nn.Module):
                     for _ in range(2):
                         self._forward_backward(self._static, geo=self._static_geo)
                         self.optimizer.step()
+                    # (flat) which parameters received a gradient, per backward segment: the flat buffers are laid out from this
+                    # BEFORE the capture, so that the captured backward already writes its large gradients into them
+                    seg_lists = self._segments_from_grads() if flat else None
             finally:  # whatever happened, the step update() was called for starts from the state it was called with
                 torch.cuda.current_stream().wait_stream(side)
                 with torch.no_grad():
@@ -642,18 +683,21 @@ class Trainer(nn.Module):
                     if tail:
                         tail.rewind_dropout_counter(seed_snap)
                 self.optimizer.zero_grad(set_to_none=True)
+            if flat:
+                for s_, params_ in enumerate(seg_lists):
+                    self._layout_segment(s_, params_)
             with gemm_tuning.scope():
                 with torch.cuda.graph(graph):
                     self._static_loss, cut = self._fb_head(self._static, zero=False, geo=self._static_geo)
                     if flat:
-                        self._pack_segment(0, cut is not None, in_capture=True)
+                        self._settle_segment(0, cut is not None)
                     else:
                         self.optimizer.step()
                 if cut is not None:  # (flat only) the backbone's backward as its own graph: segment 0 travels beside it
                     rest = torch.cuda.CUDAGraph(**keep)
                     with torch.cuda.graph(rest, pool=graph.pool()):
                         self._fb_rest(cut)
-                        self._pack_segment(1, True, in_capture=True)
+                        self._settle_segment(1, True)
                 del cut
         except RuntimeError as exc:
             err = exc
@@ -666,8 +710,7 @@ class Trainer(nn.Module):
                 self._allreduce_flat()  # eager (collectives stay outside the graphs); also the collective layout checks
                 opt_graph = torch.cuda.CUDAGraph(**keep)
                 with torch.cuda.graph(opt_graph, pool=graph.pool()):
-                    self._scatter_flat()
-                    self.optimizer.step()
+                    self.optimizer.step()  # (every .grad is a view of an exchanged flat buffer: nothing to scatter)
             self._opt_graph, self._graph_rest = opt_graph, rest
             if rest is not None and self._comm_stream is None:
                 self._comm_stream, self._seg_done = torch.cuda.Stream(), torch.cuda.Event()

@@ -24,7 +24,7 @@ def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce
     args = add_args(argparse.ArgumentParser()).parse_args(["--config", "handtracknet_train_SimGrasp.yml"])
     args.num_points, args.batch_size = 1024, batch
     cfg = get_config(args, save=False)
-    cfg["graph_step"] = graph  # data parallel: forward+backward graphs (two segments) | flat all-reduces | Adam graph
+    cfg["graph_step"] = graph  # data parallel: forward+backward graph | all-reduce of the flat gradient buffer | Adam graph
     cfg.update(cfg_extra or {})
     torch.manual_seed(0)
     tr = Trainer(cfg)
@@ -88,6 +88,8 @@ def run_training_leg(steps, warmup, batch, graph, rank, world, measure_allreduce
             sync()
             res["allreduce_us"] = round(reduce_max(time.perf_counter() - t0) / 20 * 1e6, 1)
             res["segment_bytes"] = [int(f.numel() * f.element_size()) for f in tr._flat]
+            # bytes the per-step multi-tensor copy still moves into the flat buffers (gradients whose producers do not write there)
+            res["moved_bytes"] = [int(4 * tr._segs[s_].get("moved", 0)) for s_ in sorted(tr._segs)]
             res["bytes"] = int(sum(res["segment_bytes"]))
             last = sorted(tr._segs)[-1]
             sync()
@@ -110,7 +112,7 @@ def main():
     ap.add_argument("--dp-selftest", action="store_true",
                     help="ONE rank with a one-rank process group and dp=flat: the segmented backward + exchange path end to end "
                          "on one GPU (what it costs beside the single-graph step; the all-reduce is RCCL's one-rank path)")
-    ap.add_argument("--segments", type=int, default=None, help="dp=flat: backward segments (default 2)")
+    ap.add_argument("--segments", type=int, default=None, help="dp=flat: backward segments (default 1; 2 = everything after the backbone | the backbone)")
     ap.add_argument("--no-overlap", action="store_true", help="dp=flat: exchanges in stream order (A/B)")
     a = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))

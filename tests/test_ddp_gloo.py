@@ -61,8 +61,6 @@ def _worker(rank, world, port, tmp, q, mode):
     import copy
     solo = copy.deepcopy(tr.model)
     solo.train()
-    if hasattr(solo, "cut_backbone_grad"):
-        solo.cut_backbone_grad = False
     b0 = batch(100 * rank)
     flags = tr.init_flag_dict()
     ret = solo(b0, flags)
@@ -104,6 +102,11 @@ def _worker(rank, world, port, tmp, q, mode):
            "same_grad_set": same_set, "avg_err": err, "grad_scale": scale, "sum_err": sum_err,
            "shards_differ": bool(not torch.equal(shards[0], shards[1])),
            "segments": len(getattr(tr, "_active_segs", [])) if dp == "flat" else 0,
+           # the backward cut is requested per forward, never left set on the module
+           "cut_flag_left_set": bool(getattr(tr.model, "cut_backbone_grad", False)),
+           # zero-copy exchange: every gradient the optimiser reads lives inside a flat exchange buffer
+           "grads_in_flat": (all(any(f.data_ptr() <= p.grad.data_ptr() < f.data_ptr() + 4 * f.numel() for f in tr._flat)
+                                 for p in tr.model.parameters() if p.grad is not None) if dp == "flat" else True),
            "params_sha": hashlib.sha256(flat.numpy().tobytes()).hexdigest(), "params_sample": flat[::4099].clone()})
     dist.barrier()
     dist.destroy_process_group()
@@ -138,6 +141,7 @@ def test_ddp_two_ranks_gloo(tmp_path, mode):
         assert r["avg_err"] <= 1e-6 * max(1.0, r["grad_scale"]), r   # exchanged gradient == mean over ranks
         assert r["sum_err"] > 1e-3 * r["grad_scale"], r              # ... and the check can tell a sum from a mean
         assert r["segments"] == {"ddp": 0, "flat": 2, "flat1": 1}[mode]
+        assert not r["cut_flag_left_set"] and r["grads_in_flat"]
     assert res[0]["losses"] != res[1]["losses"]  # the ranks really saw different shards
 
 
