@@ -241,9 +241,6 @@ def main():
                     "(pn2x_sa_set_compute_units; a workgroup of that kernel fills its CU, the rest stay available to the other stream); "
                     "0 = all (default: 240 gives +0.7 %% frames/s with two batches in flight, but the SA launches themselves then run 8 "
                     "rounds of tiles instead of 7, i.e. the dominant kernel's own roofline fraction drops from 0.70 to 0.63)")
-    ap.add_argument("--split-geometry", action="store_true", help="each batch in flight as TWO graphs: the sampling / search prefix "
-                    "(hand frame, both sampling levels, k-NN lists: one workgroup per cloud) on a high-priority stream of its own, the "
-                    "dense rest on the normal stream behind an event (VERDICT r4 item 4; measured in profiles/r05_misc_measurements.md)")
     ap.add_argument("--inflight", type=int, default=4, help="number of batches in flight: step i is replayed on HIP stream "
                     "i %% inflight (each stream has its own captured graph and buffers), so one batch's FPS / small "
                     "kernels overlap another batch's GEMMs")
@@ -318,40 +315,16 @@ def main():
             graphs = []
             sa_cus = args.sa_cus if (ninf > 1 and fused_on and "PN2_SA_CUS" not in os.environ) else 0
             ext.sa_set_compute_units(sa_cus)  # grid sizes are baked into the graphs at capture
-            split = bool(args.split_geometry and getattr(model, "_fast", None))
-            hp_streams, geo_graphs, geo_done = [], [], []
-            if split:
-                prio_hi = torch.cuda.Stream.priority_range()[1]
-                hp_streams = [torch.cuda.Stream(priority=prio_hi) for _ in range(ninf)]
-                geo_done = [torch.cuda.Event() for _ in range(ninf)]
             for i in range(ninf):
                 g = torch.cuda.CUDAGraph()
-                if split:
-                    gg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gg, stream=hp_streams[i]):
-                        geo = model._fast.forward_geometry(slots[i][0], dict(FLAGS))
-                    with torch.cuda.graph(g, pool=gg.pool(), stream=gstreams[i]):
-                        outs[i] = model._fast.forward_dense(geo, dict(FLAGS))
-                    geo_graphs.append(gg)
-                else:
-                    with torch.cuda.graph(g):
-                        outs[i] = model(slots[i][0], dict(FLAGS))
+                with torch.cuda.graph(g):
+                    outs[i] = model(slots[i][0], dict(FLAGS))
                 graphs.append(g)
 
             def replay_slot(i, src_flat):
-                """Batch `src_flat` through slot i's graph(s), asynchronously."""
-                if not split:
-                    with torch.cuda.stream(gstreams[i]):
-                        slots[i][1].copy_(src_flat, non_blocking=True)
-                        graphs[i].replay()
-                    return
-                with torch.cuda.stream(hp_streams[i]):
-                    hp_streams[i].wait_stream(gstreams[i])  # the previous use of this slot's buffers (four steps ago) has drained
-                    slots[i][1].copy_(src_flat, non_blocking=True)
-                    geo_graphs[i].replay()
-                    geo_done[i].record(hp_streams[i])
+                """Batch `src_flat` through slot i's graph, asynchronously."""
                 with torch.cuda.stream(gstreams[i]):
-                    gstreams[i].wait_event(geo_done[i])
+                    slots[i][1].copy_(src_flat, non_blocking=True)
                     graphs[i].replay()
             g_single = None
             if ninf > 1:  # the single-stream reference point replays a graph captured with every CU available to the SA grids
@@ -553,7 +526,6 @@ def main():
                                       "runs its real pass for that cloud (value_tied_inputs, %d regions)" % len(tied_regions),
                        "dead_attention_elided": not args.no_elide, "fused_sa_kernels": fused_on,
                        "launch": "hipGraph replay" if use_graph else "eager", "batches_in_flight": ninf,
-                       "geometry_on_priority_stream": bool(use_graph and split),
                        "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "sa_compute_units": (sa_cus or 256) if use_graph else 256,
                        "single_stream_ms_per_step": None if single_ms is None else round(single_ms, 4),

@@ -156,7 +156,8 @@ struct PerDeviceOnce {
 
 // train_ops.hip: counting-sort inversion of an index list (offsets (b, n_dst+1), order (b, l)); PN2_ERANGE if n_dst does not fit LDS
 int inverse_index_launch(int b, int n_dst, int l, const int *idx, int *offsets, int *order, hipStream_t st);
-int inverse_index_chunked_launch(int b, int n_dst, int l, int mt, int nchunks, const int *idx, int *offsets, int *order, hipStream_t st);
+int inverse_index_chunked_launch(int b, int n_dst, int l, int mt, int nchunks, const int *idx, unsigned short *offsets, int off_stride,
+                                 unsigned short *order, hipStream_t st);
 // Device scratch for kernels whose C ABI (the reference's signatures) has no scratch argument: a STREAM-ORDERED temporary,
 // allocated (hipMallocAsync) before the enqueue and released (hipFreeAsync) right after it, in stream order -- the library keeps
 // nothing between calls (pn2_hip.h: "keeps no state"); the memory comes from and returns to the HIP runtime's own pool.

@@ -8,6 +8,7 @@
 // offsets + order, train_ops.hip) and a workgroup that owns (cloud, cc channels) stages its [cc][M] slice of grad_out in LDS
 // with coalesced loads; every (target i, channel) then SUMS its contributions with plain LDS reads and adds the result to
 // grad_points with one coalesced read-modify-write (the reference's accumulate-into-the-caller's-buffer semantics).
+#include <cstdlib>
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
@@ -110,71 +111,111 @@ cm_segment_sum_kernel(int c, int n_dst, int m_src, int cc, const float *__restri
 // running sums of ITS targets (thread t owns targets t, t + NT, ...) in registers across all chunks; one coalesced
 // read-modify-write of grad_points at the end.  No atomics, grad_out read exactly once, lists re-read from L2 by the
 // workgroups of the other channels.
-constexpr int kChCC = 2;     // channels per workgroup (parallelism: b * ceil(c / 2) workgroups)
+constexpr int kChMt = 4096;  // source positions per chunk (positions within a chunk and its list offsets fit 16 bits)
+constexpr int kChNT = 1024;
 
-template <int TPT, int NT>
-__global__ void __launch_bounds__(NT)
-cm_chunked_sum_kernel(int c, int n_dst, int m_src, int mt, int nchunks, const float *__restrict__ grad_out_all,
-                      const int *__restrict__ offsets_all, const int *__restrict__ order_all, float *__restrict__ grad_points_all) {
-    extern __shared__ __attribute__((aligned(16))) float G[];  // [kChCC][mt] | order [mt]
-    int *lord = reinterpret_cast<int *>(G + (size_t)kChCC * mt);
-    const int b = blockIdx.y, c0 = blockIdx.x * kChCC;
-    const int nc = (c - c0) < kChCC ? (c - c0) : kChCC;
+// Lists of a chunk as 16-bit words (half the list traffic, which is as large as the slab's): offsets [n_dst + 1 rounded up
+// to 8] per (cloud, chunk), order [m_src] per cloud holding positions relative to the chunk.
+__host__ __device__ inline size_t ch_off_stride(int n_dst) { return ((size_t)n_dst + 1 + 7) / 8 * 8; }
+
+template <int TPT, int CC>
+__global__ void __launch_bounds__(kChNT, CC <= 2 ? 8 : 4)  // CC <= 2: two workgroups per CU (64 registers, 80 KiB of LDS each)
+cm_chunked_sum_kernel(int c, int n_dst, int m_src, int nchunks, const float *__restrict__ grad_out_all,
+                      const unsigned short *__restrict__ offsets_all, const unsigned short *__restrict__ order_all,
+                      float *__restrict__ grad_points_all) {
+    constexpr int NT = kChNT, MT = kChMt;
+    static_assert(MT == 4 * NT, "a thread stages 4 consecutive positions of a chunk");
+    // two buffers of { [CC][MT] floats | MT 16-bit order entries }
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int kBufFloats = CC * MT + MT / 2;
+    const int b = blockIdx.y, c0 = blockIdx.x * CC;
+    const int nc = (c - c0) < CC ? (c - c0) : CC;
     const float *__restrict__ src = grad_out_all + ((size_t)b * c + c0) * m_src;
+    const unsigned short *__restrict__ ord_b = order_all + (size_t)b * m_src;
     const int i_base = blockIdx.z * (TPT * NT);  // clouds of more than TPT * NT points: one workgroup per target range
-    float acc[TPT][kChCC];
+    const bool vec = ((((uintptr_t)src) & 15) == 0) && (m_src % 4 == 0) && ((((uintptr_t)ord_b) & 7) == 0);
+    float acc[TPT][CC];
 #pragma unroll
     for (int j = 0; j < TPT; ++j)
 #pragma unroll
-        for (int u = 0; u < kChCC; ++u) acc[j][u] = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-        const int e0 = k * mt;
-        const int len = (m_src - e0) < mt ? (m_src - e0) : mt;
-        const int *__restrict__ off = offsets_all + ((size_t)b * nchunks + k) * (n_dst + 1);
-        const int *__restrict__ ord = order_all + (size_t)b * m_src + e0;
-        // this thread's list bounds (registers), requested together with the slab
-        int p0[TPT], p1[TPT];
+        for (int u = 0; u < CC; ++u) acc[j][u] = 0.f;
+    // staged registers of the NEXT chunk: this thread's 4 positions of every channel row, their order entries, its list bounds
+    float4 rg[CC];
+    uint2 ro;
+    unsigned rpq[TPT];  // list bounds of this thread's targets, packed (begin | end << 16)
+    // (two workgroups per CU, CC <= 2: 64 registers -- the bounds are then loaded where they are used, the other workgroup
+    // covers their latency)
+    constexpr bool kStageBounds = CC > 2;
+    auto bounds = [&](int k, unsigned (&out)[TPT]) {
+        const unsigned short *__restrict__ off = offsets_all + ((size_t)b * nchunks + k) * ch_off_stride(n_dst);
 #pragma unroll
         for (int j = 0; j < TPT; ++j) {
-            const int i = i_base + threadIdx.x + j * NT;
-            p0[j] = i < n_dst ? off[i] : 0;
-            p1[j] = i < n_dst ? off[i + 1] : 0;
+            const int i = i_base + (int)threadIdx.x + j * NT;
+            out[j] = i < n_dst ? ((unsigned)off[i] | ((unsigned)off[i + 1] << 16)) : 0u;
         }
-        __syncthreads();  // the previous chunk's readers are done with G / lord
-        for (int u = 0; u < nc; ++u) {
-            const float *__restrict__ row = src + (size_t)u * m_src + e0;
-            float *__restrict__ dstl = G + (size_t)u * mt;
-            if ((((uintptr_t)row) & 15) == 0) {
-                int i = threadIdx.x * 4;
-                for (; i + 3 < len; i += NT * 4) *reinterpret_cast<float4 *>(dstl + i) = *reinterpret_cast<const float4 *>(row + i);
-                for (; i < len; ++i) dstl[i] = row[i];  // (the last, partial quad of the one thread that meets it)
-            } else {
-                for (int i = threadIdx.x; i < len; i += NT) dstl[i] = row[i];
-            }
-        }
-        if ((((uintptr_t)ord) & 15) == 0) {
-            int i = threadIdx.x * 4;
-            for (; i + 3 < len; i += NT * 4) *reinterpret_cast<int4 *>(lord + i) = *reinterpret_cast<const int4 *>(ord + i);
-            for (; i < len; ++i) lord[i] = ord[i];
+    };
+    auto fetch = [&](int k) {
+        const int e0 = k * MT, e = e0 + 4 * (int)threadIdx.x;
+        if constexpr (kStageBounds) bounds(k, rpq);
+        if (vec && e + 3 < m_src) {
+#pragma unroll
+            for (int u = 0; u < CC; ++u)
+                rg[u] = u < nc ? *reinterpret_cast<const float4 *>(src + (size_t)u * m_src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ro = *reinterpret_cast<const uint2 *>(ord_b + e);
         } else {
-            for (int i = threadIdx.x; i < len; i += NT) lord[i] = ord[i];
+            float t[CC][4];
+            unsigned short o[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const bool in = e + x < m_src;
+                o[x] = in ? ord_b[e + x] : (unsigned short)0;
+#pragma unroll
+                for (int u = 0; u < CC; ++u) t[u][x] = (in && u < nc) ? src[(size_t)u * m_src + e + x] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < CC; ++u) rg[u] = make_float4(t[u][0], t[u][1], t[u][2], t[u][3]);
+            ro = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
         }
-        __syncthreads();
+    };
+    auto commit = [&](int buf) {
+        float *G = lds + (size_t)buf * kBufFloats;
+#pragma unroll
+        for (int u = 0; u < CC; ++u) *reinterpret_cast<float4 *>(G + u * MT + 4 * threadIdx.x) = rg[u];
+        *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(G + CC * MT) + 4 * threadIdx.x) = ro;
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int k = 0; k < nchunks; ++k) {
+        unsigned pq[TPT];
+        if constexpr (kStageBounds) {
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) pq[j] = rpq[j];
+        } else {
+            bounds(k, pq);
+        }
+        if (k + 1 < nchunks) fetch(k + 1);  // in flight while this chunk is summed
+        const float *G = lds + (size_t)(k & 1) * kBufFloats;
+        const unsigned short *lord = reinterpret_cast<const unsigned short *>(G + CC * MT);
 #pragma unroll
         for (int j = 0; j < TPT; ++j) {
-            for (int p = p0[j]; p < p1[j]; ++p) {
+            for (int p = (int)(pq[j] & 0xffffu), p1 = (int)(pq[j] >> 16); p < p1; ++p) {
                 const int e = lord[p];
 #pragma unroll
-                for (int u = 0; u < kChCC; ++u) acc[j][u] += G[(size_t)u * mt + e];  // (row 1 of a one-channel tail holds stale data: never stored)
+                for (int u = 0; u < CC; ++u) acc[j][u] += G[u * MT + e];
             }
         }
+        if (k + 1 < nchunks) commit((k + 1) & 1);  // (its previous readers passed the barrier of the last iteration)
+        __syncthreads();
     }
     float *__restrict__ dst = grad_points_all + ((size_t)b * c + c0) * n_dst;
 #pragma unroll
     for (int j = 0; j < TPT; ++j) {
-        const int i = i_base + threadIdx.x + j * NT;
+        const int i = i_base + (int)threadIdx.x + j * NT;
         if (i < n_dst) {
-            for (int u = 0; u < nc; ++u) dst[(size_t)u * n_dst + i] += acc[j][u];
+#pragma unroll
+            for (int u = 0; u < CC; ++u)
+                if (u < nc) dst[(size_t)u * n_dst + i] += acc[j][u];
         }
     }
 }
@@ -185,33 +226,61 @@ static int chunked_mt(int t, int n_dst, int m_src) {
     const size_t l = (size_t)m_src;
     const size_t meta = (size_t)n_dst + 1 + l;
     if (!((size_t)n_dst + 1 + 256 > 16384 || meta + m_src > 16384)) return 0;  // fits the one-slab kernel
-    return m_src < 8192 ? ((m_src + 3) / 4 * 4) : 8192;
+    return kChMt;
 }
 
 size_t scatter_cm_scratch_ints(int t, int b, int n_dst, int m_src) {
-    if (const int mt = chunked_mt(t, n_dst, m_src)) {
-        const size_t nchunks = ((size_t)m_src + mt - 1) / mt;
-        return (size_t)b * (nchunks * ((size_t)n_dst + 1) + (size_t)m_src);
+    if (chunked_mt(t, n_dst, m_src)) {
+        const size_t nchunks = ((size_t)m_src + kChMt - 1) / kChMt;
+        const size_t u16 = (size_t)b * (nchunks * ch_off_stride(n_dst) + ((size_t)m_src + 7) / 8 * 8);
+        return (u16 + 1) / 2;
     }
     return (size_t)b * ((size_t)n_dst + 1 + (size_t)m_src * t);
 }
 
-template <int TPT, int NT>
-static int launch_chunked(int b, int c, int n_dst, int m_src, int mt, int nchunks, const float *grad_out, const int *offsets,
-                          const int *order, float *grad_points, hipStream_t st) {
-    const size_t lds = ((size_t)kChCC * mt + mt) * sizeof(float);
+template <int TPT, int CC>
+static int launch_chunked(int b, int c, int n_dst, int m_src, int nchunks, const float *grad_out, const unsigned short *offsets,
+                          const unsigned short *order, float *grad_points, hipStream_t st) {
+    const size_t lds = 2 * ((size_t)CC * kChMt + kChMt / 2) * sizeof(float);
     static bool attr_ok = false, attr_tried = false;  // (per kernel instantiation)
     if (!attr_tried) {
         attr_tried = true;
-        attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&cm_chunked_sum_kernel<TPT, NT>),
+        attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&cm_chunked_sum_kernel<TPT, CC>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
         if (!attr_ok) (void)hipGetLastError();
     }
     if (lds > 64 * 1024 && !attr_ok) return PN2_ERANGE;  // (the caller falls back to the slab / atomic kernels)
-    hipLaunchKernelGGL((cm_chunked_sum_kernel<TPT, NT>), dim3((c + kChCC - 1) / kChCC, b, (n_dst + TPT * NT - 1) / (TPT * NT)), dim3(NT), lds, st,
-                       c, n_dst, m_src, mt, nchunks,
-                       grad_out, offsets, order, grad_points);
+    hipLaunchKernelGGL((cm_chunked_sum_kernel<TPT, CC>), dim3((c + CC - 1) / CC, b, (n_dst + TPT * kChNT - 1) / (TPT * kChNT)), dim3(kChNT), lds,
+                       st, c, n_dst, m_src, nchunks, grad_out, offsets, order, grad_points);
     return check_launch();
+}
+
+// channels per workgroup: whole rounds of b * ceil(c / cc) workgroups on the chip's CUs, each moving cc slab rows + the lists
+static int chunked_cc(int b, int c, int n_dst, int m_src) {
+    static int cus = 0;  // (queried once: the library is built for one architecture, boxes hold one kind of device)
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) {
+            cus = n;
+        } else {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+    }
+    if (const char *e = getenv("PN2_SCM_CC")) {  // tuning probe
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4) return v;
+    }
+    const long zs = (n_dst + 8 * kChNT - 1) / (8 * kChNT);
+    const double lists = 0.5 * m_src + 0.5 * ((double)m_src / kChMt) * n_dst;  // in floats
+    int best = 1;
+    double best_cost = 0;
+    for (int cc = 1; cc <= 4; ++cc) {
+        const long wgs = (long)b * ((c + cc - 1) / cc) * zs;
+        const double cost = (double)((wgs + cus - 1) / cus) * (cc * (double)m_src + lists);
+        if (cc == 1 || cost < best_cost) { best = cc; best_cost = cost; }
+    }
+    return best;
 }
 
 int scatter_cm_dispatch(int t, int b, int c, int n_dst, int m_src, const float *grad_out, const int *idx, const float *weight,
@@ -231,12 +300,20 @@ int scatter_cm_dispatch(int t, int b, int c, int n_dst, int m_src, const float *
     }
     if (mt) {
         const int nchunks = (m_src + mt - 1) / mt;
-        int *offsets = scratch, *order = scratch + (size_t)b * nchunks * ((size_t)n_dst + 1);
-        int rc = inverse_index_chunked_launch(b, n_dst, m_src, mt, nchunks, idx, offsets, order, st);
+        unsigned short *offsets = reinterpret_cast<unsigned short *>(scratch);
+        unsigned short *order = offsets + (size_t)b * nchunks * ch_off_stride(n_dst);
+        int rc = inverse_index_chunked_launch(b, n_dst, m_src, mt, nchunks, idx, offsets, (int)ch_off_stride(n_dst), order, st);
         if (rc != PN2_OK) return rc;
-        constexpr int NT = 1024;
-        if (n_dst <= 4 * NT) return launch_chunked<4, NT>(b, c, n_dst, m_src, mt, nchunks, grad_out, offsets, order, grad_points, st);
-        return launch_chunked<8, NT>(b, c, n_dst, m_src, mt, nchunks, grad_out, offsets, order, grad_points, st);
+        const bool small = n_dst <= 4 * kChNT;
+#define PN2_CH(CC) (small ? launch_chunked<4, CC>(b, c, n_dst, m_src, nchunks, grad_out, offsets, order, grad_points, st) \
+                          : launch_chunked<8, CC>(b, c, n_dst, m_src, nchunks, grad_out, offsets, order, grad_points, st))
+        switch (chunked_cc(b, c, n_dst, m_src)) {
+            case 1: return PN2_CH(1);
+            case 2: return PN2_CH(2);
+            case 3: return PN2_CH(3);
+            default: return PN2_CH(4);
+        }
+#undef PN2_CH
     }
     int cc = (int)((16384 - meta) / m_src);
     if (cc > 16) cc = 16;

@@ -837,14 +837,45 @@ inverse_index_kernel(int n_dst, int L, const int *__restrict__ idx_all, int *__r
     inverse_index_body(n_dst, L, idx_all + (size_t)b * L, offsets_all + (size_t)b * (n_dst + 1), order_all + (size_t)b * L);
 }
 
-// The same sort for every chunk of mt consecutive positions of a cloud's list on its own (scatter_cm.hip, long lists):
-// workgroup (cloud b, chunk k) -> offsets [b][k][n_dst + 1], order [b][k * mt ...] holding positions RELATIVE to the chunk.
+// The same sort for every chunk of mt consecutive positions of a cloud's list on its own (scatter_cm.hip, long lists), with
+// 16-bit outputs (mt <= 65535): workgroup (cloud b, chunk k) -> offsets [b][k][off_stride], order [b][k * mt ...] holding
+// positions RELATIVE to the chunk.
 __global__ void __launch_bounds__(kTT)
-inverse_index_chunked_kernel(int n_dst, int L, int mt, int nchunks, const int *__restrict__ idx_all, int *__restrict__ offsets_all,
-                             int *__restrict__ order_all) {
+inverse_index_chunked_kernel(int n_dst, int L, int mt, int nchunks, int off_stride, const int *__restrict__ idx_all,
+                             unsigned short *__restrict__ offsets_all, unsigned short *__restrict__ order_all) {
+    extern __shared__ int cnt[];  // [n_dst + 1] counts -> running cursors; then [kTT] chunk totals
+    int *part = cnt + n_dst + 1;
     const int b = blockIdx.x / nchunks, k = blockIdx.x - b * nchunks;
     const int e0 = k * mt, len = (L - e0) < mt ? (L - e0) : mt;
-    inverse_index_body(n_dst, len, idx_all + (size_t)b * L + e0, offsets_all + (size_t)blockIdx.x * (n_dst + 1), order_all + (size_t)b * L + e0);
+    const int *__restrict__ idx = idx_all + (size_t)b * L + e0;
+    unsigned short *__restrict__ offsets = offsets_all + (size_t)blockIdx.x * off_stride;
+    unsigned short *__restrict__ order = order_all + (size_t)b * L + e0;
+    for (int i = threadIdx.x; i <= n_dst; i += kTT) cnt[i] = 0;
+    __syncthreads();
+    auto key = [&](int e) { const int t = idx[e]; return t < 0 ? 0 : (t >= n_dst ? n_dst - 1 : t); };
+    for (int e = threadIdx.x; e < len; e += kTT) atomicAdd(&cnt[key(e)], 1);
+    __syncthreads();
+    const int chunk = (n_dst + kTT - 1) / kTT;
+    const int i0 = threadIdx.x * chunk, i1 = (i0 + chunk) < n_dst ? (i0 + chunk) : n_dst;
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) sum += cnt[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < kTT; ++t) { const int v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = i0; i < i1; ++i) {
+        const int v = cnt[i];
+        offsets[i] = (unsigned short)run;
+        cnt[i] = run;  // cursor
+        run += v;
+    }
+    if (threadIdx.x == 0) offsets[n_dst] = (unsigned short)len;
+    __syncthreads();
+    for (int e = threadIdx.x; e < len; e += kTT) order[atomicAdd(&cnt[key(e)], 1)] = (unsigned short)e;
 }
 
 // acc += sum over p = p0, p0 + step, ... < p1 of [w] . row(order[p]), in that order.  Four list entries per round: their source
@@ -1546,10 +1577,12 @@ int inverse_index_launch(int b, int n_dst, int l, const int *idx, int *offsets, 
     return check_launch();
 }
 
-int inverse_index_chunked_launch(int b, int n_dst, int l, int mt, int nchunks, const int *idx, int *offsets, int *order, hipStream_t st) {
+int inverse_index_chunked_launch(int b, int n_dst, int l, int mt, int nchunks, const int *idx, unsigned short *offsets, int off_stride,
+                                 unsigned short *order, hipStream_t st) {
     const size_t lds = ((size_t)n_dst + 1 + kTT) * sizeof(int);
-    if (lds > 64 * 1024 || mt < 1 || (long)nchunks * mt < l) return PN2_ERANGE;
-    hipLaunchKernelGGL(inverse_index_chunked_kernel, dim3((unsigned)(b * nchunks)), dim3(kTT), lds, st, n_dst, l, mt, nchunks, idx, offsets, order);
+    if (lds > 64 * 1024 || mt < 1 || mt > 65535 || (long)nchunks * mt < l || off_stride < n_dst + 1) return PN2_ERANGE;
+    hipLaunchKernelGGL(inverse_index_chunked_kernel, dim3((unsigned)(b * nchunks)), dim3(kTT), lds, st, n_dst, l, mt, nchunks, off_stride, idx,
+                       offsets, order);
     return check_launch();
 }
 }  // namespace pn2

@@ -430,34 +430,11 @@ LINEAR_SMALL_MAX_ROWS = int(__import__("os").environ.get("HOTRACK_LINEAR_SMALL_M
 LINEAR_SMALL_MAX_K, LINEAR_SMALL_MAX_N = 384, 512
 
 
-_lib.pn2x_linear_k128_supported.argtypes = [_ci, _ci]
-_lib.pn2x_linear_k128_supported.restype = _ci
-_lib.pn2x_linear_k128.argtypes = [ctypes.c_long, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp]
-_lib.pn2x_linear_k128.restype = _ci
-# HOTRACK_LINEAR_K128_MIN_ROWS = n > 0: 128-deep layers over at least n rows run through pn2x_linear_k128 (both MFMA operands in
-# registers, no LDS).  OFF by default: alone it is at parity with the library's recorded solution on the one layer it is for (65536 x
-# 128 -> 384: 69.4 vs 72.3 us; 0.76 of the matrix peak in its block loop, ~10 us of start-up per launch) and it LOSES with four
-# batches in flight (87.1 k vs 89.2 k frames/s: eight 194-register waves per CU leave the other streams' latency chains nowhere to
-# run) -- profiles/r05_misc_measurements.md
-LINEAR_K128_MIN_ROWS = int(__import__("os").environ.get("HOTRACK_LINEAR_K128_MIN_ROWS", "0"))
-
-
 def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, relu: bool = False) -> torch.Tensor:
     """act(x w^T + bias) for x (M, K) rows, w (N, K): small problems (the B = 1 / B = 8 tracking loop; bounds above) through
-    pn2x_linear_small (one workgroup per 32 x 32 output block), 128-deep layers over many rows through pn2x_linear_k128, everything
-    else through the BLAS library (torch, with its fused bias + ReLU epilogue).  Inference only."""
+    pn2x_linear_small (one workgroup per 32 x 32 output block), everything else through the BLAS library (torch, with its fused bias + ReLU epilogue).  Inference only."""
     M, K = x.shape
     N = w.shape[0]
-    if (K == 128 and LINEAR_K128_MIN_ROWS and M >= LINEAR_K128_MIN_ROWS and _lib.pn2x_linear_k128_supported(K, N) and x.is_cuda
-            and x.dtype == torch.float32 and w.dtype == torch.float32 and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0
-            and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and (bias is None or bias.is_contiguous())
-            and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))):
-        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            _native._check(_lib.pn2x_linear_k128(M, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
-                                                 None if bias is None else bias.data_ptr(), 1 if relu else 0, y.data_ptr(), N,
-                                                 _native._stream(x)), "linear_k128")
-        return y
     if (M > LINEAR_SMALL_MAX_ROWS or M < 2 or K > LINEAR_SMALL_MAX_K or N > LINEAR_SMALL_MAX_N or not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32 or x.stride(1) != 1
             or w.stride(1) != 1 or (bias is not None and not bias.is_contiguous()) or torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
         if relu and bias is not None:

@@ -644,15 +644,6 @@ long pn2x_wgrad_multi_scratch_floats(int count, const int *rows, const int *n, c
 int pn2x_wgrad_multi(int count, const float *const *g, const int *ldg, const float *const *x, const int *ldx, const int *rows,
                      const int *n, const int *k, float *const *dw, const int *lddw, float *scratch, long scratch_floats, void *stream);
 
-/* y (rows x n, row stride ldy) = act(x (rows x 128, row stride ldx) . w^T (w: n x 128, row stride ldw) + bias (n | NULL)), relu != 0:
- * ReLU -- a dense layer with a 128-deep reduction over MANY rows (csrc/linear_k128.hip; the backbone's last per-point layer conv1 + bn1
- * folded, reference backbones.py:131-133: 65536 x 128 -> 384 at batch 64).  Both operands of v_mfma_f32_16x16x4_f32 in registers: a
- * wave keeps its 16 / 32 / 48 columns of w for the whole launch and fetches 16-row blocks of x straight from memory -- no LDS, no
- * barrier.  n in {128, 256, 384} (pn2x_linear_k128_supported); same result as the BLAS library up to summation order. */
-int pn2x_linear_k128_supported(int k, int n);
-int pn2x_linear_k128(long rows, int n, const float *x, int ldx, const float *w, int ldw, const float *bias, int relu, float *y, int ldy,
-                     void *stream);
-
 /* y (m x n, row stride ldy) = act(x (m x k) . w^T (w: n x k) + bias (n | NULL)), relu != 0: ReLU -- a dense layer over FEW rows
  * (the B = 1 tracking loop: 21 ... 1024 rows; csrc/linear_small.hip): one workgroup per 32 x 32 output block, its four waves
  * splitting the reduction.  Same result as the BLAS library up to summation order. */

@@ -231,19 +231,6 @@ class FastEval:
         G = self._geometry(input, flag_dict)
         return None if G is None else self._dense(G, flag_dict)
 
-    # The forward in two halves, for callers that launch them on different streams (bench.py --split-geometry: the sampling /
-    # search prefix -- one workgroup per cloud, latency chains -- as its own graph on a high-priority stream, the dense rest on
-    # the normal one).  forward_dense(forward_geometry(x)) == forward(x).
-    def forward_geometry(self, input, flag_dict):
-        from hotrack_amd import gemm_tuning
-        with gemm_tuning.scope(tune=False):
-            return self._geometry(input, flag_dict)
-
-    def forward_dense(self, G, flag_dict):
-        from hotrack_amd import gemm_tuning
-        with gemm_tuning.scope(tune=False):
-            return self._dense(G, flag_dict)
-
     def _geometry(self, input, flag_dict):
         from hotrack_amd import ext
         from hotrack_amd import pointnet2_utils as ops

@@ -591,59 +591,6 @@ def test_ln_linear_equals_layernorm_then_linear(rows, C, N, two, resid):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 7])
-def test_forward_in_two_halves_equals_forward(B):
-    """FastEval.forward_dense(forward_geometry(x)) == forward(x), bit for bit, eagerly and as two graphs on two streams (the
-    geometry half on a high-priority stream, the dense half behind its event: bench.py --split-geometry)."""
-    from hotrack_amd import fused, pointnet2_utils
-    from models import pointnet_utils
-    from models.hand_network import HandTrackNet
-    pointnet_utils.set_operator_backend(pointnet2_utils)
-    torch.manual_seed(0)
-    model = HandTrackNet(make_cfg("cuda"))
-    deterministic_init(model)
-    model = model.cuda().eval()
-    flags = {"track_flag": False, "test_flag": True, "save_flag": False, "IKNet_flag": False}
-
-    def to_dev(d):
-        return {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in d.items()}
-
-    a, b = to_dev(synthetic_frames(31, B, 1024)), to_dev(synthetic_frames(32, B, 1024))
-    try:
-        pointnet_utils.set_fused_backend(fused)
-        with torch.no_grad():
-            ref_a, ref_b = model(a, dict(flags))["pred_kp"].clone(), model(b, dict(flags))["pred_kp"].clone()
-            fast = model._fast
-            assert fast, "the point-major path must be the one that ran"
-            two = fast.forward_dense(fast.forward_geometry(a, dict(flags)), dict(flags))
-            assert torch.equal(two["pred_kp"], ref_a)
-            slot = to_dev(synthetic_frames(31, B, 1024))
-            hp, st = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1]), torch.cuda.Stream()
-            gg, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(gg, stream=hp):
-                geo = fast.forward_geometry(slot, dict(flags))
-            with torch.cuda.graph(gd, pool=gg.pool(), stream=st):
-                out = fast.forward_dense(geo, dict(flags))["pred_kp"]
-            ev = torch.cuda.Event()
-            for src, ref in ((b, ref_b), (a, ref_a), (b, ref_b)):
-                with torch.cuda.stream(hp):
-                    hp.wait_stream(st)
-                    for k in ("jittered_hand_kp", "hand_points"):
-                        slot[k].copy_(src[k], non_blocking=True)
-                    slot["gt_hand_pose"]["palm_template"].copy_(src["gt_hand_pose"]["palm_template"], non_blocking=True)
-                    gg.replay()
-                    ev.record(hp)
-                with torch.cuda.stream(st):
-                    st.wait_event(ev)
-                    gd.replay()
-                st.synchronize()
-                assert torch.equal(out, ref)
-    finally:
-        pointnet_utils.set_fused_backend(None)
-
-
-@pytest.mark.gpu
 def test_fast_path_nan_contract():
     """NaN behaviour of the fused inference path, pinned against torch (the module path = the reference's composition).
     The fused kernels drop NaNs in their ReLU / max-pool maxima (sa_fused.hip is built -fno-honor-nans), so the path
@@ -691,33 +638,3 @@ def test_fast_path_nan_contract():
             assert model._fast.finite_weights and torch.equal(again, good)
     finally:
         pointnet_utils.set_fused_backend(None)
-
-
-@pytest.mark.parametrize("rows,n,relu,bias", [(65536, 384, True, True), (16, 384, True, True), (1, 128, False, False), (1000, 256, True, True),
-                                              (4099, 384, False, True), (33, 384, True, False)])
-def test_linear_k128_matches_torch(rows, n, relu, bias):
-    """pn2x_linear_k128 (both MFMA operands in registers, no LDS; the backbone's conv1 + bn1 layer, reference backbones.py:131-133)
-    against torch.nn.functional.linear in fp64: ragged row counts (blocks of 16, workgroups that own an odd number of blocks), a
-    padded input row stride and an output written into a column block of a wider buffer; nothing outside the block is touched."""
-    import ctypes
-    from hotrack_amd import ext
-    lib = ext._lib
-    g = torch.Generator(device="cuda").manual_seed(rows + n)
-    xw = torch.randn(rows, 132, device="cuda", generator=g)
-    x = xw[:, :128]
-    w = torch.randn(n, 128, device="cuda", generator=g) * 0.2
-    b = torch.randn(n, device="cuda", generator=g) if bias else None
-    out = torch.full((rows + 3, n + 8), 9.0, device="cuda")
-    y = out[:rows, 4:4 + n]
-    rc = lib.pn2x_linear_k128(rows, n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), None if b is None else b.data_ptr(), 1 if relu else 0,
-                              y.data_ptr(), y.stride(0), torch.cuda.current_stream().cuda_stream)
-    assert rc == 0
-    torch.cuda.synchronize()
-    ref = torch.nn.functional.linear(x.double(), w.double(), None if b is None else b.double())
-    if relu:
-        ref = torch.relu(ref)
-    assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
-    keep = torch.ones_like(out, dtype=torch.bool)
-    keep[:rows, 4:4 + n] = False
-    assert bool((out[keep] == 9.0).all())
-    assert lib.pn2x_linear_k128_supported(128, 192) == 0 and lib.pn2x_linear_k128_supported(64, 384) == 0
