@@ -8,7 +8,6 @@
 // offsets + order, train_ops.hip) and a workgroup that owns (cloud, cc channels) stages its [cc][M] slice of grad_out in LDS
 // with coalesced loads; every (target i, channel) then SUMS its contributions with plain LDS reads and adds the result to
 // grad_points with one coalesced read-modify-write (the reference's accumulate-into-the-caller's-buffer semantics).
-#include <cstdlib>
 #include "pn2_common.h"
 #include "../../include/pn2_ext.h"
 
@@ -111,6 +110,12 @@ cm_segment_sum_kernel(int c, int n_dst, int m_src, int cc, const float *__restri
 // running sums of ITS targets (thread t owns targets t, t + NT, ...) in registers across all chunks; one coalesced
 // read-modify-write of grad_points at the end.  No atomics, grad_out read exactly once, lists re-read from L2 by the
 // workgroups of the other channels.
+// What bounds it now (rocprofv3, stress shape 8 x 67 x 8192 <- 131072: sum kernel 138 us + chunk inversion 30 us = 1.76 TB/s; 97 us
+// for ONE cloud on an otherwise idle chip): not bandwidth but instruction issue -- a chunk holds ~0.5 entries per target, and a thread
+// runs one short data-dependent loop per target it owns (8 loops, each as long as the longest list among the wave's lanes):
+// ~3 us per chunk x 32 chunks.  Tried and slower: four targets in lockstep rounds (selects + a longer common loop: 148 us idle),
+// 8 CONSECUTIVE targets per thread as one run with a select cascade per entry (VALU-bound: 133 us idle), the first two entries
+// of every target predicated without a loop (128 registers and spills).
 constexpr int kChMt = 4096;  // source positions per chunk (positions within a chunk and its list offsets fit 16 bits)
 constexpr int kChNT = 1024;
 
@@ -119,7 +124,7 @@ constexpr int kChNT = 1024;
 __host__ __device__ inline size_t ch_off_stride(int n_dst) { return ((size_t)n_dst + 1 + 7) / 8 * 8; }
 
 template <int TPT, int CC>
-__global__ void __launch_bounds__(kChNT, CC <= 2 ? 8 : 4)  // CC <= 2: two workgroups per CU (64 registers, 80 KiB of LDS each)
+__global__ void __launch_bounds__(kChNT)
 cm_chunked_sum_kernel(int c, int n_dst, int m_src, int nchunks, const float *__restrict__ grad_out_all,
                       const unsigned short *__restrict__ offsets_all, const unsigned short *__restrict__ order_all,
                       float *__restrict__ grad_points_all) {
@@ -143,9 +148,7 @@ cm_chunked_sum_kernel(int c, int n_dst, int m_src, int nchunks, const float *__r
     float4 rg[CC];
     uint2 ro;
     unsigned rpq[TPT];  // list bounds of this thread's targets, packed (begin | end << 16)
-    // (two workgroups per CU, CC <= 2: 64 registers -- the bounds are then loaded where they are used, the other workgroup
-    // covers their latency)
-    constexpr bool kStageBounds = CC > 2;
+    constexpr bool kStageBounds = true;  // (false: bounds loaded where they are used -- 8 registers fewer, one more round trip per chunk)
     auto bounds = [&](int k, unsigned (&out)[TPT]) {
         const unsigned short *__restrict__ off = offsets_all + ((size_t)b * nchunks + k) * ch_off_stride(n_dst);
 #pragma unroll
@@ -266,10 +269,6 @@ static int chunked_cc(int b, int c, int n_dst, int m_src) {
             (void)hipGetLastError();
             cus = 256;
         }
-    }
-    if (const char *e = getenv("PN2_SCM_CC")) {  // tuning probe
-        const int v = atoi(e);
-        if (v >= 1 && v <= 4) return v;
     }
     const long zs = (n_dst + 8 * kChNT - 1) / (8 * kChNT);
     const double lists = 0.5 * m_src + 0.5 * ((double)m_src / kChMt) * n_dst;  // in floats

@@ -861,12 +861,15 @@ inverse_index_chunked_kernel(int n_dst, int L, int mt, int nchunks, int off_stri
     for (int i = i0; i < i1; ++i) sum += cnt[i];
     part[threadIdx.x] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int t = 0; t < kTT; ++t) { const int v = part[t]; part[t] = run; run += v; }
+    // exclusive scan of the kTT partial sums: Hillis-Steele in LDS (8 steps; one thread walking them was 256 dependent LDS
+    // round trips, a third of this launch)
+    for (int d = 1; d < kTT; d <<= 1) {
+        const int v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
     }
-    __syncthreads();
-    int run = part[threadIdx.x];
+    int run = part[threadIdx.x] - sum;
     for (int i = i0; i < i1; ++i) {
         const int v = cnt[i];
         offsets[i] = (unsigned short)run;
