@@ -996,13 +996,14 @@ rows_segment_sum_split_kernel(int n_dst, int m_src, int Q, int EL, const float *
     }
 }
 
-static int rows_per_block_for(long rows, int C) {
+static int rows_per_block_for(long rows, int C, bool stats_only = false) {
     const int rpp = kTT / (C >> 2);
     long rpb = (rows + 1023) / 1024;  // ~1024 workgroups on a large problem
     // A thread walks rows_per_block / rpp rows.  Small tensors (the 4096 - 8192-row stacks of a 32-cloud step: <= 8 MB) used
     // to get 16 rows per thread like the large ones -- 32 - 64 workgroups, each thread a chain of 16 dependent-in-time round
     // trips: 9 - 10 us for a 4 MB tensor.  Four rows per thread (all four loads in flight, see the kernels) fill the chip.
-    const long min_rows = (rows * C <= (2L << 20) ? 4L : 16L) * rpp;
+    // (not the statistics pass: its cost at this size is the 2 C fp64 atomics per workgroup: 38 -> 52 us over a step's seven launches)
+    const long min_rows = ((rows * C <= (2L << 20) && !stats_only) ? 4L : 16L) * rpp;
     if (rpb < min_rows) rpb = min_rows;
     return (int)rpb;
 }
@@ -1016,7 +1017,7 @@ extern "C" int pn2x_bn_stats(long rows, int c, const float *y, int ldy, double *
     if (rows < 1 || bad_c(c) || ldy < c || ldy % 4) return PN2_EINVAL;
     if (!y || !sums) return PN2_ENULL;
     if (((uintptr_t)y) % 16) return PN2_EINVAL;
-    const int rpb = rows_per_block_for(rows, c);
+    const int rpb = rows_per_block_for(rows, c, true);
     hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kTT), 0, (hipStream_t)stream, rows, c, y, ldy, rpb, sums);
     return check_launch();
 }

@@ -250,6 +250,23 @@ def scatter_add_rows(dout: torch.Tensor, idx: torch.Tensor, din: torch.Tensor) -
     return din
 
 
+_group_list_cache = {}
+
+
+def _group_lists(B: int, G: int, K: int, dev):
+    """(offsets (B, G + 1), order (B, G K)) of the trivial lists "target g <- rows g K ... g K + K - 1": what inverse_index would
+    return for idx[b, r] = r // K.  Constant per shape: built once, eagerly (never inside a graph capture) and kept."""
+    key = (B, G, K, dev)
+    t = _group_list_cache.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("train_ops: group lists of a new shape requested inside a graph capture (run one eager step first)")
+        off = (torch.arange(G + 1, dtype=torch.int32, device=dev) * K).unsqueeze(0).expand(B, -1).contiguous()
+        order = torch.arange(G * K, dtype=torch.int32, device=dev).unsqueeze(0).expand(B, -1).contiguous()
+        t = _group_list_cache[key] = (off, order)
+    return t
+
+
 class _SaLayer1(torch.autograd.Function):
     """One module call = all its scales: a1f (B,N,sum C1) | None, cadd (B,S,sum C1) | None, then per scale (idx_i, wx_i)."""
 
@@ -326,6 +343,20 @@ class _SaLayer1(torch.autograd.Function):
                     blk_a.stride(1), db_.shape[1], cb, db_.data_ptr(), db_.stride(1), invs[2].data_ptr(), invs[3].data_ptr(), blk_b.data_ptr(),
                     blk_b.stride(1), 0, _native._stream(da)), "rows_segment_sum_pair")
             paired = True
+        # the centre term's gradient = per centroid the sum of its K consecutive rows: for two scales ONE segment-sum launch over
+        # trivial lists (group g <- rows g K ... g K + K - 1) instead of two torch reductions
+        cadd_done = False
+        if d_cadd is not None and PAIR_SCALES and n == 2 and S <= INVERSE_MAX_ROWS:
+            (da, db_), Bq = douts, douts[0].shape[0]
+            ca, cb = da.shape[2], db_.shape[2]
+            ga, gb = _group_lists(Bq, S, da.shape[1] // S, dev), _group_lists(Bq, S, db_.shape[1] // S, dev)
+            blk_a, blk_b = d_cadd[:, :, :ca], d_cadd[:, :, ca:ca + cb]
+            with torch.cuda.device(dev):
+                _native._check(_lib.pn2x_rows_segment_sum_pair(
+                    Bq, S, da.shape[1], ca, da.data_ptr(), da.stride(1), ga[0].data_ptr(), ga[1].data_ptr(), blk_a.data_ptr(), blk_a.stride(1),
+                    db_.shape[1], cb, db_.data_ptr(), db_.stride(1), gb[0].data_ptr(), gb[1].data_ptr(), blk_b.data_ptr(), blk_b.stride(1), 0,
+                    _native._stream(da)), "rows_segment_sum_pair")
+            cadd_done = True
         for i, (dy, idx, rel) in enumerate(zip(douts, idxs, rels)):
             B, SK, C1 = dy.shape
             if paired:
@@ -335,7 +366,7 @@ class _SaLayer1(torch.autograd.Function):
                 rows_segment_sum(dy, inv, a1f_shape[1], d_a1f[:, :, col:col + C1])
             elif d_a1f is not None:
                 scatter_add_rows(dy, idx.view(B, SK), d_a1f[:, :, col:col + C1])
-            if d_cadd is not None:
+            if d_cadd is not None and not cadd_done:
                 torch.sum(dy.view(B, S, SK // S, C1), dim=2, out=d_cadd[:, :, col:col + C1])
             ready = ctx.aux["dwx"].pop(i, None) if ctx.aux is not None else None
             if ready is not None:  # formed by the consumer's first-layer backward (pn2x_bn_bwd_apply_rel)
