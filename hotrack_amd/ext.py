@@ -206,7 +206,8 @@ def mlp2_rows_supported(c1: int, c2: int, c3: int) -> bool:
 def mlp2_rows(x: torch.Tensor, w2, b2, w3, b3, out: torch.Tensor = None, w2e=None) -> torch.Tensor:
     """relu(relu(x[:, :c1] W2^T + x[:, c1:c1+3] W2e^T + b2) W3^T + b3) over the rows of a 2-D float32 GPU tensor (last dim
     contiguous, any row stride) in one launch (include/pn2_ext.h: pn2x_mlp2_rows).  `w2e` (c2, 3) or None; `out` may be a
-    column block of a wider buffer."""
+    column block of a wider buffer whose row stride is a multiple of 4 floats and whose first element is 16-byte aligned (rows are
+    stored as 16-byte quads)."""
     if x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or x.stride(1) != 1:
         raise TypeError("mlp2_rows: x must be a 2-D float32 GPU tensor with a contiguous last dimension")
     R = x.shape[0]
@@ -219,6 +220,8 @@ def mlp2_rows(x: torch.Tensor, w2, b2, w3, b3, out: torch.Tensor = None, w2e=Non
         out = torch.empty((R, C3), dtype=f32, device=x.device)
     if out.dim() != 2 or out.shape[0] != R or out.shape[1] < C3 or out.stride(1) != 1 or out.dtype != f32 or out.device != x.device:
         raise ValueError("mlp2_rows: out must be (rows, >= c3) float32 on the same device")
+    if (R > 1 and out.stride(0) % 4) or out.data_ptr() % 16:
+        raise ValueError("mlp2_rows: out needs a row stride that is a multiple of 4 floats and a 16-byte aligned first element")
     with torch.cuda.device(x.device):
         _native._check(_native._call(_lib.pn2x_mlp2_rows, "mlp2_rows_kernel", None, R, C1, C2, C3, x.data_ptr(), ldx,
                                      _native._ptr(w2, "w2", f32, C2 * C1), None if w2e is None else _native._ptr(w2e, "w2e", f32, C2 * 3),

@@ -49,27 +49,35 @@ def _record(g, x, dw_owner, dw_ptr, lddw, n, k):
 
 
 _consts = {}
+_retired = []  # constants replaced by larger ones: captured graphs may still read them (never freed)
 
 
-def _ones(rows: int, dev) -> torch.Tensor:
-    """(rows, 1) of ones: `g^T . ones` = the column sums of g (a bias gradient) as one more problem of the grouped launch."""
-    key = ("ones", dev)
+def _const(key, rows_needed, make):
+    """A process-wide constant tensor, grown on demand -- but never created or replaced inside a graph capture (a tensor from
+    the capturing graph's pool is only filled by replays, and replacing one drops memory earlier graphs read): None then, and the
+    caller takes its non-deferred path."""
     t = _consts.get(key)
-    if t is None or t.shape[0] < rows:
-        t = torch.ones((max(rows, 1024), 1), dtype=_f32, device=dev)
-        _consts[key] = t
-    return t[:rows]
+    if t is not None and t.shape[0] >= rows_needed:
+        return t
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return None
+    if t is not None:
+        _retired.append(t)
+    t = _consts[key] = make()
+    return t
 
 
-def _eye(n: int, dev) -> torch.Tensor:
+def _ones(rows: int, dev):
+    """(rows, 1) of ones: `g^T . ones` = the column sums of g (a bias gradient) as one more problem of the grouped launch."""
+    t = _const(("ones", dev), rows, lambda: torch.ones((max(rows, 1024), 1), dtype=_f32, device=dev))
+    return None if t is None else t[:rows]
+
+
+def _eye(n: int, dev):
     """(n, n) identity: `eye^T . block` copies a small gradient block into its columns of a wider weight gradient at the end of
     the pass (instead of a concatenation launch inside it)."""
-    key = ("eye", dev)
-    t = _consts.get(key)
-    if t is None or t.shape[0] < n:
-        t = torch.eye(max(n, 128), dtype=_f32, device=dev)
-        _consts[key] = t
-    return t[:n, :n]
+    t = _const(("eye", dev), n, lambda: torch.eye(max(n, 128), dtype=_f32, device=dev))
+    return None if t is None else t[:n, :n]
 
 
 class _Linear(torch.autograd.Function):
@@ -96,9 +104,13 @@ class _Linear(torch.autograd.Function):
                 _record(gg, _rows(x), dw, dw.data_ptr(), w2.shape[1], w2.shape[0], w2.shape[1])
                 dw = dw.view(weight.shape)  # a fresh view: autograd adopts it (no clone); the late product lands in its storage
             if want_b:  # the column sums of g: one more (N x 1) problem of the grouped launch
-                db = _ts.grad_buffer(ctx.bias, (w2.shape[0], 1))
-                _record(gg, _ones(g.shape[0], g.device), db, db.data_ptr(), 1, w2.shape[0], 1)
-                db = db.view(-1)
+                ones = _ones(g.shape[0], g.device)
+                if ones is None:  # (a first use inside a graph capture: the plain reduction)
+                    db = g.sum(0)
+                else:
+                    db = _ts.grad_buffer(ctx.bias, (w2.shape[0], 1))
+                    _record(gg, ones, db, db.data_ptr(), 1, w2.shape[0], 1)
+                    db = db.view(-1)
         else:
             if ctx.needs_input_grad[1]:
                 dw = torch.mm(g.t(), x).view(weight.shape)
@@ -188,27 +200,32 @@ class _PerPoint(torch.autograd.Function):
     block (C_s, Dc) (only for weights that have one)."""
 
     @staticmethod
-    def forward(ctx, x, D, sizes, *ws):
+    def forward(ctx, x, D, sizes, share, *ws):
         w2 = [w.view(w.shape[0], -1) for w in ws]
-        outs, wfs, i = [], [], 0
+        blocks = [w[:, :D] for w in w2]
+        # ONE product over the feature blocks of every scale of every module (rows of one stacked weight); a module's a1f is its
+        # column block of the result (row stride = all columns: the consumers take a row stride)
+        wf_all = blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=0)
+        out = torch.mm(x, wf_all.t())
+        outs, col, i = [], 0, 0
         for n in sizes:
-            blocks = [w[:, :D] for w in w2[i:i + n]]
-            wf = blocks[0] if n == 1 else torch.cat(blocks, dim=0)
-            outs.append(torch.mm(x, wf.t()))
-            wfs.append(wf)  # (kept for the input gradient: no second concatenation in the backward)
+            width = sum(w.shape[0] for w in w2[i:i + n])
+            outs.append(out[:, col:col + width] if len(sizes) > 1 else out)
+            col += width
             i += n
+        if share is not None:  # where the consumers' backward leaves the gradients of these column blocks: one buffer, see backward
+            share["cols"], share["rows"], share["buf"] = col, x.shape[0], None
         outs += [w[:, D:D + 3] for w in w2]
         centre = [w.shape[1] > D + 3 for w in w2]
         outs += [w[:, D + 3:] for w, c in zip(w2, centre) if c]
-        ctx.save_for_backward(x, *ws, *wfs)
-        ctx.D, ctx.sizes, ctx.centre = D, tuple(sizes), centre
+        ctx.save_for_backward(x, wf_all, *ws)
+        ctx.D, ctx.sizes, ctx.centre, ctx.share = D, tuple(sizes), centre, share
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         D, sizes, centre = ctx.D, ctx.sizes, ctx.centre
-        x, *rest = ctx.saved_tensors
-        ws, wfs = rest[:len(rest) - len(sizes)], rest[len(rest) - len(sizes):]
+        x, wf_all, *ws = ctx.saved_tensors
         w2 = [w.view(w.shape[0], -1) for w in ws]
         nm, nw = len(sizes), len(ws)
         ga = grads[:nm]
@@ -216,16 +233,35 @@ class _PerPoint(torch.autograd.Function):
         gc_it = iter(grads[nm + nw:])
         gc = [next(gc_it) if c else None for c in centre]
         dev = x.device
-        # input gradient: sum over modules of g_m . W_f,m (the first product creates it, the others accumulate: no add pass)
+        # input gradient.  When every module's gradient arrived as ITS column block of the shared buffer (train_ops._SaLayer1
+        # writes there: `share`), it is one product [g_1 | g_2 ...] . W_all; otherwise the sum over modules of g_m . W_f,m (the
+        # first product creates it, the others accumulate: no add pass)
         dx = None
         if ctx.needs_input_grad[0]:
-            for m in range(nm):
-                if ga[m] is not None:
-                    if dx is None:
-                        dx = torch.mm(ga[m], wfs[m])
-                    else:
-                        dx.addmm_(ga[m], wfs[m])
-        live = [w for j, w in enumerate(ws) if ctx.needs_input_grad[3 + j]]
+            buf = ctx.share.get("buf") if ctx.share is not None else None
+            whole, col = buf is not None and all(g is not None for g in ga), 0
+            if whole:
+                for g in ga:
+                    whole = whole and (g.dim() == 2 and g.stride(1) == 1 and g.stride(0) == buf.stride(0)
+                                       and g.data_ptr() == buf.data_ptr() + 4 * col and g.shape[0] == buf.shape[0])
+                    col += g.shape[1] if g.dim() == 2 else 0
+                whole = whole and col == buf.shape[1]
+            if whole:
+                dx = torch.mm(buf, wf_all)
+            else:
+                row = 0
+                for m, n_ in enumerate(sizes):
+                    width = sum(w.shape[0] for w in w2[sum(sizes[:m]):sum(sizes[:m]) + n_])
+                    if ga[m] is not None:
+                        wfm = wf_all[row:row + width]
+                        if dx is None:
+                            dx = torch.mm(ga[m], wfm)
+                        else:
+                            dx.addmm_(ga[m], wfm)
+                    row += width
+            if ctx.share is not None:
+                ctx.share["buf"] = None
+        live = [w for j, w in enumerate(ws) if ctx.needs_input_grad[4 + j]]
         defer = bool(live) and x.is_cuda and _defer_ok(live)
         xx = _rows(x) if defer else x
         dws, i = [], 0
@@ -237,7 +273,7 @@ class _PerPoint(torch.autograd.Function):
             for j in range(i, i + n):
                 w = w2[j]
                 C = w.shape[0]
-                if not ctx.needs_input_grad[3 + j]:
+                if not ctx.needs_input_grad[4 + j]:
                     dws.append(None)
                     c0 += C
                     continue
@@ -245,7 +281,7 @@ class _PerPoint(torch.autograd.Function):
                 tail = [zx] + ([gc[j] if gc[j] is not None else torch.zeros((C, w.shape[1] - D - 3), dtype=_f32, device=dev)] if centre[j] else [])
                 if g_m is None:
                     full = torch.cat([torch.zeros((C, D), dtype=_f32, device=dev)] + tail, dim=1)
-                elif defer:
+                elif defer and _eye(C, dev) is not None:
                     # [feature block | xyz | centre], every block written at the end of the pass by the grouped launch: the feature
                     # block as g^T x, the two small ones as eye^T . block (a copy as one more problem: no concatenation launch here)
                     full = _ts.grad_buffer(ws[j], (C, w.shape[1]))
@@ -257,20 +293,24 @@ class _PerPoint(torch.autograd.Function):
                         blk = _rows(blk)
                         _record(eye, blk, full, full.data_ptr() + 4 * col, ld, C, blk.shape[1])
                         col += blk.shape[1]
-                else:
+                else:  # (not deferred -- or the identity constant would have had to be created inside a graph capture)
                     full = torch.cat([torch.mm(g_m[:, c0:c0 + C].t(), x)] + tail, dim=1)
                 dws.append(full.view(ws[j].shape))
                 c0 += C
             i += n
-        return (dx, None, None, *dws)
+        return (dx, None, None, None, *dws)
 
 
 def per_point_first_layer(x: torch.Tensor, groups, D: int):
     """groups: per module the list of its scales' first-layer weight PARAMETERS (C_s, D + 3 [+ Dc][, 1, 1]).
-    -> (a1f per module (R, sum_s C_s), [per module [per scale (xyz block, centre block | None)]])."""
+    -> (a1f per module (R, sum_s C_s) -- column blocks of ONE product --, [per module [per scale (xyz block, centre block | None)]],
+    share).  `share` (a dict, or None for a single module) lets the consumers' backward write the gradients of the a1f blocks into
+    one (R, all columns) buffer -- share_grad_block(share, rows, first column, width) -- so that the input gradient here is one
+    product instead of one per module."""
     sizes = tuple(len(g) for g in groups)
     ws = [w for g in groups for w in g]
-    outs = _PerPoint.apply(x, int(D), sizes, *ws)
+    share = {} if len(sizes) > 1 else None
+    outs = _PerPoint.apply(x, int(D), sizes, share, *ws)
     nm, nw = len(sizes), len(ws)
     a1f = list(outs[:nm])
     wx = list(outs[nm:nm + nw])
@@ -280,4 +320,22 @@ def per_point_first_layer(x: torch.Tensor, groups, D: int):
     for n in sizes:
         blocks.append([(wx[j], wc[j]) for j in range(i, i + n)])
         i += n
-    return a1f, blocks
+    if share is not None:
+        col = 0
+        share["first_col"] = []
+        for a in a1f:
+            share["first_col"].append(col)
+            col += a.shape[1]
+    return a1f, blocks, share
+
+
+def share_grad_block(share, module: int, device):
+    """The (R, width) column block of the shared gradient buffer that belongs to module `module`'s a1f (allocated on first use in
+    a backward pass), or None when there is no shared buffer."""
+    if share is None or "cols" not in share:
+        return None
+    if share.get("buf") is None:
+        share["buf"] = torch.empty((share["rows"], share["cols"]), dtype=_f32, device=device)
+    c0 = share["first_col"][module]
+    c1 = share["first_col"][module + 1] if module + 1 < len(share["first_col"]) else share["cols"]
+    return share["buf"][:, c0:c1]

@@ -326,7 +326,15 @@ class _SaLayer1(torch.autograd.Function):
         idxs, rels, invs = ctx.saved_tensors[:n], ctx.saved_tensors[n:2 * n], ctx.saved_tensors[2 * n:]
         dev = douts[0].device
         fits = a1f_shape is not None and a1f_shape[1] <= INVERSE_MAX_ROWS
-        d_a1f = (torch.empty if fits else torch.zeros)(a1f_shape, dtype=_f32, device=dev) if a1f_shape is not None else None
+        d_a1f = None
+        share = ctx.aux.get("a1f_share") if (ctx.aux is not None and a1f_shape is not None and fits) else None
+        if share is not None:  # this module's column block of the buffer all modules of one per-point product share (linear_dw)
+            from .linear_dw import share_grad_block
+            blk = share_grad_block(share[0], share[1], dev)
+            if blk is not None and blk.shape[0] == a1f_shape[0] * a1f_shape[1] and blk.shape[1] == a1f_shape[2]:
+                d_a1f = blk.view(a1f_shape)  # (row stride = the buffer's width: every kernel below takes one)
+        if d_a1f is None and a1f_shape is not None:
+            d_a1f = (torch.empty if fits else torch.zeros)(a1f_shape, dtype=_f32, device=dev)
         d_cadd = torch.empty(cadd_shape, dtype=_f32, device=dev) if cadd_shape is not None else None
         d_wx = []
         col = 0

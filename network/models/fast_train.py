@@ -23,6 +23,12 @@ import torch
 import torch.nn.functional as F
 
 
+# ONE switch for "weight gradients of plain linear layers deferred to the grouped end-of-pass launch" (hotrack_amd.linear_dw):
+# FastTrain, the rearrange modules and FastTail all read it here (three separate reads of the environment let a
+# programmatic change switch the path only partly).  HOTRACK_DEFER_WGRAD=0, or fast_train.DEFER_WGRAD = False before a forward.
+DEFER_WGRAD = os.environ.get("HOTRACK_DEFER_WGRAD", "1") != "0"
+
+
 def _w2d(conv):
     return conv.weight.view(conv.weight.shape[0], -1)
 
@@ -83,8 +89,11 @@ class FastTrain:
         self.ws = None
         import os
         self.use_fused_stacks = os.environ.get("HOTRACK_FUSED_STACKS", "1") != "0"  # 0: round-2 path (library GEMMs + streaming BN)
-        self.defer_wgrad = os.environ.get("HOTRACK_DEFER_WGRAD", "1") != "0"  # 0: every weight gradient a library GEMM inside the pass
         self.small_stack_rows = int(os.environ.get("HOTRACK_SMALL_STACK_ROWS", "4096"))  # stacks with at most this many rows: unfused layers
+
+    @property
+    def defer_wgrad(self) -> bool:
+        return DEFER_WGRAD  # False: every weight gradient a library GEMM inside the pass
 
     @staticmethod
     def supported(net) -> bool:
@@ -136,8 +145,10 @@ class FastTrain:
         the first layers of `mods`, which all read the same rows (one Function: one input gradient, deferred weight gradients)."""
         from hotrack_amd.linear_dw import per_point_first_layer
         groups = [[convs[0].weight for convs in m.conv_blocks] for m in mods]
-        a1f, blocks = per_point_first_layer(feat2d, groups, D)
-        return [([(None, wx, wc) for wx, wc in b], a) for b, a in zip(blocks, a1f)]
+        a1f, blocks, share = per_point_first_layer(feat2d, groups, D)
+        # (share, m): where module m's backward leaves the gradient of its a1f block -- one buffer for all modules, so that the
+        # input gradient of the per-point product is one GEMM (hotrack_amd.linear_dw._PerPoint)
+        return [([(None, wx, wc) for wx, wc in b], a, (share, m)) for m, (b, a) in enumerate(zip(blocks, a1f))]
 
     @staticmethod
     def _first_layer_blocks(mod, D, has_center):
@@ -158,11 +169,13 @@ class FastTrain:
         S = cxyz.shape[1]
         D = 0 if feat2d is None else feat2d.shape[1]
         a1f = cadd = None
+        a1f_share = None
         if pre is not None:
-            w1, a1f2d = pre
+            w1, a1f2d = pre[:2]
+            a1f_share = pre[2] if len(pre) > 2 else None
             a1f = a1f2d.view(B, N, -1)
         elif D and self.defer_wgrad:
-            (w1, a1f2d), = self._per_point(feat2d, [mod], D)
+            (w1, a1f2d, _), = self._per_point(feat2d, [mod], D)
             a1f = a1f2d.view(B, N, -1)
         else:
             w1, wf = self._first_layer_blocks(mod, D, center2d is not None)
@@ -172,6 +185,8 @@ class FastTrain:
             wc = w1[0][2] if len(w1) == 1 else torch.cat([w[2] for w in w1], dim=0)
             cadd = F.linear(center2d, wc).view(B, S, -1)
         aux = {} if self.use_fused_stacks else None  # relative coordinates -> the stacks, d(W_xyz) <- the stacks (train_ops.sa_layer1)
+        if aux is not None and a1f_share is not None and a1f_share[0] is not None:
+            aux["a1f_share"] = a1f_share
         y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1], invs=invs, aux=aux,
                         ws=self.ws if os.environ.get("HOTRACK_SA1_STATS", "1") != "0" else None)
         outs = []
@@ -309,15 +324,16 @@ class FastTrain:
         idxs, invs = geo["knn"], geo["knn_inv"]
         # the per-point halves of both modules' first layers read src2: one Function, one input gradient (_Linear2Shared)
         if self.defer_wgrad:
-            (w1_q1, a1f_q1), (w1_q2, a1f_q2) = self._per_point(src2, [net.q1, net.q2], C)
+            (w1_q1, a1f_q1, sh_q1), (w1_q2, a1f_q2, sh_q2) = self._per_point(src2, [net.q1, net.q2], C)
         else:
+            sh_q1 = sh_q2 = None
             w1_q1, wf_q1 = self._first_layer_blocks(net.q1, C, False)
             w1_q2, wf_q2 = self._first_layer_blocks(net.q2, C, True)
             a1f_q1, a1f_q2 = _Linear2Shared.apply(src2, wf_q1, wf_q2)
         # both modules gather through the same neighbour lists: inverted once (geometry) for the two backward scatters
-        f11 = self._sa_scales(net.q1, xyz, kp, src2, idxs, pre=(w1_q1, a1f_q1), invs=invs)             # (B,J,C)
+        f11 = self._sa_scales(net.q1, xyz, kp, src2, idxs, pre=(w1_q1, a1f_q1, sh_q1), invs=invs)             # (B,J,C)
         f12 = self._rearrange(net.r1, f11)                                                                 # (B*J, C)
-        f13 = self._sa_scales(net.q2, xyz, kp, src2, idxs, center2d=f12, pre=(w1_q2, a1f_q2), invs=invs)
+        f13 = self._sa_scales(net.q2, xyz, kp, src2, idxs, center2d=f12, pre=(w1_q2, a1f_q2, sh_q2), invs=invs)
         f14 = self._rearrange(net.r2, f13).view(B, J, C)
         self.last_token_rows = f14.view(B * J, C)  # token-major rows for FastTail (the transposed view below is what `r2` returns)
         return f14.transpose(1, 2), src2.view(B, N, C)
@@ -336,7 +352,7 @@ class FastTrain:
             g = gather_rows(tok, cache[0], cache[1])  # (B, J*re, C); backward: one segment-sum launch
         else:
             g = tok.index_select(1, cache[0][0].long())
-        if os.environ.get("HOTRACK_DEFER_WGRAD", "1") != "0":
+        if DEFER_WGRAD:
             from hotrack_amd.linear_dw import linear
             return linear(g.view(B * J, mod.re * C), mod.linear.weight, mod.linear.bias)
         return F.linear(g.view(B * J, mod.re * C), mod.linear.weight.squeeze(-1), mod.linear.bias)
@@ -419,7 +435,7 @@ class FastTail:
         seed_used = torch.empty(1, dtype=torch.int64, device=dev)
         grads = T.TailGrads(dev, 14 * C + 2 * H + Hf + 3 * Hf + 3)
         pd = lambda m: float(m.p) if m.training else 0.0
-        if os.environ.get("HOTRACK_DEFER_WGRAD", "1") != "0":
+        if DEFER_WGRAD:
             from hotrack_amd.linear_dw import linear as lin
         else:
             lin = lambda x, w: F.linear(x, w.view(w.shape[0], -1))

@@ -78,8 +78,13 @@ def test_group_and_fused_sa_full_size(data):
     a1f = torch.matmul(feat.transpose(1, 2), W1[:, :C].t().contiguous())
     out = ext.sa_mlp_max(idx, W2, b2, W3, b3, a1f=a1f, xyz=xyz, cxyz=new_xyz, wx=W1[:, C:].contiguous(), b1=b1)
     gx = torch.gather(xyz.transpose(1, 2).unsqueeze(2).expand(-1, -1, S, -1), 3, idx.long().unsqueeze(1).expand(-1, 3, -1, -1))
-    x = torch.cat([grouped, gx - new_xyz.transpose(1, 2).unsqueeze(-1)], 1)[:2]  # 2 clouds through the unfused path
-    h = torch.relu(torch.einsum("oc,bcsk->bosk", W1, x) + b1[None, :, None, None])
-    h = torch.relu(torch.einsum("oc,bcsk->bosk", W2, h) + b2[None, :, None, None])
-    h = torch.relu(torch.einsum("oc,bcsk->bosk", W3, h) + b3[None, :, None, None]).max(-1)[0]
-    assert float((out[:2] - h).abs().max()) < 1e-3 * max(1.0, float(h.abs().max()))
+    # 2 clouds through the unfused composition in fp64 (the ground truth: an fp32 einsum carries its own summation-order error),
+    # held to the bound the small shapes are held to (tests/test_gpu_fused.py::test_fused_sa_scale_matches_unfused: 2e-5 of the
+    # output scale; VERDICT r5: the full-size test allowed 1e-3 without a reason)
+    x = torch.cat([grouped, gx - new_xyz.transpose(1, 2).unsqueeze(-1)], 1)[:2].double()
+    d = lambda t: t.double()
+    h = torch.relu(torch.einsum("oc,bcsk->bosk", d(W1), x) + d(b1)[None, :, None, None])
+    h = torch.relu(torch.einsum("oc,bcsk->bosk", d(W2), h) + d(b2)[None, :, None, None])
+    h = torch.relu(torch.einsum("oc,bcsk->bosk", d(W3), h) + d(b3)[None, :, None, None]).max(-1)[0]
+    err, scale = float((out[:2].double() - h).abs().max()), float(h.abs().max())
+    assert err <= 2e-5 * max(1.0, scale), (err, scale)

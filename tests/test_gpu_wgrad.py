@@ -136,7 +136,7 @@ def _net_forward(net, x, deferred):
     D = net.D
     if deferred:
         from hotrack_amd.linear_dw import linear, per_point_first_layer
-        (a, bc), blocks = per_point_first_layer(x, [[net.conv_a.weight], [net.conv_b.weight, net.conv_c.weight]], D)
+        (a, bc), blocks, _share = per_point_first_layer(x, [[net.conv_a.weight], [net.conv_b.weight, net.conv_c.weight]], D)
         wx = [b[0] for mod in blocks for b in mod]
         wc = [b[1] for mod in blocks for b in mod if b[1] is not None]
     else:
