@@ -348,8 +348,16 @@ template <int QMAX, int QR, int QL>
 static int launch_fps_stream(int b, int n, int m, const float *xyz, int *idx, hipStream_t st) {
     const size_t lds = (size_t)QL * 3 * 1024 * sizeof(float);
     static PerDeviceOnce raised;
-    if (lds > 48 * 1024 && raised.first_use())
-        (void)hipFuncSetAttribute((const void *)fps_stream_kernel<QMAX, QR, QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool refused[64] = {};  // devices whose runtime would not raise the dynamic-LDS cap (the result was ignored)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (lds > 48 * 1024 && raised.first_use()) {
+        if (hipFuncSetAttribute((const void *)fps_stream_kernel<QMAX, QR, QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            refused[dev] = true;
+        }
+    }
+    if (lds > 48 * 1024 && refused[dev]) return PN2_ERANGE;  // the caller takes the HBM-temp kernel (needs `temp`)
     hipLaunchKernelGGL((fps_stream_kernel<QMAX, QR, QL>), dim3(b), dim3(1024), lds, st, n, m, xyz, idx);
     return check_launch();
 }
@@ -407,10 +415,9 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, h
         if (skip_flags || radii) return PN2_ERANGE;  // the shortcut covers the register-resident kernels only
         static const bool no_stream = getenv("PN2_FPS_NO_STREAM") != nullptr;  // (A/B against the HBM-temp kernel: tests, probes)
         if (Q <= 64 && !no_stream) {  // running distances in registers, coordinates streamed from L2: no scratch buffer
-            static const bool plain = getenv("PN2_FPS_STREAM_PLAIN") != nullptr;  // (A/B: no resident coordinates)
-            if (plain) return Q <= 32 ? launch_fps_stream<32, 0, 0>(b, n, m, xyz, idx, st) : launch_fps_stream<64, 0, 0>(b, n, m, xyz, idx, st);
-            if (Q <= 32) return launch_fps_stream<32, 16, 12>(b, n, m, xyz, idx, st);
-            return launch_fps_stream<64, 0, 13>(b, n, m, xyz, idx, st);  // (64 distance registers leave no room for coordinates: hipcc spills from QR = 4)
+            // (64 distance registers leave no room for coordinates: hipcc spills from QR = 4)
+            const int rc = Q <= 32 ? launch_fps_stream<32, 16, 12>(b, n, m, xyz, idx, st) : launch_fps_stream<64, 0, 13>(b, n, m, xyz, idx, st);
+            if (rc != PN2_ERANGE) return rc;  // PN2_ERANGE: no 144-156 KiB of dynamic LDS here -> the HBM-temp kernel below
         }
         if (!temp) return PN2_ESCRATCH;
         hipLaunchKernelGGL(fps_large_kernel, dim3(b), dim3(1024), 0, st, n, m, xyz, temp, idx);

@@ -849,10 +849,7 @@ __global__ void __launch_bounds__(kT, 2) tg_bwd2_pair_kernel(BwdArgs a0, BwdArgs
 
 // the (C_{i-1} / 32, C_i / 32) pairs the two-role kernel is instantiated for
 #define PN2_TGB2_SHAPES(X) X(2, 2) X(2, 4) X(4, 4) X(4, 6)
-static bool g_tgb2 = [] {
-    const char *e = getenv("HOTRACK_TGB2");   // 0: the round-4 kernel for every shape (A/B measurements, tests of both)
-    return !(e && e[0] == '0');
-}();
+static bool g_tgb2 = true;  // (pn2x_tg_bwd_set_variant(0): the round-4 kernel for every shape -- tests of both, A/B benches)
 }  // namespace tgb
 }  // namespace pn2
 // 1: the register-resident-W kernel where it is instantiated (default), 0: the round-4 kernel everywhere.  Process-wide; the
@@ -908,8 +905,8 @@ static bool find_shape(int c_in, int c_out, Shape &s) {
 static int grid_of(long rows, const Shape &s) {
     const long tiles = (rows + BM - 1) / BM;
     // persistent workgroups: one per CU where the LDS footprint admits only one, two otherwise
-    static const int v2_two = [] { const char *e = getenv("PN2_TGB2_TWO_PER_CU"); return e ? atoi(e) : 0; }();  // (A/B probe)
-    const long cap = (long)num_compute_units() * ((!s.v2 || v2_two) && s.lds * 2 <= 160 * 1024 ? 2 : 1);
+    // (two workgroups of the register-resident-W kernel per CU were measured in round 5 and are slower)
+    const long cap = (long)num_compute_units() * (!s.v2 && s.lds * 2 <= 160 * 1024 ? 2 : 1);
     return (int)(tiles < cap ? tiles : cap);
 }
 

@@ -891,7 +891,7 @@ extern "C" int pn2x_tg_reduce_multi2(int count, const float *const *partial, con
             a.P[i] = n_partials[j]; a.numel[i] = numel[j]; a.N[i] = channels[j];
             a.sld[i] = sums_ld ? sums_ld[j] : channels[j];
             if (a.sld[i] < channels[j]) return PN2_EINVAL;
-            static const int per_slice = [] { const char *e = getenv("PN2_TGR_SLICE"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+            constexpr int per_slice = 128;  // (32 in round 4: 59.6 -> 50.0 us, a quarter of the atomics)
             // partial tiles per slice (PN2_TGR_SLICE: probes).  32 per slice = 8 slices x numel atomics per layer: 59.6 us for the step's
             // 200 MB of partial tiles; 128 per slice: 50.0 us (fewer atomics, still thousands of workgroups)
             int ps = a.P[i] / per_slice;

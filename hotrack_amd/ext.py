@@ -262,7 +262,7 @@ _lib.pn2x_three_nn_interpolate_pm.argtypes = [_ci, _ci, _ci, _ci, _vp, _vp, _vp,
 _lib.pn2x_three_nn_interpolate_pm.restype = _ci
 _lib.pn2x_three_nn_interpolate_pm_supported.argtypes = [_ci] * 6
 _lib.pn2x_three_nn_interpolate_pm_supported.restype = _ci
-NN_INTERP_FUSED = os.environ.get("HOTRACK_NN_INTERP_FUSED", "1") != "0"
+NN_INTERP_FUSED = True  # (module attribute: tests / A-B runs set it False for the two-launch chain)
 
 
 def three_nn_interpolate_pm(unknown: torch.Tensor, known: torch.Tensor, points: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -429,7 +429,7 @@ _lib.pn2x_linear_small.restype = _ci
 # where pn2x_linear_small beats the library's best recorded solution (scripts/probes/linear_small_bench.py, profiles/
 # r03_linear_small.json): 2 ... 512 rows, reductions up to 384 deep, up to 512 outputs -- e.g. 128 x 128 -> 256: 4.7 vs 20 us,
 # 128 x 131 -> 128: 7.0 vs 12.8; it loses on one row, on deep reductions (21 x 1024 -> 384: 17 vs 5.9) and from ~1000 rows
-LINEAR_SMALL_MAX_ROWS = int(__import__("os").environ.get("HOTRACK_LINEAR_SMALL_MAX_ROWS", "512"))
+LINEAR_SMALL_MAX_ROWS = 512
 LINEAR_SMALL_MAX_K, LINEAR_SMALL_MAX_N = 384, 512
 
 
@@ -454,7 +454,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, relu: bo
 
 _lib.pn2x_ln_linear_small.argtypes = [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _cf, _vp, _vp, _ci, _vp, _ci, _vp, _ci, _vp]
 _lib.pn2x_ln_linear_small.restype = _ci
-LN_LINEAR_MAX_ROWS = int(__import__("os").environ.get("HOTRACK_LN_LINEAR_MAX_ROWS", "256"))  # 0: always the two launches (B = 8: 0.419 -> 0.410 ms with 168 rows through it)
+LN_LINEAR_MAX_ROWS = 256  # 0: always the two launches (B = 8: 0.419 -> 0.410 ms with 168 rows through it)
 
 
 def ln_linear_supported(rows: int, c: int) -> bool:
@@ -542,8 +542,8 @@ def ball_query_picks(radius: float, nsample: int, xyz: torch.Tensor, picks: torc
     return idx, new_xyz
 
 
-FPS_KNN_COLAUNCH = os.environ.get("HOTRACK_FPS_KNN_COLAUNCH", "1") != "0"
-BALL_TIE_COLAUNCH = os.environ.get("HOTRACK_BALL_TIE_COLAUNCH", "1") != "0"
+FPS_KNN_COLAUNCH = True  # (module attributes: tests compare the co-launches with the separate launches)
+BALL_TIE_COLAUNCH = True
 _lib.pn2x_ball_query_picks_ties.argtypes = [_ci, _ci, _ci, ctypes.c_float, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp]
 _lib.pn2x_ball_query_picks_ties.restype = _ci
 _lib.pn2x_ball_query_picks_ties_supported.argtypes = [_ci] * 4

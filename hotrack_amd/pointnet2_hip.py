@@ -65,6 +65,7 @@ _lib.pn2x_scatter_cm_scratch_ints.restype = ctypes.c_long
 _lib.pn2x_scatter_cm.argtypes = [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp]
 _lib.pn2x_scatter_cm.restype = _ci
 _PN2_ERANGE = -3
+PN2_ESCRATCH = -4  # include/pn2_hip.h: this size needs the optional scratch buffer (FPS temp)
 
 
 def _scatter_cm(t, b, c, n_dst, m_src, grad_out, idx_ptr, w_ptr, out_ptr, dev, stream):

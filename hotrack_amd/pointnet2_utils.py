@@ -45,7 +45,15 @@ class FurthestPointSampling(Function):
         # (running distances are register-resident up to 65536 points per cloud; beyond that the kernel keeps them in the
         # reference's HBM scratch, pre-filled with 1e10 as at reference :28)
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device) if N > 65536 else None
-        pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
+        try:
+            pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
+        except pointnet2.Pn2Error as exc:
+            # 16385 .. 65536 points without scratch need 144-156 KiB of dynamic LDS; a runtime that refuses it (or
+            # PN2_FPS_NO_STREAM) answers "scratch missing": the HBM-temp kernel then, with the reference's scratch
+            if temp is not None or "[code %d]" % pointnet2.PN2_ESCRATCH not in str(exc):
+                raise
+            temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+            pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
         ctx.mark_non_differentiable(output)
         return output
 

@@ -38,7 +38,7 @@ _lib.pn2x_sa_layer1_stats_pair.argtypes = [_ci, _ci, _ci, _vp, _vp] + _SCALE + _
 _lib.pn2x_sa_layer1_stats_pair.restype = _ci
 _lib.pn2x_rows_segment_sum_pair.argtypes = [_ci, _ci] + [_ci, _ci, _vp, _ci, _vp, _vp, _vp, _ci] * 2 + [_ci, _vp]
 _lib.pn2x_rows_segment_sum_pair.restype = _ci
-PAIR_SCALES = os.environ.get("HOTRACK_PAIR_SCALES", "1") != "0"  # the two scales of a module: one launch where a pair kernel exists
+PAIR_SCALES = True  # the two scales of a module: one launch where a pair kernel exists (False: one launch per scale; tests compare)
 _lib.pn2x_rows_outer3.argtypes = [_cl, _ci, _vp, _ci, _vp, _vp, _vp, _cl, _vp]
 _lib.pn2x_rows_outer3.restype = _ci
 _lib.pn2x_rows_outer3_scratch_floats.argtypes = [_cl, _ci]

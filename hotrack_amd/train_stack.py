@@ -36,7 +36,7 @@ _lib.pn2x_tg_fwd2.argtypes = _lib.pn2x_tg_fwd.argtypes
 _lib.pn2x_tg_fwd2.restype = _ci
 _lib.pn2x_tg_fwd2_supported.argtypes = [_ci, _ci]
 _lib.pn2x_tg_fwd2_supported.restype = _ci
-FWD2 = _os.environ.get("HOTRACK_STACK_FWD2", "1") != "0"  # 64- / 128-channel inputs: the W-resident forward (csrc/train_fwd.hip)
+FWD2 = True  # 64- / 128-channel inputs: the W-resident forward (csrc/train_fwd.hip); False: pn2x_tg_fwd for every shape (tests)
 _DY = [_ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]  # gmode, g, ldg, arg, kmax, yi, ldyi, mean, invstd, gamma, beta, sums_bwd
 _lib.pn2x_tg_dgrad.argtypes = [_cl, _ci, _ci] + _DY + [_vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
 _lib.pn2x_tg_dgrad.restype = _ci
@@ -96,13 +96,13 @@ def set_bwd_kernel_variant(v2: bool) -> None:
     """True (default): the layer backward with W_i register-resident (round 5) where it is instantiated; False: the round-4 kernel
     for every shape.  Process-wide; switch between whole backward passes only (tests, A/B benches)."""
     _native._check(_lib.pn2x_tg_bwd_set_variant(1 if v2 else 0), "tg_bwd_set_variant")
-FUSED_BWD = _os.environ.get("HOTRACK_STACK_FUSED_BWD", "1") != "0"  # data + weight gradient of a layer in one kernel (train_bwd.hip)
-ROUTE_ON_LOAD = _os.environ.get("HOTRACK_STACK_ROUTE_ON_LOAD", "1") != "0"  # max-pooled top: sums from the arg-max rows, routed on load
+FUSED_BWD = True  # data + weight gradient of a layer in one kernel (train_bwd.hip); False: the two-kernel backward (tests compare)
+ROUTE_ON_LOAD = True  # max-pooled top: sums from the arg-max rows, routed on load
 _lib.pn2x_bn_bwd_reduce.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
 _lib.pn2x_bn_bwd_reduce.restype = _ci
 _lib.pn2x_bn_bwd_reduce_g.argtypes = [_cl, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp]
 _lib.pn2x_bn_bwd_reduce_g.restype = _ci
-ROUTE_DENSE = _os.environ.get("HOTRACK_STACK_ROUTE_DENSE", "1") != "0"  # max-routed top gradient materialised once by the reduction
+ROUTE_DENSE = True  # max-routed top gradient materialised once by the reduction (where ROUTE_ON_LOAD does not apply)
 # The weight gradients are not read before the optimiser: the backward writes only partial tiles and ONE launch at the end of
 # the pass (autograd's final callbacks) sums the tiles of every layer of every stack.  Off (HOTRACK_STACK_DEFER_REDUCE=0, or
 # `DEFER_REDUCE = False`) where something reads .grad from inside the pass -- DistributedDataParallel's bucket hooks do.

@@ -89,7 +89,7 @@ class FastTrain:
         self.ws = None
         import os
         self.use_fused_stacks = os.environ.get("HOTRACK_FUSED_STACKS", "1") != "0"  # 0: round-2 path (library GEMMs + streaming BN)
-        self.small_stack_rows = int(os.environ.get("HOTRACK_SMALL_STACK_ROWS", "4096"))  # stacks with at most this many rows: unfused layers
+        self.small_stack_rows = 4096  # stacks with at most this many rows run as unfused layers (8192 lost at batch 64: DESIGN.md 5b)
 
     @property
     def defer_wgrad(self) -> bool:
@@ -188,7 +188,7 @@ class FastTrain:
         if aux is not None and a1f_share is not None and a1f_share[0] is not None:
             aux["a1f_share"] = a1f_share
         y1s = sa_layer1(a1f, cadd, xyz, cxyz, idxs, [w[1] for w in w1], invs=invs, aux=aux,
-                        ws=self.ws if os.environ.get("HOTRACK_SA1_STATS", "1") != "0" else None)
+                        ws=self.ws)
         outs = []
         pair = self._pair_stacks(mod, y1s, idxs, aux) if len(y1s) == 2 else None
         if pair is not None:  # both neighbourhood sizes layer by layer, equal-shaped fused launches grouped (train_stack.mlp_stack_pair)

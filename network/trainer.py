@@ -550,8 +550,7 @@ class Trainer(nn.Module):
         steps; it needs 0.3 ms per step against 3.3 ms on the device.  One graph executable, so its replays are strictly
         ordered: a prefetch still in flight is always waited for before the graph or its buffers are touched."""
         cur = torch.cuda.current_stream()
-        probe = os.environ.get("HOTRACK_GEO_PROBE", "")  # timing probes only (profiles/r06_misc_measurements.md)
-        if self._geo_ready_for is not None and probe != "nowait":
+        if self._geo_ready_for is not None:
             cur.wait_event(self._geo_done)
         inline = self._geo_ready_for is None or self._geo_ready_for is not data
         if inline:  # not prefetched: here and now, on this stream
@@ -568,11 +567,11 @@ class Trainer(nn.Module):
             self._geo_copied[1 - slot].synchronize()  # the copy that last read the other pack (previous step) has finished
             if inline:  # the graph has just been replayed on THIS stream: its next replay must not start beside that one
                 self._geo_copied[slot].synchronize()
-            with torch.cuda.stream(cur if probe == "samestream" else self._geo_stream):
+            with torch.cuda.stream(self._geo_stream):
                 self._copy_leaves(self._geo_in, next_data)
                 self._geo_graph.replay()
                 self._pack_geometry(1 - slot)
-                self._geo_done.record(cur if probe == "samestream" else self._geo_stream)
+                self._geo_done.record(self._geo_stream)
             self._geo_ready_for = next_data
 
     def _pack_geometry(self, slot):
@@ -592,26 +591,22 @@ class Trainer(nn.Module):
             self._copy_leaves(self._static, data)
         self._graph.replay()
         if self._opt_graph is not None:
-            # data parallel: [forward + backward segment 0 + pack] | [backward segment 1 + pack] | exchanges | [scatter + Adam].
-            # Segment 0's exchange runs on the collective's own stream beside graph 2.  The step's stream never records an
+            # data parallel: [forward + backward (gradients land in the flat buffer)] | all-reduce of the buffer, in place | [Adam].
+            # bwd_segments = 2: [forward + backward segment 0] | [backward segment 1] | exchanges | [Adam]; with dp_overlap
+            # segment 0's exchange runs on the collective's own stream beside graph 2.  The step's stream never records an
             # event that another stream waits for (that stalls it by 50-200 us on this runtime: profiles/r04_two_graph_overlap.txt):
             # the HOST waits for graph 1 (an event nobody waits for on the device) and then issues the collective from an idle
             # stream; the step's stream only ever waits FOR the collective (free).
             works = []
             if self._graph_rest is not None:
                 cur = torch.cuda.current_stream()
-                probe = os.environ.get("HOTRACK_DP_PROBE", "")  # timing probes only (profiles/r05_misc_measurements.md)
-                if self.dp_overlap and probe != "norecord":
+                if self.dp_overlap:
                     self._seg_done.record(cur)
                 self._graph_rest.replay()
                 if self.dp_overlap:
-                    if probe != "norecord":
-                        self._seg_done.synchronize()
-                    if probe == "mainstream":
+                    self._seg_done.synchronize()
+                    with torch.cuda.stream(self._comm_stream):
                         works.append(self._exchange(0, async_op=True))
-                    else:
-                        with torch.cuda.stream(self._comm_stream):
-                            works.append(self._exchange(0, async_op=True))
                 else:
                     works.append(self._exchange(0))
                 works.append(self._exchange(1, async_op=self.dp_overlap))

@@ -2,6 +2,9 @@
 
 Index outputs must be bit-exact; float outputs within 1e-5 (BASELINE.json north_star).
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -99,6 +102,28 @@ def test_fps_streamed_clouds_index_exact(ops, oracle, B, N, M, kind, monkeypatch
     native.furthest_point_sampling_wrapper(B, N, M, dev(xyz), None, out)  # no scratch buffer needed
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
     np.testing.assert_array_equal(ops.furthest_point_sample(dev(xyz), M).cpu().numpy(), ref)
+
+
+def test_fps_op_falls_back_to_the_scratch_kernel_when_the_streamed_kernel_is_unavailable(oracle):
+    """ADVICE r5: the operator passes no scratch for 16385 .. 65536 points (fps_stream_kernel needs 144-156 KiB of dynamic LDS);
+    where that kernel cannot run -- PN2_FPS_NO_STREAM here, a refused hipFuncSetAttribute elsewhere -- the C ABI answers
+    PN2_ESCRATCH and the operator retries with the reference's temp buffer.  Child process: the switch is read once."""
+    import subprocess
+    B, N, M = 1, 20000, 40
+    xyz = cloud(11, B, N, "uniform")
+    ref = oracle.furthest_point_sample(xyz, M)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_fps_child_in.npy")
+    np.save(path, xyz)
+    try:
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from hotrack_amd import pointnet2_utils as ops;"
+                "x = torch.from_numpy(np.load(%r)).cuda(); print(','.join(str(int(v)) for v in ops.furthest_point_sample(x, %d)[0].cpu()))"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, M))
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PN2_FPS_NO_STREAM="1"), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got = np.array([int(v) for v in out.stdout.strip().splitlines()[-1].split(",")], dtype=np.int32)
+    finally:
+        os.remove(path)
+    np.testing.assert_array_equal(got, ref[0])
 
 
 def test_fps_large_needs_temp(oracle):
