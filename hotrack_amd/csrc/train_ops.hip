@@ -998,7 +998,11 @@ rows_segment_sum_split_kernel(int n_dst, int m_src, int Q, int EL, const float *
 
 static int rows_per_block_for(long rows, int C, bool stats_only = false) {
     const int rpp = kTT / (C >> 2);
-    long rpb = (rows + 1023) / 1024;  // ~1024 workgroups on a large problem
+    // ~1024 workgroups on a large problem; 512 for the reductions: every workgroup ends in 2 C fp64 atomics onto 8 accumulator copies,
+    // and with 1024 of them that tail was ~20 us of a step's reduction launches (sweep 256 / 512 / 1024 / 2048: 2.562 / 2.560 / 2.580 /
+    // 2.580 ms per step)
+    const long tg = stats_only ? 512 : 1024;
+    long rpb = (rows + tg - 1) / tg;
     // A thread walks rows_per_block / rpp rows.  Small tensors (the 4096 - 8192-row stacks of a 32-cloud step: <= 8 MB) used
     // to get 16 rows per thread like the large ones -- 32 - 64 workgroups, each thread a chain of 16 dependent-in-time round
     // trips: 9 - 10 us for a 4 MB tensor.  Four rows per thread (all four loads in flight, see the kernels) fill the chip.
@@ -1070,7 +1074,7 @@ extern "C" int pn2x_bn_bwd_reduce_g(long rows, int c, const float *dh, int ldd, 
     if (!dh || !y || !mean || !invstd || !gamma || !beta || !sums) return PN2_ENULL;
     if (((uintptr_t)y | (uintptr_t)dh | (uintptr_t)arg | (uintptr_t)g_out) % 16) return PN2_EINVAL;
     if (g_out && (ldg < c || ldg % 4)) return PN2_EINVAL;
-    const int rpb = rows_per_block_for(rows, c);
+    const int rpb = rows_per_block_for(rows, c, rows * c > (2L << 20));
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kTT), 0, (hipStream_t)stream, rows, c, dh,
                        ldd, y, ldy, mean, invstd, gamma, beta, rpb, arg ? 1 : relu, sums, arg, arg ? k : 1, arg ? g_out : nullptr, ldg);
     return check_launch();
