@@ -656,6 +656,7 @@ class HandLosses(torch.autograd.Function):
                                                   _native._stream(pred_hf)), "hand_losses")
         ctx.save_for_backward(pred_hf, palm, saved, *([weights] if weights is not None else []))
         ctx.scale = float(scale)
+        ctx.set_materialize_grads(False)  # (backward handles None: no zero-fill launch for the output nobody differentiates)
         if weights is None:
             return out[:9]
         return out[:9], out[9]

@@ -149,6 +149,7 @@ class _PoseHead(torch.autograd.Function):
                                                         _native._stream(h)), "tail_pose_head_fwd")
         ctx.save_for_backward(h, w, R, scale)
         ctx.acc, ctx.J = acc, J
+        ctx.set_materialize_grads(False)  # (backward handles a missing g_hand / g_cam: no zero-fill launch for it)
         return kp_hand, kp_cam
 
     @staticmethod

@@ -337,7 +337,13 @@ class Trainer(nn.Module):
                 cut, net.backward_cut = (net.backward_cut if seg else None), None
                 net.cut_backbone_grad = False
         loss_dict = self.summarize_losses(loss_dict)
-        loss_dict["total_loss"].backward()  # "ddp": bucketed all-reduce overlapped with backward
+        total = loss_dict["total_loss"]
+        one = getattr(self, "_unit_grad", None)  # (the root gradient as a kept tensor: backward() alone fills a fresh one every step)
+        if one is None or one.device != total.device or one.dtype != total.dtype or one.shape != total.shape:
+            capturing = total.is_cuda and torch.cuda.is_current_stream_capturing()
+            one = None if capturing else torch.ones_like(total)
+            self._unit_grad = one
+        total.backward(one)  # "ddp": bucketed all-reduce overlapped with backward
         return loss_dict, cut
 
     @staticmethod
