@@ -35,4 +35,14 @@ python scripts/bench_legs.py stress > $O/${tag}_stress_leg.json 2>/dev/null
 python scripts/bench_legs.py latency > $O/${tag}_latency_leg.json 2>/dev/null
 python scripts/kernel_resources.py > $O/${tag}_kernel_resources.txt 2>&1
 bash scripts/scale_selftest.sh 2 > $O/${tag}_scale_selftest.log 2>&1
+# dp = flat with a one-rank RCCL group: what the exchange mechanism costs beside the single-graph step
+for i in 1 2 3; do
+python scripts/bench_train.py --graph 2>/dev/null | grep '^{' > $O/${tag}_dp_none_$i.json
+python scripts/bench_train.py --graph --dp-selftest 2>/dev/null | grep '^{' > $O/${tag}_dp_seg1_$i.json
+done
+python scripts/bench_train.py --graph --dp-selftest --segments 2 --no-overlap 2>/dev/null | grep '^{' > $O/${tag}_dp_seg2_inorder.json
+python scripts/bench_train.py --graph --dp-selftest --segments 2 2>/dev/null | grep '^{' > $O/${tag}_dp_seg2_overlap.json
+python scripts/probes/train_step_parts.py 2>/dev/null | grep "ms / iteration\|full step" > $O/${tag}_train_step_parts.txt
+python scripts/probes/train_step_parts.py --dp 2>/dev/null | grep "ms / iteration\|full step" >> $O/${tag}_train_step_parts.txt
+python scripts/probes/scatter_cm_bench.py > $O/${tag}_scatter_cm_bench.txt 2>/dev/null
 tail -3 $O/${tag}_pytest_gpu.log; cat $O/${tag}_bench_train_graph.json; tail -2 $O/${tag}_scale_selftest.log
