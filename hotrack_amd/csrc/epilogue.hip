@@ -136,3 +136,62 @@ extern "C" int pn2x_max_rows(int b, int r, int c, const float *x, float *out, vo
     hipLaunchKernelGGL(max_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, c, x, out);
     return check_launch();
 }
+
+// ---- several device-to-device copies as ONE launch --------------------------------------------------------------------------------
+// The batch hand-over of a graph-captured step (network/trainer.py: a handful of batch leaves + the geometry pack into the captured
+// step's static buffers) was five runtime copy launches in round 5 and one torch multi-tensor launch of 17 us in round 6; the
+// tensors are a few hundred KB.  Table in the kernel arguments (capture-safe, nothing to keep coherent), a workgroup moves 16 KB.
+namespace pn2 {
+constexpr int kCopyMax = 24;
+constexpr long kCopyChunk = 16384;  // bytes per workgroup
+struct CopyPack {
+    char *dst[kCopyMax];
+    const char *src[kCopyMax];
+    long bytes[kCopyMax];
+    int first[kCopyMax + 1];  // first workgroup of every copy
+    int n;
+};
+__global__ void __launch_bounds__(256) copy_multi_kernel(CopyPack a) {
+    int t = 0;
+    const int wg = blockIdx.x;
+    while (t + 1 < a.n && a.first[t + 1] <= wg) ++t;
+    const long off = (long)(wg - a.first[t]) * kCopyChunk;
+    const long n = a.bytes[t];
+    const long end = off + kCopyChunk < n ? off + kCopyChunk : n;
+    char *__restrict__ d = a.dst[t];
+    const char *__restrict__ s = a.src[t];
+    if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0) {
+        long i = off + 16L * threadIdx.x;
+        for (; i + 16 <= end; i += 16L * 256) *reinterpret_cast<float4 *>(d + i) = *reinterpret_cast<const float4 *>(s + i);
+        for (; i < end; ++i) d[i] = s[i];  // (the one thread that meets the last, partial quad)
+    } else {
+        for (long i = off + threadIdx.x; i < end; i += 256) d[i] = s[i];
+    }
+}
+}  // namespace pn2
+
+extern "C" int pn2x_copy_multi_max(void) { return pn2::kCopyMax; }
+
+extern "C" int pn2x_copy_multi(int n, void *const *dst, const void *const *src, const long *bytes, void *stream) {
+    using namespace pn2;
+    if (n < 0 || n > kCopyMax) return PN2_EINVAL;
+    if (n == 0) return PN2_OK;
+    if (!dst || !src || !bytes) return PN2_ENULL;
+    CopyPack a;
+    a.n = n;
+    long wgs = 0;
+    for (int i = 0; i < n; ++i) {
+        if (bytes[i] < 0) return PN2_EINVAL;
+        if (bytes[i] > 0 && (!dst[i] || !src[i])) return PN2_ENULL;
+        a.dst[i] = (char *)dst[i];
+        a.src[i] = (const char *)src[i];
+        a.bytes[i] = bytes[i];
+        a.first[i] = (int)wgs;
+        wgs += (bytes[i] + kCopyChunk - 1) / kCopyChunk;
+    }
+    a.first[n] = (int)wgs;
+    if (wgs > 2147483647L) return PN2_ERANGE;
+    if (wgs == 0) return PN2_OK;
+    hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch();
+}

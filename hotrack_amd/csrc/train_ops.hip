@@ -838,47 +838,63 @@ inverse_index_kernel(int n_dst, int L, const int *__restrict__ idx_all, int *__r
 }
 
 // The same sort for every chunk of mt consecutive positions of a cloud's list on its own (scatter_cm.hip, long lists), with
-// 16-bit outputs (mt <= 65535): workgroup (cloud b, chunk k) -> offsets [b][k][off_stride], order [b][k * mt ...] holding
-// positions RELATIVE to the chunk.
-__global__ void __launch_bounds__(kTT)
+// 16-bit outputs (mt <= 4 * kInvT): workgroup (cloud b, chunk k) -> offsets [b][k][off_stride], order [b][k * mt ...] holding
+// positions RELATIVE to the chunk.  1024 threads: a thread keeps its <= 4 entries' targets in registers between the histogram and the
+// scatter, the counters' prefix sums go per thread (n_dst / 1024 counters) -> per wave (shuffles) -> over the 16 wave totals; the
+// 256-thread version above spent 28 us on 32 serial counters per thread, a 256-entry LDS scan and a second read of the index list.
+constexpr int kInvT = 1024;
+__global__ void __launch_bounds__(kInvT)
 inverse_index_chunked_kernel(int n_dst, int L, int mt, int nchunks, int off_stride, const int *__restrict__ idx_all,
                              unsigned short *__restrict__ offsets_all, unsigned short *__restrict__ order_all) {
-    extern __shared__ int cnt[];  // [n_dst + 1] counts -> running cursors; then [kTT] chunk totals
-    int *part = cnt + n_dst + 1;
+    extern __shared__ int cnt[];  // [n_dst + 1] counts -> running cursors; then [16] wave totals
+    int *wtot = cnt + n_dst + 1;
     const int b = blockIdx.x / nchunks, k = blockIdx.x - b * nchunks;
     const int e0 = k * mt, len = (L - e0) < mt ? (L - e0) : mt;
     const int *__restrict__ idx = idx_all + (size_t)b * L + e0;
     unsigned short *__restrict__ offsets = offsets_all + (size_t)blockIdx.x * off_stride;
     unsigned short *__restrict__ order = order_all + (size_t)b * L + e0;
-    for (int i = threadIdx.x; i <= n_dst; i += kTT) cnt[i] = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int key[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {  // (requested before the counters are cleared: the loads overlap the clearing)
+        const int e = tid + x * kInvT;
+        int t = e < len ? idx[e] : 0;
+        key[x] = t < 0 ? 0 : (t >= n_dst ? n_dst - 1 : t);  // (out-of-range indices cannot corrupt LDS)
+    }
+    for (int i = tid; i <= n_dst; i += kInvT) cnt[i] = 0;
     __syncthreads();
-    auto key = [&](int e) { const int t = idx[e]; return t < 0 ? 0 : (t >= n_dst ? n_dst - 1 : t); };
-    for (int e = threadIdx.x; e < len; e += kTT) atomicAdd(&cnt[key(e)], 1);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+        if (tid + x * kInvT < len) atomicAdd(&cnt[key[x]], 1);
     __syncthreads();
-    const int chunk = (n_dst + kTT - 1) / kTT;
-    const int i0 = threadIdx.x * chunk, i1 = (i0 + chunk) < n_dst ? (i0 + chunk) : n_dst;
+    const int chunk = (n_dst + kInvT - 1) / kInvT;
+    const int i0 = tid * chunk, i1 = (i0 + chunk) < n_dst ? (i0 + chunk) : n_dst;
     int sum = 0;
     for (int i = i0; i < i1; ++i) sum += cnt[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    // exclusive scan of the kTT partial sums: Hillis-Steele in LDS (8 steps; one thread walking them was 256 dependent LDS
-    // round trips, a third of this launch)
-    for (int d = 1; d < kTT; d <<= 1) {
-        const int v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    int incl = sum;  // inclusive scan over the wave's 64 thread sums
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
     }
-    int run = part[threadIdx.x] - sum;
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];  // (<= 15 broadcast reads)
+    int run = base + incl - sum;
     for (int i = i0; i < i1; ++i) {
         const int v = cnt[i];
         offsets[i] = (unsigned short)run;
         cnt[i] = run;  // cursor
         run += v;
     }
-    if (threadIdx.x == 0) offsets[n_dst] = (unsigned short)len;
+    if (tid == 0) offsets[n_dst] = (unsigned short)len;
     __syncthreads();
-    for (int e = threadIdx.x; e < len; e += kTT) order[atomicAdd(&cnt[key(e)], 1)] = (unsigned short)e;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int e = tid + x * kInvT;
+        if (e < len) order[atomicAdd(&cnt[key[x]], 1)] = (unsigned short)e;
+    }
 }
 
 // acc += sum over p = p0, p0 + step, ... < p1 of [w] . row(order[p]), in that order.  Four list entries per round: their source
@@ -1587,9 +1603,9 @@ int inverse_index_launch(int b, int n_dst, int l, const int *idx, int *offsets, 
 
 int inverse_index_chunked_launch(int b, int n_dst, int l, int mt, int nchunks, const int *idx, unsigned short *offsets, int off_stride,
                                  unsigned short *order, hipStream_t st) {
-    const size_t lds = ((size_t)n_dst + 1 + kTT) * sizeof(int);
-    if (lds > 64 * 1024 || mt < 1 || mt > 65535 || (long)nchunks * mt < l || off_stride < n_dst + 1) return PN2_ERANGE;
-    hipLaunchKernelGGL(inverse_index_chunked_kernel, dim3((unsigned)(b * nchunks)), dim3(kTT), lds, st, n_dst, l, mt, nchunks, off_stride, idx,
+    const size_t lds = ((size_t)n_dst + 1 + 16) * sizeof(int);
+    if (lds > 64 * 1024 || mt < 1 || mt > 4 * kInvT || (long)nchunks * mt < l || off_stride < n_dst + 1) return PN2_ERANGE;
+    hipLaunchKernelGGL(inverse_index_chunked_kernel, dim3((unsigned)(b * nchunks)), dim3(kInvT), lds, st, n_dst, l, mt, nchunks, off_stride, idx,
                        offsets, order);
     return check_launch();
 }

@@ -677,3 +677,28 @@ class HandLosses(torch.autograd.Function):
                                                            None if weights is None else weights.data_ptr(), d.data_ptr(),
                                                            _native._stream(pred_hf)), "hand_losses_backward")
         return d, None, None, None, None, None, None, None, None
+
+
+_lib.pn2x_copy_multi_max.restype = _ci
+_lib.pn2x_copy_multi.argtypes = [_ci, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_long), _vp]
+_lib.pn2x_copy_multi.restype = _ci
+
+
+def copy_multi(dsts, srcs) -> None:
+    """dsts[i].copy_(srcs[i]) for same-shaped, same-dtype contiguous tensors on ONE GPU as one launch (pn2x_copy_multi)."""
+    n = len(dsts)
+    if n == 0:
+        return
+    cap = int(_lib.pn2x_copy_multi_max())
+    dev = dsts[0].device
+    for d, s_ in zip(dsts, srcs):
+        if (not d.is_cuda or d.device != dev or s_.device != dev or d.dtype != s_.dtype or d.shape != s_.shape
+                or not d.is_contiguous() or not s_.is_contiguous()):
+            raise ValueError("copy_multi: same-shaped contiguous tensors of one dtype on one GPU")
+    with torch.cuda.device(dev):
+        for i0 in range(0, n, cap):
+            k = min(cap, n - i0)
+            D, S, Bn = (_vp * k)(), (_vp * k)(), (ctypes.c_long * k)()
+            for j in range(k):
+                D[j], S[j], Bn[j] = dsts[i0 + j].data_ptr(), srcs[i0 + j].data_ptr(), dsts[i0 + j].numel() * dsts[i0 + j].element_size()
+            _native._check(_lib.pn2x_copy_multi(k, D, S, Bn, _native._stream(dsts[0])), "copy_multi")

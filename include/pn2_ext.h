@@ -217,6 +217,12 @@ int pn2x_bias_act_pm(long rows, int c, float *y, int ldy, const float *bias, lon
  */
 int pn2x_max_rows(int b, int r, int c, const float *x, float *out, void *stream);
 
+/* n <= pn2x_copy_multi_max() device-to-device copies (dst[i] <- src[i], bytes[i] bytes, non-overlapping) as ONE launch: the batch
+ * hand-over of a graph-captured training step (a few batch tensors + the geometry pack into the captured step's static buffers;
+ * the reference's trainer.py:278-302 moves a batch with one .to(device) per tensor).  The table travels in the kernel arguments. */
+int pn2x_copy_multi_max(void);
+int pn2x_copy_multi(int n, void *const *dst, const void *const *src, const long *bytes, void *stream);
+
 /*
  * out = LN2( LN1( x + y + bias ) ) over the last dimension of row-major (rows, c) data, c <= 1024:
  * torch.nn.functional.layer_norm semantics (biased variance, eps inside the square root), affine (g, b) each.

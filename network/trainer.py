@@ -527,13 +527,13 @@ class Trainer(nn.Module):
         pairs = [(dst, src) for (_, dst), (_, src) in zip(self._leaves(dst_tree), self._leaves(src_tree))] + list(more)
         fast = [(d, s_) for d, s_ in pairs if s_.is_cuda and s_.device == d.device and s_.dtype == d.dtype and s_.shape == d.shape]
         if len(fast) > 1:
-            # one launch needs one dtype: 4-byte leaves of any type (the int32 geometry pack beside the fp32 batch) travel as
-            # float32 bit patterns -- mixed lists took the per-tensor path (five copy launches in front of every step)
-            def bits(t):
-                return t.view(torch.float32) if (t.dtype != torch.float32 and t.element_size() == 4 and t.is_contiguous()) else t
-            fd, fs = [bits(d) for d, _ in fast], [bits(s_) for _, s_ in fast]
-            if all(a_.dtype == fd[0].dtype for a_ in fd + fs):
-                torch._foreach_copy_(fd, fs)
+            # ONE launch of our own (pn2x_copy_multi: the table in the kernel arguments): torch's multi-tensor copy needs one dtype
+            # (the int32 geometry pack beside the fp32 batch took the per-tensor path: five launches) and takes 17 us for these
+            # few hundred KB even then
+            contig = [(d, s_) for d, s_ in fast if d.is_contiguous() and s_.is_contiguous()]
+            if len(contig) == len(fast):
+                from hotrack_amd import ext
+                ext.copy_multi([d for d, _ in fast], [s_ for _, s_ in fast])
             else:
                 torch._foreach_copy_([d for d, _ in fast], [s_ for _, s_ in fast])
         else:

@@ -1018,3 +1018,21 @@ def test_query_module_pair_launches_equal_single_launches(monkeypatch, with_cent
         assert (a is None) == (b is None), i
         if a is not None:
             torch.testing.assert_close(b, a, rtol=2e-4, atol=2e-5 * max(1.0, float(a.abs().max())), msg=lambda m: f"tensor {i}: {m}")
+
+
+def test_copy_multi_equals_tensor_copies():
+    """pn2x_copy_multi (the batch hand-over of the captured step as one launch): mixed dtypes, sizes around the 16 KB chunk, a
+    1-element tensor, more tensors than one launch takes."""
+    from hotrack_amd import ext
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(32, 1024, 3), (32, 21, 3), (1,), (4097,), (16384 // 4,), (5, 7, 11)] + [(37 + i,) for i in range(30)]
+    srcs = []
+    for i, sh in enumerate(shapes):
+        t = torch.randn(sh, device="cuda", generator=g)
+        srcs.append(t if i % 3 else (t * 1000).to(torch.int32))
+    dsts = [torch.zeros_like(s) for s in srcs]
+    ext.copy_multi(dsts, srcs)
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    with pytest.raises(ValueError):
+        ext.copy_multi([dsts[0]], [srcs[1]])
