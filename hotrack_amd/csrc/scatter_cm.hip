@@ -35,7 +35,10 @@ constexpr int kScT = 1024;  // 16 waves per workgroup: the LDS slab allows only 
 
 // LDS: [cc][m_src] slice of grad_out | offsets (n_dst + 1) | order (L) | weights (L, T == 3): the inverted lists are walked
 // from LDS too (per-item dependent global loads -- offsets, then order, then the value -- were a latency chain).
-template <int T>
+// INV: the workgroup inverts its cloud's index list itself (counting sort in LDS: offsets_all is then the raw index list
+// (b, L), order_all unused) -- for the short lists of the HandTrackNet shapes the separate inversion launch was a third of the
+// operator's time (interp_bwd 22 us = inversion 8 + sums 14), and the sort of <= 8192 entries costs a workgroup ~2 us.
+template <int T, bool INV>
 __global__ void __launch_bounds__(kScT)
 cm_segment_sum_kernel(int c, int n_dst, int m_src, int cc, const float *__restrict__ grad_out_all, const int *__restrict__ offsets_all,
                       const int *__restrict__ order_all, const float *__restrict__ weight_all, float *__restrict__ grad_points_all) {
@@ -44,6 +47,7 @@ cm_segment_sum_kernel(int c, int n_dst, int m_src, int cc, const float *__restri
     int *loff = reinterpret_cast<int *>(G + (size_t)cc * m_src);
     int *lord = loff + n_dst + 1;
     float *lw = reinterpret_cast<float *>(lord + L);
+    int *lcur = reinterpret_cast<int *>(lw + (T == 3 ? L : 0));  // INV: [n_dst] scatter cursors, then [16] wave totals
     const int b = blockIdx.y, c0 = blockIdx.x * cc;
     const int nc = (c - c0) < cc ? (c - c0) : cc;
     const float *__restrict__ src = grad_out_all + ((size_t)b * c + c0) * m_src;
@@ -53,15 +57,50 @@ cm_segment_sum_kernel(int c, int n_dst, int m_src, int cc, const float *__restri
     } else {
         for (int i = threadIdx.x; i < tot; i += kScT) G[i] = src[i];
     }
-    const int *__restrict__ offsets = offsets_all + (size_t)b * (n_dst + 1);
-    const int *__restrict__ order = order_all + (size_t)b * L;
-    for (int i = threadIdx.x; i <= n_dst; i += kScT) loff[i] = offsets[i];
-    for (int i = threadIdx.x; i < L; i += kScT) lord[i] = order[i];
     if constexpr (T == 3) {
         const float *__restrict__ weight = weight_all + (size_t)b * L;
         for (int i = threadIdx.x; i < L; i += kScT) lw[i] = weight[i];
     }
-    __syncthreads();
+    if constexpr (!INV) {
+        const int *__restrict__ offsets = offsets_all + (size_t)b * (n_dst + 1);
+        const int *__restrict__ order = order_all + (size_t)b * L;
+        for (int i = threadIdx.x; i <= n_dst; i += kScT) loff[i] = offsets[i];
+        for (int i = threadIdx.x; i < L; i += kScT) lord[i] = order[i];
+        __syncthreads();
+    } else {
+        const int *__restrict__ idx = offsets_all + (size_t)b * L;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        int *wtot = lcur + n_dst;
+        auto key = [&](int e) { const int t = idx[e]; return t < 0 ? 0 : (t >= n_dst ? n_dst - 1 : t); };  // (bad indices cannot corrupt LDS)
+        for (int i = tid; i <= n_dst; i += kScT) loff[i] = 0;
+        __syncthreads();
+        for (int e = tid; e < L; e += kScT) atomicAdd(&loff[key(e)], 1);
+        __syncthreads();
+        const int chunk = (n_dst + kScT - 1) / kScT;
+        const int i0 = tid * chunk, i1 = (i0 + chunk) < n_dst ? (i0 + chunk) : n_dst;
+        int sum = 0;
+        for (int i = i0; i < i1; ++i) sum += loff[i];
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int run = incl - sum;
+        for (int w = 0; w < wave; ++w) run += wtot[w];
+        for (int i = i0; i < i1; ++i) {
+            const int v = loff[i];
+            loff[i] = run;
+            lcur[i] = run;
+            run += v;
+        }
+        if (tid == 0) loff[n_dst] = L;
+        __syncthreads();
+        for (int e = tid; e < L; e += kScT) lord[atomicAdd(&lcur[key(e)], 1)] = e;
+        __syncthreads();
+    }
     float *__restrict__ dst = grad_points_all + ((size_t)b * c + c0) * n_dst;
     const int total = n_dst * nc;
     constexpr int U = 4;  // items per thread in flight
@@ -290,8 +329,13 @@ int scatter_cm_dispatch(int t, int b, int c, int n_dst, int m_src, const float *
     const size_t l = (size_t)m_src * t;
     const size_t meta = (size_t)n_dst + 1 + l * (t == 3 ? 2 : 1);  // ints / floats next to the slab
     if (!mt && ((size_t)n_dst + 1 + 256 > 16384 || meta + m_src > 16384)) return PN2_ERANGE;  // 64 KiB of LDS per workgroup
+    // short lists: the workgroups sort the list themselves (one launch, no scratch); LDS then also holds n_dst cursors + 16 wave totals
+    const size_t meta_inv = meta + (size_t)n_dst + 16;
+    const bool inv = !mt && l <= 8192 && meta_inv + m_src <= 16384;
     StreamScratch own;  // released in stream order when this call returns (after the launches below)
-    if (!scratch) {
+    if (inv) {
+        // (no scratch needed: the reference-signature entries work inside a graph capture for these shapes too)
+    } else if (!scratch) {
         scratch = own.acquire(need, st);
         if (!scratch) return PN2_ERANGE;
     } else if (scratch_ints < need) {
@@ -314,19 +358,27 @@ int scatter_cm_dispatch(int t, int b, int c, int n_dst, int m_src, const float *
         }
 #undef PN2_CH
     }
-    int cc = (int)((16384 - meta) / m_src);
+    const size_t meta_used = inv ? meta_inv : meta;
+    int cc = (int)((16384 - meta_used) / m_src);
     if (cc > 16) cc = 16;
     if (cc > c) cc = c;
     while (cc > 1 && (long)b * ((c + cc - 1) / cc) < 512) cc = (cc + 1) / 2;  // >= 2 workgroups of 16 waves per CU
+    const dim3 grid((c + cc - 1) / cc, b);
+    const size_t lds = ((size_t)cc * m_src + meta_used) * sizeof(float);
+    if (inv) {
+        if (t == 1)
+            hipLaunchKernelGGL((cm_segment_sum_kernel<1, true>), grid, dim3(kScT), lds, st, c, n_dst, m_src, cc, grad_out, idx, (const int *)nullptr, weight, grad_points);
+        else
+            hipLaunchKernelGGL((cm_segment_sum_kernel<3, true>), grid, dim3(kScT), lds, st, c, n_dst, m_src, cc, grad_out, idx, (const int *)nullptr, weight, grad_points);
+        return check_launch();
+    }
     int *offsets = scratch, *order = scratch + (size_t)b * (n_dst + 1);
     int rc = inverse_index_launch(b, n_dst, (int)l, idx, offsets, order, st);
     if (rc != PN2_OK) return rc;
-    const dim3 grid((c + cc - 1) / cc, b);
-    const size_t lds = ((size_t)cc * m_src + meta) * sizeof(float);
     if (t == 1)
-        hipLaunchKernelGGL(cm_segment_sum_kernel<1>, grid, dim3(kScT), lds, st, c, n_dst, m_src, cc, grad_out, offsets, order, weight, grad_points);
+        hipLaunchKernelGGL((cm_segment_sum_kernel<1, false>), grid, dim3(kScT), lds, st, c, n_dst, m_src, cc, grad_out, offsets, order, weight, grad_points);
     else
-        hipLaunchKernelGGL(cm_segment_sum_kernel<3>, grid, dim3(kScT), lds, st, c, n_dst, m_src, cc, grad_out, offsets, order, weight, grad_points);
+        hipLaunchKernelGGL((cm_segment_sum_kernel<3, false>), grid, dim3(kScT), lds, st, c, n_dst, m_src, cc, grad_out, offsets, order, weight, grad_points);
     return check_launch();
 }
 

@@ -208,7 +208,36 @@ def test_knn(ops, oracle, B, n, m, k, kind):
 
 GROUP_CASES = [(4, 3, 1024, 256, 32), (4, 0, 1024, 256, 32), (4, 64, 256, 128, 32), (2, 384, 1024, 21, 16),
                (2, 384, 1024, 21, 64), (2, 5, 100, 7, 3), (1, 67, 8192, 2048, 64), (2, 1, 1, 1, 1), (2, 130, 333, 10, 5),
-               (8, 33, 8192, 1024, 64), (5, 30, 16384, 2048, 64)]  # the last two take the LDS-staged forward (rows beyond L2)
+               (8, 33, 8192, 1024, 64), (5, 30, 16384, 2048, 64),  # the last two take the LDS-staged forward (rows beyond L2)
+               # long position lists -> the chunked atomics-free backward (scatter_cm.hip, round 6): odd list lengths (scalar staging, a
+               # partial last chunk), one / odd channel counts (ragged channel group), more than 8192 points (two target ranges),
+               # 4 and 8 targets per thread
+               (2, 5, 9000, 1667, 9), (1, 1, 12000, 3000, 7), (3, 4, 4097, 700, 30), (2, 7, 3000, 2100, 8), (1, 3, 15000, 4099, 5)]
+
+
+def test_group_points_grad_long_lists_with_padding_skew(ops):
+    """The chunked backward on the kind of list a ball query produces at the configs[4] shape: every group's tail repeats its first
+    index (padding), a few points are everybody's neighbour (thousands of contributions to one target inside one chunk: the
+    per-target list walk runs long), most points receive nothing.  Against an fp64 index_add."""
+    B, C, N, P, S = 2, 6, 8192, 2048, 64
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, N, (B, P, S), generator=g)
+    fill = torch.randint(1, S, (B, P, 1), generator=g)                      # valid entries per group
+    pos = torch.arange(S).view(1, 1, S)
+    idx = torch.where(pos < fill, idx, idx[:, :, :1].expand(-1, -1, S))     # padding = the group's first index
+    hot = torch.randint(0, N, (B, 4), generator=g)
+    idx[:, ::7, 0] = hot[:, :1]                                             # hot targets: ~300 groups x up to 64 repeats
+    idx[:, 1::11, 0] = hot[:, 1:2]
+    idx = torch.where(pos < fill, idx, idx[:, :, :1].expand(-1, -1, S)).to(torch.int32)
+    feat = torch.randn(B, C, N, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(B, C, P, S, generator=g).cuda()
+    out = ops.grouping_operation(feat, idx.cuda())
+    out.backward(go)
+    ref = torch.zeros(B, C, N, dtype=torch.float64)
+    ref.scatter_add_(2, idx.long().view(B, 1, P * S).expand(-1, C, -1), go.cpu().double().view(B, C, P * S))
+    err = float((feat.grad.cpu().double() - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), (err, float(ref.abs().max()))  # (a hot target sums ~10^4 values)
+    assert int((ref.abs().sum(1) == 0).sum()) > 0  # ... and some points received nothing
 
 
 @pytest.mark.parametrize("B,C,N,P,S", GROUP_CASES)
