@@ -292,8 +292,11 @@ class FastTrain:
         if self.ws is None or self.ws.buf.device != dev:
             self.ws = Workspace(dev)
         self.ws.reset()  # one fill launch: the fp64 accumulators of every BatchNorm reduction of this step, both directions
-        xyz = xyz2_cm.detach().transpose(1, 2).contiguous()   # (B,N,3)
-        kp = xyz1_cm.detach().transpose(1, 2).contiguous()    # (B,J,3)
+        if geo is not None and geo.get("frame") is not None:  # the geometry stage's own point-major buffers (no copies here)
+            xyz, kp = geo["frame"][2], geo["frame"][3]
+        else:
+            xyz = xyz2_cm.detach().transpose(1, 2).contiguous()   # (B,N,3)
+            kp = xyz1_cm.detach().transpose(1, 2).contiguous()    # (B,J,3)
         B, N, _ = xyz.shape
         J = kp.shape[1]
         if geo is None:

@@ -171,6 +171,9 @@ class HandTrackNet(nn.Module):
                                    hand_points.contiguous(), 0.2)
             geo = self._ftrain.geometry(frame[2], frame[3], with_inverse=True)
         geo["frame"] = tuple(frame)
+        # the keypoints channel-major (B,3,kp), contiguous: what the pose head and the loss kernel read -- a batch-only copy
+        # that otherwise sits in the dense step (one 5 us launch in front of the tail)
+        geo["xyz1_cm"] = frame[3].transpose(1, 2).contiguous()
         return geo
 
     def forward(self, input, flag_dict):
@@ -215,6 +218,8 @@ class HandTrackNet(nn.Module):
             R, t, xyz2_pm, xyz1_pm = geo["frame"]
             canon_pose = {"scale": _scale_const(hand_points.device), "rotation": R, "translation": t}
             xyz2, xyz1 = xyz2_pm.transpose(1, 2), xyz1_pm.transpose(1, 2)
+            if geo.get("xyz1_cm") is not None:
+                xyz1 = geo["xyz1_cm"]  # (already contiguous: the copy below is then a no-op)
         elif self._fast_train_frame_ok(hand_points, palm_template, kp_num, use_ft):
             # training on the GPU: the hand frame (Kabsch of the palm template + canonicalisation of cloud and keypoints) as ONE
             # launch, as in the inference path -- no gradient flows through it (inputs only); the torch composition below is
