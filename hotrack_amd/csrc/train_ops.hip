@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(kTT)
 bn_relu_max_kernel(long groups, int K, int C, const float *__restrict__ Y, int ldy, const double *__restrict__ sums,
                    const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ conv_bias, float eps,
                    float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
-                   float *__restrict__ save_mean, float *__restrict__ save_invstd, float *__restrict__ out, int *__restrict__ arg) {
+                   float *__restrict__ save_mean, float *__restrict__ save_invstd, float *__restrict__ out, int ldo, int *__restrict__ arg) {
     const int Q = C >> 2;
     const long item = (long)blockIdx.x * kTT + threadIdx.x;
     const long rows = groups * K;
@@ -211,7 +211,7 @@ bn_relu_max_kernel(long groups, int K, int C, const float *__restrict__ Y, int l
         for (int i = 0; i < 4; ++i)
             if (h[i] > m[i] || h[i] != h[i]) { m[i] = h[i]; am[i] = kk; }  // a NaN sticks (h > NaN is false afterwards), as torch's max
     }
-    *reinterpret_cast<float4 *>(out + grp * C + 4 * q) = make_float4(relu_nan(m[0]), relu_nan(m[1]), relu_nan(m[2]), relu_nan(m[3]));
+    *reinterpret_cast<float4 *>(out + grp * ldo + 4 * q) = make_float4(relu_nan(m[0]), relu_nan(m[1]), relu_nan(m[2]), relu_nan(m[3]));
     *reinterpret_cast<int4 *>(arg + grp * C + 4 * q) = make_int4(am[0], am[1], am[2], am[3]);
 }
 
@@ -223,7 +223,7 @@ bn_relu_max_kernel(long groups, int K, int C, const float *__restrict__ Y, int l
 // constants are computed once per workgroup (the serial kernel derives them per thread from the fp64 sums).
 struct MaxSplitArgs {
     long groups; int K, C, S; const float *Y; int ldy; const double *sums; const float *gamma, *beta, *conv_bias; float eps, momentum;
-    float *running_mean, *running_var; long long *nbt; float *save_mean, *save_invstd, *out; int *arg;
+    float *running_mean, *running_var; long long *nbt; float *save_mean, *save_invstd, *out; int *arg; int ldo;  // out rows ldo floats apart (a column block of a wider buffer)
 };
 __device__ __forceinline__ void bn_relu_max_split_body(const MaxSplitArgs &A, unsigned bx) {
     const long groups = A.groups;
@@ -320,7 +320,7 @@ __device__ __forceinline__ void bn_relu_max_split_body(const MaxSplitArgs &A, un
                 }
             }
         }
-        *reinterpret_cast<float4 *>(out + grp * C + 4 * q) = make_float4(relu_nan(m[0]), relu_nan(m[1]), relu_nan(m[2]), relu_nan(m[3]));
+        *reinterpret_cast<float4 *>(out + grp * A.ldo + 4 * q) = make_float4(relu_nan(m[0]), relu_nan(m[1]), relu_nan(m[2]), relu_nan(m[3]));
         *reinterpret_cast<int4 *>(arg + grp * C + 4 * q) = make_int4(am[0], am[1], am[2], am[3]);
     }
 }
@@ -1381,8 +1381,18 @@ extern "C" int pn2x_bn_relu_max(long groups, int k, int c, const float *y, int l
                                 const float *beta, const float *conv_bias, float eps, float momentum, float *running_mean,
                                 float *running_var, long long *num_batches_tracked, float *save_mean, float *save_invstd, float *out,
                                 int *arg, void *stream) {
+    return pn2x_bn_relu_max_ld(groups, k, c, y, ldy, sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
+                               num_batches_tracked, save_mean, save_invstd, out, c, arg, stream);
+}
+
+// ... with the output rows ldo floats apart: `out` may be a column block of a wider (groups x ldo) buffer -- the two scales of a
+// module write the two halves of ONE tensor instead of being concatenated by a copy launch (round 6)
+extern "C" int pn2x_bn_relu_max_ld(long groups, int k, int c, const float *y, int ldy, const double *sums, const float *gamma,
+                                   const float *beta, const float *conv_bias, float eps, float momentum, float *running_mean,
+                                   float *running_var, long long *num_batches_tracked, float *save_mean, float *save_invstd, float *out,
+                                   int ldo, int *arg, void *stream) {
     using namespace pn2;
-    if (groups < 1 || k < 1 || bad_c(c) || ldy < c || ldy % 4) return PN2_EINVAL;
+    if (groups < 1 || k < 1 || bad_c(c) || ldy < c || ldy % 4 || ldo < c || ldo % 4) return PN2_EINVAL;
     if (!y || !sums || !gamma || !beta || !save_mean || !save_invstd || !out || !arg) return PN2_ENULL;
     if (((uintptr_t)y | (uintptr_t)out | (uintptr_t)arg) % 16) return PN2_EINVAL;
     const long items = groups * (c / 4);
@@ -1391,13 +1401,13 @@ extern "C" int pn2x_bn_relu_max(long groups, int k, int c, const float *y, int l
     if (split >= 4) {
         const int ipb = kTT / split;
         const MaxSplitArgs a{groups, k, c, split, y, ldy, sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
-                             num_batches_tracked, save_mean, save_invstd, out, arg};
+                             num_batches_tracked, save_mean, save_invstd, out, arg, ldo};
         hipLaunchKernelGGL(bn_relu_max_split_kernel, dim3((unsigned)((items + ipb - 1) / ipb)), dim3(kTT), 0, (hipStream_t)stream, a);
         return check_launch();
     }
     hipLaunchKernelGGL(bn_relu_max_kernel, dim3((unsigned)((items + kTT - 1) / kTT)), dim3(kTT), 0, (hipStream_t)stream, groups, k, c, y, ldy,
                        sums, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd,
-                       out, arg);
+                       out, ldo, arg);
     return check_launch();
 }
 
@@ -1410,6 +1420,19 @@ extern "C" int pn2x_bn_relu_max_pair(long groups_a, int k_a, int c_a, const floa
                                      const float *beta_b, const float *conv_bias_b, float eps_b, float momentum_b, float *running_mean_b,
                                      float *running_var_b, long long *nbt_b, float *save_mean_b, float *save_invstd_b, float *out_b, int *arg_b,
                                      void *stream) {
+    return pn2x_bn_relu_max_pair_ld(groups_a, k_a, c_a, y_a, ldy_a, sums_a, gamma_a, beta_a, conv_bias_a, eps_a, momentum_a, running_mean_a,
+                                    running_var_a, nbt_a, save_mean_a, save_invstd_a, out_a, c_a, arg_a, groups_b, k_b, c_b, y_b, ldy_b, sums_b,
+                                    gamma_b, beta_b, conv_bias_b, eps_b, momentum_b, running_mean_b, running_var_b, nbt_b, save_mean_b,
+                                    save_invstd_b, out_b, c_b, arg_b, stream);
+}
+
+extern "C" int pn2x_bn_relu_max_pair_ld(long groups_a, int k_a, int c_a, const float *y_a, int ldy_a, const double *sums_a, const float *gamma_a,
+                                        const float *beta_a, const float *conv_bias_a, float eps_a, float momentum_a, float *running_mean_a,
+                                        float *running_var_a, long long *nbt_a, float *save_mean_a, float *save_invstd_a, float *out_a, int ldo_a,
+                                        int *arg_a, long groups_b, int k_b, int c_b, const float *y_b, int ldy_b, const double *sums_b,
+                                        const float *gamma_b, const float *beta_b, const float *conv_bias_b, float eps_b, float momentum_b,
+                                        float *running_mean_b, float *running_var_b, long long *nbt_b, float *save_mean_b, float *save_invstd_b,
+                                        float *out_b, int ldo_b, int *arg_b, void *stream) {
     using namespace pn2;
     auto split_of = [](long groups, int k, int c) {
         const long items = groups * (c / 4);
@@ -1418,21 +1441,21 @@ extern "C" int pn2x_bn_relu_max_pair(long groups_a, int k_a, int c_a, const floa
         return split;
     };
     const bool ok_a = groups_a >= 1 && k_a >= 1 && !bad_c(c_a) && ldy_a >= c_a && ldy_a % 4 == 0 && y_a && sums_a && gamma_a && beta_a &&
-                      save_mean_a && save_invstd_a && out_a && arg_a && (((uintptr_t)y_a | (uintptr_t)out_a | (uintptr_t)arg_a) % 16) == 0;
+                      save_mean_a && save_invstd_a && out_a && arg_a && (((uintptr_t)y_a | (uintptr_t)out_a | (uintptr_t)arg_a) % 16) == 0 && ldo_a >= c_a && ldo_a % 4 == 0;
     const bool ok_b = groups_b >= 1 && k_b >= 1 && !bad_c(c_b) && ldy_b >= c_b && ldy_b % 4 == 0 && y_b && sums_b && gamma_b && beta_b &&
-                      save_mean_b && save_invstd_b && out_b && arg_b && (((uintptr_t)y_b | (uintptr_t)out_b | (uintptr_t)arg_b) % 16) == 0;
+                      save_mean_b && save_invstd_b && out_b && arg_b && (((uintptr_t)y_b | (uintptr_t)out_b | (uintptr_t)arg_b) % 16) == 0 && ldo_b >= c_b && ldo_b % 4 == 0;
     const int sa = ok_a ? split_of(groups_a, k_a, c_a) : 1, sb = ok_b ? split_of(groups_b, k_b, c_b) : 1;
     if (!ok_a || !ok_b || sa < 4 || sb < 4) {
-        const int rc = pn2x_bn_relu_max(groups_a, k_a, c_a, y_a, ldy_a, sums_a, gamma_a, beta_a, conv_bias_a, eps_a, momentum_a, running_mean_a,
-                                        running_var_a, nbt_a, save_mean_a, save_invstd_a, out_a, arg_a, stream);
+        const int rc = pn2x_bn_relu_max_ld(groups_a, k_a, c_a, y_a, ldy_a, sums_a, gamma_a, beta_a, conv_bias_a, eps_a, momentum_a, running_mean_a,
+                                           running_var_a, nbt_a, save_mean_a, save_invstd_a, out_a, ldo_a, arg_a, stream);
         if (rc != PN2_OK) return rc;
-        return pn2x_bn_relu_max(groups_b, k_b, c_b, y_b, ldy_b, sums_b, gamma_b, beta_b, conv_bias_b, eps_b, momentum_b, running_mean_b,
-                                running_var_b, nbt_b, save_mean_b, save_invstd_b, out_b, arg_b, stream);
+        return pn2x_bn_relu_max_ld(groups_b, k_b, c_b, y_b, ldy_b, sums_b, gamma_b, beta_b, conv_bias_b, eps_b, momentum_b, running_mean_b,
+                                   running_var_b, nbt_b, save_mean_b, save_invstd_b, out_b, ldo_b, arg_b, stream);
     }
     const MaxSplitArgs a{groups_a, k_a, c_a, sa, y_a, ldy_a, sums_a, gamma_a, beta_a, conv_bias_a, eps_a, momentum_a, running_mean_a,
-                         running_var_a, nbt_a, save_mean_a, save_invstd_a, out_a, arg_a};
+                         running_var_a, nbt_a, save_mean_a, save_invstd_a, out_a, arg_a, ldo_a};
     const MaxSplitArgs b{groups_b, k_b, c_b, sb, y_b, ldy_b, sums_b, gamma_b, beta_b, conv_bias_b, eps_b, momentum_b, running_mean_b,
-                         running_var_b, nbt_b, save_mean_b, save_invstd_b, out_b, arg_b};
+                         running_var_b, nbt_b, save_mean_b, save_invstd_b, out_b, arg_b, ldo_b};
     const long ia = groups_a * (c_a / 4), ib = groups_b * (c_b / 4);
     const unsigned na = (unsigned)((ia + kTT / sa - 1) / (kTT / sa)), nb = (unsigned)((ib + kTT / sb - 1) / (kTT / sb));
     hipLaunchKernelGGL(bn_relu_max_split_pair_kernel, dim3(na + nb), dim3(kTT), 0, (hipStream_t)stream, a, b, na);

@@ -298,6 +298,11 @@ _lib.pn2x_bn_bwd_reduce_routed_pair.argtypes = _lib.pn2x_bn_bwd_reduce_routed.ar
 _lib.pn2x_bn_bwd_reduce_routed_pair.restype = _ci
 _lib.pn2x_bn_relu_max_pair.argtypes = _t._lib.pn2x_bn_relu_max.argtypes[:-1] * 2 + [_vp]
 _lib.pn2x_bn_relu_max_pair.restype = _ci
+_MAX_LD = _t._lib.pn2x_bn_relu_max.argtypes[:-2] + [_ci, _vp]  # (..., out, ldo, arg): the output rows ldo floats apart
+_lib.pn2x_bn_relu_max_ld.argtypes = _MAX_LD + [_vp]
+_lib.pn2x_bn_relu_max_ld.restype = _ci
+_lib.pn2x_bn_relu_max_pair_ld.argtypes = _MAX_LD * 2 + [_vp]
+_lib.pn2x_bn_relu_max_pair_ld.restype = _ci
 _lib.pn2x_bn_bwd_apply_rel_pair.argtypes = _lib.pn2x_bn_bwd_apply_rel.argtypes[:-1] * 2 + [_vp]
 _lib.pn2x_bn_bwd_apply_rel_pair.restype = _ci
 _lib.pn2x_bn_bwd_apply_rel_scratch_floats.argtypes = [_cl, _ci]
@@ -328,7 +333,8 @@ class Layer:
 # keypoint-query module).  Everything else is launched where it stands.
 class _Fwd:
     @staticmethod
-    def gen(y1, K, ws, metas, aux, tensors):
+    def gen(y1, K, ws, metas, aux, tensors, out_dst=None):
+        # out_dst: (G, C) view of a wider buffer the max-pooled top writes into (the scales of a module: no concatenation launch)
         # tensors: per layer (weight | placeholder, gamma, beta, conv bias | placeholder); metas: per layer (running_mean, running_var, nbt, eps, momentum)
         L = len(metas)
         R, C1 = y1.shape
@@ -377,11 +383,15 @@ class _Fwd:
             arg = None
             if K:
                 G = R // K
-                out = torch.empty((G, C), dtype=_f32, device=dev)
+                if (out_dst is not None and tuple(out_dst.shape) == (G, C) and out_dst.stride(1) == 1 and out_dst.stride(0) % 4 == 0
+                        and out_dst.data_ptr() % 16 == 0 and out_dst.dtype == _f32):
+                    out = out_dst
+                else:
+                    out = torch.empty((G, C), dtype=_f32, device=dev)
                 arg = torch.empty((G, C), dtype=torch.int32, device=dev)
                 yield ("max", (G, K, C, yl.data_ptr(), yl.stride(0), ws_f[L - 1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(bias),
                                float(eps), float(mom), _p(rm), _p(rv), _p(nbt), sv[0].data_ptr(), sv[1].data_ptr(), out.data_ptr(),
-                               arg.data_ptr()), st, dev)  # (issued by _drive: alone, or with the sibling stack's as one pair launch)
+                               out.stride(0) if G > 1 else C, arg.data_ptr()), st, dev)  # (issued by _drive: alone, or with the sibling stack's as one pair launch)
             else:
                 out = torch.empty((R, C), dtype=_f32, device=dev)
                 _native._check(_lib.pn2x_bn_relu_apply(R, C, yl.data_ptr(), yl.stride(0), ws_f[L - 1].data_ptr(), gamma.data_ptr(),
@@ -573,7 +583,7 @@ def _issue(req):
             _native._check(_lib.pn2x_bn_bwd_apply_rel(*args, st), "bn_bwd_apply_rel")
             return None
         if kind == "max":
-            _native._check(_lib.pn2x_bn_relu_max(*args, st), "bn_relu_max")
+            _native._check(_lib.pn2x_bn_relu_max_ld(*args, st), "bn_relu_max")
             return None
         if kind == "routed":
             _native._check(_lib.pn2x_bn_bwd_reduce_routed(*args, st), "bn_bwd_reduce_routed")
@@ -592,7 +602,7 @@ def _issue_pair(a, b):
             _native._check(_lib.pn2x_bn_bwd_apply_rel_pair(*a[1], *b[1], st), "bn_bwd_apply_rel_pair")
             return None, None
         if kind == "max":
-            _native._check(_lib.pn2x_bn_relu_max_pair(*a[1], *b[1], st), "bn_relu_max_pair")
+            _native._check(_lib.pn2x_bn_relu_max_pair_ld(*a[1], *b[1], st), "bn_relu_max_pair")
             return None, None
         if kind == "routed":
             _native._check(_lib.pn2x_bn_bwd_reduce_routed_pair(*a[1], *b[1], st), "bn_bwd_reduce_routed_pair")
@@ -679,6 +689,31 @@ class _StackPair(torch.autograd.Function):
         return (ra[0], rb[0], None, None, None, None, None, None, None, None, *ra[1], *rb[1])
 
 
+class _StackPairCat(torch.autograd.Function):
+    """_StackPair whose two max-pooled tops write the two column blocks of ONE (G, Ca + Cb) tensor -- what a multi-scale module
+    returns (reference pointnet_utils.py:405-409, :583-590: `torch.cat(new_points_list, dim=1)`) -- instead of being concatenated by a
+    copy launch; the backward reads its two column blocks of the incoming gradient in place."""
+
+    @staticmethod
+    def forward(ctx, y1a, y1b, Ka, Kb, ws, metas_a, metas_b, aux_a, aux_b, n_a, *tensors):
+        ca, cb = tensors[n_a - 3].shape[0], tensors[-3].shape[0]  # (the last layers' BatchNorm weights)
+        both = torch.empty((y1a.shape[0] // Ka, ca + cb), dtype=_f32, device=y1a.device)
+        ra, rb = _drive([_Fwd.gen(y1a, Ka, ws, metas_a, aux_a, tensors[:n_a], both[:, :ca]),
+                         _Fwd.gen(y1b, Kb, ws, metas_b, aux_b, tensors[n_a:], both[:, ca:])], y1a.device)
+        if ra[0].data_ptr() != both.data_ptr() or rb[0].data_ptr() != both.data_ptr() + 4 * ca:  # (a top that could not take the view)
+            both = torch.cat([ra[0], rb[0]], dim=1)
+        ctx.save_for_backward(*ra[1], *rb[1])
+        ctx.split, ctx.infos, ctx.ca = len(ra[1]), (ra[2], rb[2]), ca
+        return both
+
+    @staticmethod
+    def backward(ctx, dboth):
+        t = ctx.saved_tensors
+        da, db = dboth[:, :ctx.ca], dboth[:, ctx.ca:]
+        ra, rb = _drive([_Bwd.gen(ctx.infos[0], t[:ctx.split], da), _Bwd.gen(ctx.infos[1], t[ctx.split:], db)], dboth.device)
+        return (ra[0], rb[0], None, None, None, None, None, None, None, None, *ra[1], *rb[1])
+
+
 def mlp_stack(y1: torch.Tensor, layers, ws, max_over: int = 0, aux=None) -> torch.Tensor:
     """relu(BN_L(... relu(BN_1(y1)) W_2^T ...)), optionally followed by the max over every `max_over` consecutive rows.
     y1 (R, C_1) pre-activations of layer 1 (without the conv bias: it cancels in the normalisation); layers: list of Layer;
@@ -715,7 +750,7 @@ def _stack_inputs(y1, layers):
     return metas, tensors
 
 
-def mlp_stack_pair(y1a, y1b, layers_a, layers_b, ws, max_over_a: int = 0, max_over_b: int = 0, aux_a=None, aux_b=None):
+def mlp_stack_pair(y1a, y1b, layers_a, layers_b, ws, max_over_a: int = 0, max_over_b: int = 0, aux_a=None, aux_b=None, cat: bool = False):
     """mlp_stack for TWO stacks at once: (mlp_stack(y1a, layers_a, ...), mlp_stack(y1b, layers_b, ...)), with the fused launches of
     layers of equal shape grouped into one launch each (forward and backward).  For the neighbourhood sizes of a multi-scale
     module: same widths, different weights, different row counts."""
@@ -726,6 +761,13 @@ def mlp_stack_pair(y1a, y1b, layers_a, layers_b, ws, max_over_a: int = 0, max_ov
             raise ValueError("mlp_stack_pair: rows must be a multiple of max_over")
     metas_a, tensors_a = _stack_inputs(y1a, layers_a)
     metas_b, tensors_b = _stack_inputs(y1b, layers_b)
+    if (cat and max_over_a and max_over_b and y1a.shape[0] // max_over_a == y1b.shape[0] // max_over_b
+            and layers_a[-1].bn.weight.shape[0] % 4 == 0 and layers_b[-1].bn.weight.shape[0] % 4 == 0):
+        # cat = True: ONE (G, Ca + Cb) tensor = torch.cat((out_a, out_b), dim=1), written in place by the two tops
+        return _StackPairCat.apply(y1a, y1b, int(max_over_a), int(max_over_b), ws, metas_a, metas_b, aux_a, aux_b, len(tensors_a), *tensors_a, *tensors_b)
+    if cat:
+        oa, ob = _StackPair.apply(y1a, y1b, int(max_over_a), int(max_over_b), ws, metas_a, metas_b, aux_a, aux_b, len(tensors_a), *tensors_a, *tensors_b)
+        return torch.cat([oa, ob], dim=1)
     return _StackPair.apply(y1a, y1b, int(max_over_a), int(max_over_b), ws, metas_a, metas_b, aux_a, aux_b, len(tensors_a), *tensors_a, *tensors_b)
 
 

@@ -407,6 +407,18 @@ int pn2x_bn_relu_max_pair(long groups_a, int k_a, int c_a, const float *y_a, int
                           const float *beta_b, const float *conv_bias_b, float eps_b, float momentum_b, float *running_mean_b,
                           float *running_var_b, long long *nbt_b, float *save_mean_b, float *save_invstd_b, float *out_b, int *arg_b,
                           void *stream);
+/* the same with the output rows ldo floats apart (`out` = a column block of a wider buffer: the scales of a multi-scale module,
+ * reference pointnet_utils.py:405-409 / :583-590 `torch.cat(new_points_list, dim=1)`, write the halves of one tensor) */
+int pn2x_bn_relu_max_ld(long groups, int k, int c, const float *y, int ldy, const double *sums, const float *gamma, const float *beta,
+                        const float *conv_bias, float eps, float momentum, float *running_mean, float *running_var,
+                        long long *num_batches_tracked, float *save_mean, float *save_invstd, float *out, int ldo, int *arg, void *stream);
+int pn2x_bn_relu_max_pair_ld(long groups_a, int k_a, int c_a, const float *y_a, int ldy_a, const double *sums_a, const float *gamma_a,
+                             const float *beta_a, const float *conv_bias_a, float eps_a, float momentum_a, float *running_mean_a,
+                             float *running_var_a, long long *nbt_a, float *save_mean_a, float *save_invstd_a, float *out_a, int ldo_a,
+                             int *arg_a, long groups_b, int k_b, int c_b, const float *y_b, int ldy_b, const double *sums_b,
+                             const float *gamma_b, const float *beta_b, const float *conv_bias_b, float eps_b, float momentum_b,
+                             float *running_mean_b, float *running_var_b, long long *nbt_b, float *save_mean_b, float *save_invstd_b,
+                             float *out_b, int ldo_b, int *arg_b, void *stream);
 int pn2x_bn_relu_max_bwd(long groups, int k, int c, const float *dout, const int *arg, const float *y, int ldy, const float *mean,
                          const float *invstd, const float *gamma, const float *beta, double *sums, float *dy, int ldo, float *dgamma,
                          float *dbeta, float *dbias, void *stream);

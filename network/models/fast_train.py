@@ -191,8 +191,8 @@ class FastTrain:
                         ws=self.ws)
         outs = []
         pair = self._pair_stacks(mod, y1s, idxs, aux) if len(y1s) == 2 else None
-        if pair is not None:  # both neighbourhood sizes layer by layer, equal-shaped fused launches grouped (train_stack.mlp_stack_pair)
-            outs = [h.view(B, S, -1) for h in pair]
+        if pair is not None:  # both neighbourhood sizes layer by layer, equal-shaped fused launches grouped (train_stack.mlp_stack_pair);
+            return pair.view(B, S, -1)  # their tops wrote the two halves of the module's output (no concatenation launch)
         else:
             for i, y1 in enumerate(y1s):
                 K = idxs[i].shape[2]
@@ -217,7 +217,7 @@ class FastTrain:
             stacks.append((y1.view(-1, y1.shape[-1]), layers, idxs[i].shape[2]))
         (ya, la, ka), (yb, lb, kb) = stacks
         return train_stack.mlp_stack_pair(ya, yb, la, lb, self.ws, ka, kb, aux_a=None if aux is None else (aux, 0),
-                                          aux_b=None if aux is None else (aux, 1))
+                                          aux_b=None if aux is None else (aux, 1), cat=True)
 
     def _fp(self, mod, xyz1, xyz2, points1, points2, extra=None, nn3=None):
         """xyz1 (B,N,3), xyz2 (B,S,3), points1 (B,N,D1)|None, points2 (B,S,D2) -> (B*N, D') rows.
