@@ -48,6 +48,8 @@ class _SplitCols(torch.autograd.Function):
     def backward(ctx, *grads):
         rows, dtype, dev = ctx.meta
         parts = [g if g is not None else torch.zeros((rows, n), dtype=dtype, device=dev) for g, n in zip(grads, ctx.sizes)]
+        if len(parts) == 1:  # one block = the whole weight (sa1: xyz columns only): its gradient as it is, no copy launch
+            return (parts[0].reshape(rows, -1),) + (None,)
         return (torch.cat(parts, dim=1),) + (None,) * len(ctx.sizes)
 
 
