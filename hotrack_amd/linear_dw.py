@@ -80,9 +80,68 @@ def _eye(n: int, dev):
     return None if t is None else t[:n, :n]
 
 
+# ---- a tensor used by TWO consumers: its two input gradients summed by the earlier consumer's product, not by an add launch ------
+# autograd sums the gradients a twice-used tensor receives with an element-wise launch (four of them per training step: the
+# tail's two residual connections, the two backbone levels that feed both the next level and a skip connection).  The later
+# consumer (in forward order; its backward runs first) reads the tensor through tap(x, stash): its gradient is parked in the
+# stash instead of being returned; the earlier consumer -- a product of this module given the same stash -- forms its input
+# gradient as  parked + g W  (addmm into the parked tensor).  Either order of the two backwards is handled: a product that
+# finds nothing parked marks the stash done, and the tap then returns its gradient the ordinary way.
+FUSE_GRAD_SUMS = True  # (module attribute: tests set it False to compare with autograd's own sums)
+
+
+class GradStash:
+    __slots__ = ("g", "armed", "done")
+
+    def __init__(self):
+        self.g, self.armed, self.done = None, False, False
+
+
+class _Tap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stash):
+        ctx.stash = stash
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.stash
+        if g is None or not st.armed or st.done or st.g is not None:
+            return g, None  # (nobody will pick it up: the ordinary path)
+        st.g = g
+        return None, None
+
+
+def tap(x: torch.Tensor, stash) -> torch.Tensor:
+    """x for its LATER consumer (see above); identity when stash is None or the fusion is off."""
+    if stash is None or not FUSE_GRAD_SUMS or not x.requires_grad:
+        return x
+    return _Tap.apply(x, stash)
+
+
+def _arm(stash, x):
+    if stash is not None and FUSE_GRAD_SUMS and x.requires_grad:
+        stash.armed = True
+        return stash
+    return None
+
+
+def _dx_with_stash(stash, g, w):
+    """g . w, plus the gradient parked in `stash` (accumulated into the parked tensor itself)."""
+    if stash is not None:
+        parked, stash.g, stash.done = stash.g, None, True
+        if (parked is not None and parked.is_contiguous() and parked.dtype == g.dtype and parked.device == g.device
+                and parked.numel() == g.shape[0] * w.shape[1]):
+            return parked.view(g.shape[0], w.shape[1]).addmm_(g, w)
+        dx = torch.mm(g, w)
+        return dx if parked is None else dx.add_(parked.reshape(dx.shape))
+    return torch.mm(g, w)
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, stash=None):
+        ctx.stash = _arm(stash, x)
         w2 = weight.view(weight.shape[0], -1)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -93,7 +152,7 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         w2 = weight.view(weight.shape[0], -1)
-        dx = torch.mm(g, w2) if ctx.needs_input_grad[0] else None
+        dx = _dx_with_stash(ctx.stash, g, w2) if ctx.needs_input_grad[0] else None
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and ctx.bias is not None
         dw = db = None
         params = ([weight] if ctx.needs_input_grad[1] else []) + ([ctx.bias] if want_b else [])
@@ -116,12 +175,13 @@ class _Linear(torch.autograd.Function):
                 dw = torch.mm(g.t(), x).view(weight.shape)
             if want_b:
                 db = g.sum(0)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
-    """x (R, C_in) . weight^T (+ bias): `weight` the PARAMETER itself, (C_out, C_in) or a 1x1 convolution's (C_out, C_in, 1[, 1])."""
-    return _Linear.apply(x, weight, bias)
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, stash=None) -> torch.Tensor:
+    """x (R, C_in) . weight^T (+ bias): `weight` the PARAMETER itself, (C_out, C_in) or a 1x1 convolution's (C_out, C_in, 1[, 1]).
+    stash: a GradStash shared with tap(x, stash) at x's later consumer (the two input gradients are then summed by this product)."""
+    return _Linear.apply(x, weight, bias, stash)
 
 
 class _LinearBlocks(torch.autograd.Function):
@@ -132,7 +192,8 @@ class _LinearBlocks(torch.autograd.Function):
     wider gradient to be copied); weight gradients per column block at the end of the pass."""
 
     @staticmethod
-    def forward(ctx, weight, reps, *xs):
+    def forward(ctx, weight, reps, stashes, *xs):
+        ctx.stashes = tuple(_arm(st, x) for st, x in zip(stashes, xs)) if stashes is not None else (None,) * len(xs)
         w2 = weight.view(weight.shape[0], -1)
         y, col, cols = None, 0, []
         order = sorted(range(len(xs)), key=lambda i: reps[i] != 1)  # a full-rows block first: it creates y
@@ -167,11 +228,11 @@ class _LinearBlocks(torch.autograd.Function):
             return gs[n]
         dxs = []
         for i, x in enumerate(xs):
-            if not ctx.needs_input_grad[2 + i]:
+            if not ctx.needs_input_grad[3 + i]:
                 dxs.append(None)
                 continue
             wb = w2[:, cols[i]:cols[i] + x.shape[1]]
-            dxs.append(torch.mm(g if reps[i] == 1 else gsum(reps[i]), wb))
+            dxs.append(_dx_with_stash(ctx.stashes[i], g if reps[i] == 1 else gsum(reps[i]), wb))
         dw = None
         if ctx.needs_input_grad[0]:
             if g.is_cuda and _defer_ok([weight]):
@@ -183,15 +244,15 @@ class _LinearBlocks(torch.autograd.Function):
                 dw = dw.view(weight.shape)
             else:
                 dw = torch.cat([torch.mm((g if reps[i] == 1 else gsum(reps[i])).t(), x) for i, x in enumerate(xs)], dim=1).view(weight.shape)
-        return (dw, None, *dxs)
+        return (dw, None, None, *dxs)
 
 
-def linear_blocks(blocks, weight: torch.Tensor) -> torch.Tensor:
+def linear_blocks(blocks, weight: torch.Tensor, stashes=None) -> torch.Tensor:
     """torch.nn.functional.linear(cat(blocks, dim=1), weight) without materialising the concatenation.  blocks: list of X (R, k)
     or (X (R / n, k), n) -- a block whose rows are each repeated n times; weight: the PARAMETER (N, sum k[, 1[, 1]])."""
     xs = [b[0] if isinstance(b, tuple) else b for b in blocks]
     reps = tuple(int(b[1]) if isinstance(b, tuple) else 1 for b in blocks)
-    return _LinearBlocks.apply(weight, reps, *xs)
+    return _LinearBlocks.apply(weight, reps, None if stashes is None else tuple(stashes), *xs)
 
 
 class _PerPoint(torch.autograd.Function):
@@ -200,7 +261,8 @@ class _PerPoint(torch.autograd.Function):
     block (C_s, Dc) (only for weights that have one)."""
 
     @staticmethod
-    def forward(ctx, x, D, sizes, share, *ws):
+    def forward(ctx, x, D, sizes, share, stash, *ws):
+        ctx.stash = _arm(stash, x)
         w2 = [w.view(w.shape[0], -1) for w in ws]
         blocks = [w[:, :D] for w in w2]
         # ONE product over the feature blocks of every scale of every module (rows of one stacked weight); a module's a1f is its
@@ -247,7 +309,7 @@ class _PerPoint(torch.autograd.Function):
                     col += g.shape[1] if g.dim() == 2 else 0
                 whole = whole and col == buf.shape[1]
             if whole:
-                dx = torch.mm(buf, wf_all)
+                dx = _dx_with_stash(ctx.stash, buf, wf_all)
             else:
                 row = 0
                 for m, n_ in enumerate(sizes):
@@ -255,13 +317,15 @@ class _PerPoint(torch.autograd.Function):
                     if ga[m] is not None:
                         wfm = wf_all[row:row + width]
                         if dx is None:
-                            dx = torch.mm(ga[m], wfm)
+                            dx = _dx_with_stash(ctx.stash, ga[m], wfm)
                         else:
                             dx.addmm_(ga[m], wfm)
                     row += width
+                if dx is None and ctx.stash is not None:  # (no module sent a gradient: what is parked goes on as it is)
+                    dx, ctx.stash.g, ctx.stash.done = ctx.stash.g, None, True
             if ctx.share is not None:
                 ctx.share["buf"] = None
-        live = [w for j, w in enumerate(ws) if ctx.needs_input_grad[4 + j]]
+        live = [w for j, w in enumerate(ws) if ctx.needs_input_grad[5 + j]]
         defer = bool(live) and x.is_cuda and _defer_ok(live)
         xx = _rows(x) if defer else x
         dws, i = [], 0
@@ -273,7 +337,7 @@ class _PerPoint(torch.autograd.Function):
             for j in range(i, i + n):
                 w = w2[j]
                 C = w.shape[0]
-                if not ctx.needs_input_grad[4 + j]:
+                if not ctx.needs_input_grad[5 + j]:
                     dws.append(None)
                     c0 += C
                     continue
@@ -298,10 +362,10 @@ class _PerPoint(torch.autograd.Function):
                 dws.append(full.view(ws[j].shape))
                 c0 += C
             i += n
-        return (dx, None, None, None, *dws)
+        return (dx, None, None, None, None, *dws)
 
 
-def per_point_first_layer(x: torch.Tensor, groups, D: int):
+def per_point_first_layer(x: torch.Tensor, groups, D: int, stash=None):
     """groups: per module the list of its scales' first-layer weight PARAMETERS (C_s, D + 3 [+ Dc][, 1, 1]).
     -> (a1f per module (R, sum_s C_s) -- column blocks of ONE product --, [per module [per scale (xyz block, centre block | None)]],
     share).  `share` (a dict, or None for a single module) lets the consumers' backward write the gradients of the a1f blocks into
@@ -310,7 +374,7 @@ def per_point_first_layer(x: torch.Tensor, groups, D: int):
     sizes = tuple(len(g) for g in groups)
     ws = [w for g in groups for w in g]
     share = {} if len(sizes) > 1 else None
-    outs = _PerPoint.apply(x, int(D), sizes, share, *ws)
+    outs = _PerPoint.apply(x, int(D), sizes, share, stash, *ws)
     nm, nw = len(sizes), len(ws)
     a1f = list(outs[:nm])
     wx = list(outs[nm:nm + nw])

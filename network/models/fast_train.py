@@ -142,12 +142,12 @@ class FastTrain:
             return linear(x2d, conv.weight, bias)
         return F.linear(x2d, _w2d(conv), bias)
 
-    def _per_point(self, feat2d, mods, D):
+    def _per_point(self, feat2d, mods, D, stash=None):
         """Per module (first-layer blocks [(None, xyz block, centre block | None) per scale], feat2d . W_f^T): the per-point halves of
         the first layers of `mods`, which all read the same rows (one Function: one input gradient, deferred weight gradients)."""
         from hotrack_amd.linear_dw import per_point_first_layer
         groups = [[convs[0].weight for convs in m.conv_blocks] for m in mods]
-        a1f, blocks, share = per_point_first_layer(feat2d, groups, D)
+        a1f, blocks, share = per_point_first_layer(feat2d, groups, D, stash=stash)
         # (share, m): where module m's backward leaves the gradient of its a1f block -- one buffer for all modules, so that the
         # input gradient of the per-point product is one GEMM (hotrack_amd.linear_dw._PerPoint)
         return [([(None, wx, wc) for wx, wc in b], a, (share, m)) for m, (b, a) in enumerate(zip(blocks, a1f))]
@@ -162,7 +162,7 @@ class FastTrain:
             wf = w1[0][0] if len(w1) == 1 else torch.cat([w[0] for w in w1], dim=0)
         return w1, wf
 
-    def _sa_scales(self, mod, xyz, cxyz, feat2d, idxs, center2d=None, pre=None, invs=None):
+    def _sa_scales(self, mod, xyz, cxyz, feat2d, idxs, center2d=None, pre=None, invs=None, feat_stash=None):
         """All scales of one SA module.  xyz (B,N,3), cxyz (B,S,3), feat2d (B*N, D)|None, center2d (B*S, D2)|None ->
         (B, S, sum C3) point-major.  pre = (w1, a1f2d): the first-layer blocks and the per-point product feat2d wf^T computed by
         the caller (_Linear2Shared)."""
@@ -177,7 +177,7 @@ class FastTrain:
             a1f_share = pre[2] if len(pre) > 2 else None
             a1f = a1f2d.view(B, N, -1)
         elif D and self.defer_wgrad:
-            (w1, a1f2d, _), = self._per_point(feat2d, [mod], D)
+            (w1, a1f2d, _), = self._per_point(feat2d, [mod], D, stash=feat_stash)
             a1f = a1f2d.view(B, N, -1)
         else:
             w1, wf = self._first_layer_blocks(mod, D, center2d is not None)
@@ -307,19 +307,23 @@ class FastTrain:
         # ---- backbone: sa1, sa2, sa3 (group-all), fp3, fp2, fp1, conv1 -------------------------------------------------
         S1, S2 = bh.sa1.npoint, bh.sa2.npoint
         l1_xyz, l2_xyz = geo["l1_xyz"], geo["l2_xyz"]
+        from hotrack_amd.linear_dw import GradStash, tap
+        # l1_feat / l2_feat each feed the next level AND a skip connection: the later consumer reads them through tap(), the
+        # earlier one's product sums both input gradients (linear_dw: no element-wise add launch in the backward)
+        st1, st2 = (GradStash(), GradStash()) if (self.defer_wgrad and self.use_fused_stacks) else (None, None)
         l1_feat = self._sa_scales(bh.sa1, xyz, l1_xyz, None, [geo["idx1"]])                            # (B,S1,64)
         l2_feat = self._sa_scales(bh.sa2, l1_xyz, l2_xyz, l1_feat.reshape(B * S1, -1), [geo["idx2"]],
-                                  invs=None if geo["inv2"] is None else [geo["inv2"]])                  # (B,S2,128)
+                                  invs=None if geo["inv2"] is None else [geo["inv2"]], feat_stash=st1)  # (B,S2,128)
         # group-all: [xyz | feat], centre = origin (not subtracted)
         if self.defer_wgrad and self.use_fused_stacks:
             from hotrack_amd.linear_dw import linear_blocks
-            y1 = linear_blocks([l2_xyz.reshape(B * S2, 3), l2_feat.reshape(B * S2, -1)], bh.sa3.mlp_convs[0].weight)
+            y1 = linear_blocks([l2_xyz.reshape(B * S2, 3), l2_feat.reshape(B * S2, -1)], bh.sa3.mlp_convs[0].weight, stashes=[None, st2])
             l3 = self._stack(y1, bh.sa3.mlp_convs, bh.sa3.mlp_bns, first_done=True, max_over=S2).view(B, 1, -1)  # (B,1,512)
         else:
             x = torch.cat([l2_xyz, l2_feat], dim=2).view(B * S2, -1)
             l3 = self._stack(x, bh.sa3.mlp_convs, bh.sa3.mlp_bns, max_over=S2).view(B, 1, -1)
-        l2_out = self._fp(bh.fp3, l2_xyz, l2_xyz[:, :1], l2_feat, l3).view(B, S2, -1)
-        l1_out = self._fp(bh.fp2, l1_xyz, l2_xyz, l1_feat, l2_out, nn3=geo["fp2"]).view(B, S1, -1)
+        l2_out = self._fp(bh.fp3, l2_xyz, l2_xyz[:, :1], tap(l2_feat, st2), l3).view(B, S2, -1)
+        l1_out = self._fp(bh.fp2, l1_xyz, l2_xyz, tap(l1_feat, st1), l2_out, nn3=geo["fp2"]).view(B, S1, -1)
         # fp1 (skip = xyz) and the backbone's conv1 / bn1 as one stack [131 -> 128 -> 128 -> C]
         src2 = self._fp(bh.fp1, xyz, l1_xyz, xyz, l1_out, extra=(bh.conv1, bh.bn1), nn3=geo["fp1"])    # (B*N, C)
         src2 = net.cut_after_backbone(src2)  # (a fresh leaf when the trainer runs the backward in two segments: hand_network.py)
@@ -441,14 +445,17 @@ class FastTail:
         grads = T.TailGrads(dev, 14 * C + 2 * H + Hf + 3 * Hf + 3)
         pd = lambda m: float(m.p) if m.training else 0.0
         if DEFER_WGRAD:
-            from hotrack_amd.linear_dw import linear as lin
+            from hotrack_amd.linear_dw import GradStash, linear as lin, tap
+            sa, sb = GradStash(), GradStash()  # h / h2 feed their block's first product AND its residual: one input gradient each
         else:
-            lin = lambda x, w: F.linear(x, w.view(w.shape[0], -1))
+            lin = lambda x, w, stash=None: F.linear(x, w.view(w.shape[0], -1))
+            tap = lambda x, stash: x
+            sa = sb = None
         h = T.ln(rows, s11.norm1, c11.norm1, grads, seed_dev=self.seed, seed_out=seed_used)
-        d = T.relu_dropout(lin(h, c11.linear1.weight), c11.linear1.bias, pd(c11.dropout2), 1, seed_used, grads)
-        h2 = T.ln(h, c11.norm2, c3.norm1, grads, y=lin(d, c11.linear2.weight), bias=c11.linear2.bias, p=pd(c11.dropout3), site=2, seed_in=seed_used)
-        d2 = T.relu_dropout(lin(h2, c3.linear1.weight), c3.linear1.bias, pd(c3.dropout2), 3, seed_used, grads)
-        h3 = T.ln(h2, c3.norm2, None, grads, y=lin(d2, c3.linear2.weight), bias=c3.linear2.bias, p=pd(c3.dropout3), site=4, seed_in=seed_used)
+        d = T.relu_dropout(lin(h, c11.linear1.weight, stash=sa), c11.linear1.bias, pd(c11.dropout2), 1, seed_used, grads)
+        h2 = T.ln(tap(h, sa), c11.norm2, c3.norm1, grads, y=lin(d, c11.linear2.weight), bias=c11.linear2.bias, p=pd(c11.dropout3), site=2, seed_in=seed_used)
+        d2 = T.relu_dropout(lin(h2, c3.linear1.weight, stash=sb), c3.linear1.bias, pd(c3.dropout2), 3, seed_used, grads)
+        h3 = T.ln(tap(h2, sb), c3.norm2, None, grads, y=lin(d2, c3.linear2.weight), bias=c3.linear2.bias, p=pd(c3.dropout3), site=4, seed_in=seed_used)
         hf = T.relu_dropout(lin(h3, net.final_mlp[0].weight), net.final_mlp[0].bias, 0.0, 0, None, grads)
         # last Conv1d + residual on the initial keypoints + de-canonicalisation: one launch per direction
         return T.pose_head(hf, net.final_mlp[2].weight.squeeze(-1), net.final_mlp[2].bias, xyz1, canon_pose["rotation"],

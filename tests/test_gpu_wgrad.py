@@ -261,3 +261,47 @@ def test_linear_blocks_equals_linear_of_the_concatenation(mode):
     for got, want in zip((y1.detach(), xb.grad, xc.grad, conv.weight.grad), ref):
         assert got.shape == want.shape
         assert float((got - want).abs().max()) <= 3e-5 * float(want.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("order", ["product_first", "tap_first"])
+def test_twice_used_tensor_gradient_sum_inside_the_product(order):
+    """linear_dw.tap / GradStash: a tensor read by a product AND by a later consumer gets ONE input gradient, parked by the later
+    consumer and summed by the product's addmm -- equal to autograd's own sum (FUSE_GRAD_SUMS = False), in the intended order of
+    the two backwards and in the other one (the tap created before the product: the product then finds nothing parked and the
+    tap returns its gradient the ordinary way)."""
+    from hotrack_amd import linear_dw as L
+    dev = torch.device("cuda")
+    torch.manual_seed(1)
+    lin1, lin2 = torch.nn.Linear(48, 40).to(dev), torch.nn.Linear(7, 24).to(dev)
+    w3 = torch.nn.Parameter(torch.randn(16, 48 + 7, device=dev))
+    x0 = torch.randn(300, 48, device=dev)
+    z0 = torch.randn(300, 7, device=dev)
+
+    def run(fuse):
+        L.FUSE_GRAD_SUMS = fuse
+        for p in (*lin1.parameters(), *lin2.parameters(), w3):
+            p.grad = None
+        x = (x0 * 1.0).requires_grad_(True)
+        z = (z0 * 1.0).requires_grad_(True)
+        xs = x * 1.5  # (non-leaf: both consumers send it a gradient)
+        zs = z * 0.5
+        st, st2 = L.GradStash(), L.GradStash()
+        if order == "product_first":
+            a = L.linear(xs, lin1.weight, lin1.bias, stash=st)
+            b = L.linear_blocks([xs, zs], w3, stashes=[None, st2])
+            later = torch.tanh(L.tap(xs, st)).sum() + (L.tap(zs, st2) ** 2).sum()
+        else:
+            tx, tz = L.tap(xs, st), L.tap(zs, st2)
+            later = torch.tanh(tx).sum() + (tz ** 2).sum()
+            a = L.linear(xs, lin1.weight, lin1.bias, stash=st)
+            b = L.linear_blocks([xs, zs], w3, stashes=[None, st2])
+        loss = (a * a).mean() + b.sum() * 0.01 + later * 0.1 + L.linear(zs, lin2.weight, lin2.bias).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return [x.grad.clone(), z.grad.clone()] + [p.grad.clone() for p in (*lin1.parameters(), *lin2.parameters(), w3)]
+    try:
+        got, ref = run(True), run(False)
+    finally:
+        L.FUSE_GRAD_SUMS = True
+    for g, r in zip(got, ref):
+        torch.testing.assert_close(g, r, rtol=1e-5, atol=1e-6)
