@@ -204,13 +204,21 @@ bn_relu_max_kernel(long groups, int K, int C, const float *__restrict__ Y, int l
     const float *__restrict__ y = Y + grp * K * ldy + 4 * q;
     float m[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     int am[4] = {0, 0, 0, 0};
-    for (int kk = 0; kk < K; ++kk) {
-        const float4 v = *reinterpret_cast<const float4 *>(y + (long)kk * ldy);
+    auto take = [&](const float4 v, int kk) {
         const float h[4] = {bn_act(v.x, k, 0), bn_act(v.y, k, 1), bn_act(v.z, k, 2), bn_act(v.w, k, 3)};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (h[i] > m[i] || h[i] != h[i]) { m[i] = h[i]; am[i] = kk; }  // a NaN sticks (h > NaN is false afterwards), as torch's max
+    };
+    int kk = 0;
+    for (; kk + 3 < K; kk += 4) {  // four rows in flight (the scan is one dependent-in-time load per row otherwise); same order
+        const float4 v0 = *reinterpret_cast<const float4 *>(y + (long)kk * ldy);
+        const float4 v1 = *reinterpret_cast<const float4 *>(y + (long)(kk + 1) * ldy);
+        const float4 v2 = *reinterpret_cast<const float4 *>(y + (long)(kk + 2) * ldy);
+        const float4 v3 = *reinterpret_cast<const float4 *>(y + (long)(kk + 3) * ldy);
+        take(v0, kk); take(v1, kk + 1); take(v2, kk + 2); take(v3, kk + 3);
     }
+    for (; kk < K; ++kk) take(*reinterpret_cast<const float4 *>(y + (long)kk * ldy), kk);
     *reinterpret_cast<float4 *>(out + grp * ldo + 4 * q) = make_float4(relu_nan(m[0]), relu_nan(m[1]), relu_nan(m[2]), relu_nan(m[3]));
     *reinterpret_cast<int4 *>(arg + grp * C + 4 * q) = make_int4(am[0], am[1], am[2], am[3]);
 }
