@@ -303,13 +303,21 @@ __device__ __forceinline__ void bn_relu_max_split_body(const MaxSplitArgs &A, un
 #pragma unroll
         for (int i = 0; i < 4; ++i) { k.mean[i] = cst[0][t0 + i]; k.invstd[i] = cst[1][t0 + i]; k.g[i] = cst[2][t0 + i]; k.b[i] = cst[3][t0 + i]; }
         const float *__restrict__ y = Y + grp * K * ldy + 4 * q;
-        for (int kk = ks; kk < K; kk += S) {
-            const float4 v = *reinterpret_cast<const float4 *>(y + (long)kk * ldy);
+        auto take = [&](const float4 v, int kk) {
             const float h[4] = {bn_act(v.x, k, 0), bn_act(v.y, k, 1), bn_act(v.z, k, 2), bn_act(v.w, k, 3)};
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (h[i] > m[i] || h[i] != h[i]) { m[i] = h[i]; am[i] = kk; }
+        };
+        int kk = ks;
+        for (; kk + 3 * S < K; kk += 4 * S) {  // this lane's rows four at a time (loads in flight together), same order
+            const float4 v0 = *reinterpret_cast<const float4 *>(y + (long)kk * ldy);
+            const float4 v1 = *reinterpret_cast<const float4 *>(y + (long)(kk + S) * ldy);
+            const float4 v2 = *reinterpret_cast<const float4 *>(y + (long)(kk + 2 * S) * ldy);
+            const float4 v3 = *reinterpret_cast<const float4 *>(y + (long)(kk + 3 * S) * ldy);
+            take(v0, kk); take(v1, kk + S); take(v2, kk + 2 * S); take(v3, kk + 3 * S);
         }
+        for (; kk < K; kk += S) take(*reinterpret_cast<const float4 *>(y + (long)kk * ldy), kk);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { pm[threadIdx.x][i] = m[i]; pa[threadIdx.x][i] = am[i]; }
